@@ -1,0 +1,122 @@
+"""ctypes binding of libgenie_hip.so (C ABI: include/genie_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, this raises.  The oracle under
+oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgenie_hip.so")
+
+PREC_EXACT, PREC_BF16 = 0, 1
+LAYOUT_TOKEN_MAJOR, LAYOUT_BCTHW = 0, 1
+UNMASK_RANDOM, UNMASK_GREEDY = 0, 1
+E_ARG, E_SHAPE, E_UNSUPPORTED, E_LAUNCH, E_ASSERT = -1, -2, -3, -4, -5
+
+c_f32p = C.c_void_p  # device pointers travel as plain integers
+c_ptr = C.c_void_p
+
+
+class GenieCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_layers", "num_heads", "head_dim", "d_model", "T", "S", "hidden", "factored_vocab", "num_factored",
+        "image_vocab_size", "qk_norm", "use_mup", "qkv_bias", "proj_bias", "mlp_bias")] + [
+        ("attn_scale", C.c_float), ("readout_mult", C.c_float), ("precision", C.c_int32)]
+
+
+class AttnWeights(C.Structure):
+    _fields_ = [(n, c_ptr) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "norm_w", "norm_b", "qkv_w16", "proj_w16")]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("norm1_w", c_ptr), ("norm1_b", c_ptr), ("spatial", AttnWeights), ("temporal", AttnWeights),
+                ("norm2_w", c_ptr), ("norm2_b", c_ptr), ("fc1_w", c_ptr), ("fc1_b", c_ptr), ("fc2_w", c_ptr),
+                ("fc2_b", c_ptr), ("fc1_w16", c_ptr), ("fc2_w16", c_ptr)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("pos_embed", c_ptr), ("mask_embed", c_ptr), ("embed", c_ptr * 4), ("out_w", c_ptr),
+                ("out_b", c_ptr), ("out_w16", c_ptr), ("layers_host", C.POINTER(LayerWeights))]
+
+
+# name -> (restype, argtypes); must list every symbol include/genie_hip.h declares
+SIGNATURES = {
+    "genie_version": (C.c_int, []),
+    "genie_last_error": (C.c_char_p, []),
+    "genie_check_config": (C.c_int, [C.POINTER(GenieCfg)]),
+    "genie_workspace_bytes": (C.c_size_t, [C.POINTER(GenieCfg), C.c_int]),
+    "genie_pack_bf16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_embed": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, c_ptr, c_ptr]),
+    "genie_layer_norm": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
+    "genie_linear": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "genie_spatial_attention": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, c_ptr]),
+    "genie_temporal_attention": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, c_ptr]),
+    "genie_attention_core": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_ptr,
+                                       c_ptr, c_ptr]),
+    "genie_st_block_forward": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(LayerWeights), c_ptr, C.c_int, c_ptr,
+                                         C.c_size_t, c_ptr]),
+    "genie_decoder_forward": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, c_ptr, C.c_size_t,
+                                        c_ptr]),
+    "genie_readout_logits": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_compute_logits": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_factored_ce": (C.c_int, [C.POINTER(GenieCfg), c_ptr, C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int,
+                                    c_ptr, c_ptr]),
+    "genie_readout_ce": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, c_ptr, c_ptr, C.c_int, C.c_int,
+                                   C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_sample": (C.c_int, [C.POINTER(GenieCfg), c_ptr, C.c_int, C.c_int, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "genie_mask_step": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, C.c_int64, C.c_int,
+                                  C.c_int, c_ptr]),
+    "genie_maskgit_generate": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr, c_ptr,
+                                         C.c_size_t, c_ptr]),
+    "genie_bits_from_tokens": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
+}
+
+_lib = None
+
+
+class GenieHipError(RuntimeError):
+    def __init__(self, code, where, msg):
+        super().__init__(f"{where}: libgenie_hip error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python 1xgpt_amd/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU fallback for the HIP path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if lib.genie_version() != 1:
+            raise RuntimeError(f"libgenie_hip ABI version {lib.genie_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc, where):
+    if rc != 0:
+        msg = load().genie_last_error().decode(errors="replace")
+        if rc == E_ASSERT:
+            raise AssertionError(msg)
+        if rc == E_UNSUPPORTED and "unmask_mode" in msg:
+            raise NotImplementedError(msg)
+        raise GenieHipError(rc, where, msg)
+
+
+def make_cfg(config, precision=PREC_EXACT) -> GenieCfg:
+    return GenieCfg(
+        num_layers=config.num_layers, num_heads=config.num_heads, head_dim=config.d_model // config.num_heads,
+        d_model=config.d_model, T=config.T, S=config.S, hidden=int(config.d_model * config.mlp_ratio),
+        factored_vocab=config.factored_vocab_size, num_factored=config.num_factored_vocabs,
+        image_vocab_size=config.image_vocab_size, qk_norm=int(config.qk_norm), use_mup=int(config.use_mup),
+        qkv_bias=int(config.qkv_bias), proj_bias=int(config.proj_bias), mlp_bias=int(config.mlp_bias),
+        attn_scale=config.attn_scale, readout_mult=config.readout_mult, precision=precision)

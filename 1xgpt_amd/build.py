@@ -1,0 +1,48 @@
+"""Build libgenie_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python 1xgpt_amd/build.py            # rebuild if sources are newer than the library
+    python 1xgpt_amd/build.py --force
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgenie_hip.so")
+SOURCES = ["api.hip", "kernels_exact.hip", "kernels_bf16.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "genie_hip.h"))
+    objs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc, "-x", "hip", "-c", s, "-o", o] + FLAGS
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-o", LIB] + objs + ["--offload-arch=gfx950"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

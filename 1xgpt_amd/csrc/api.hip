@@ -1,0 +1,387 @@
+// C ABI of libgenie_hip.so (include/genie_hip.h): argument checking, workspace carving and the
+// launch sequences of STBlock / decoder / readout / MaskGIT.  All work is enqueued on the caller's
+// stream; nothing here allocates, synchronises or touches the host-side of any tensor.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// Workspace carving.  All offsets 256-byte aligned.
+struct Workspace {
+    float* x;        // (M, d)      residual stream, f32 in both precisions
+    void* xn;        // (M, d)      LayerNorm output, then attention output (f32 | bf16)
+    void* big;       // (M, max(3d, hidden))  qkv, later the MLP hidden (f32 | bf16)
+    float* logits;   // (M, V)      token-major logits scratch
+    int64_t* samples;  // (B, S)
+    float* conf;       // (B, S)
+    uint8_t* unmasked; // (B, S)
+    size_t total;
+};
+
+static Workspace carve(const genie_cfg& c, int B, void* base) {
+    Workspace w;
+    const size_t M = (size_t)B * c.T * c.S;
+    const size_t wide = (size_t)(3 * c.d_model > c.hidden ? 3 * c.d_model : c.hidden);
+    const size_t V = (size_t)c.factored_vocab * c.num_factored;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* r = p ? (void*)(p + off) : nullptr;
+        off += align_up(bytes, 256);
+        return r;
+    };
+    w.x = (float*)take(M * c.d_model * 4);
+    w.xn = take(M * c.d_model * 4);
+    w.big = take(M * wide * 4);
+    w.logits = (float*)take(M * V * 4);
+    w.samples = (int64_t*)take((size_t)B * c.S * 8);
+    w.conf = (float*)take((size_t)B * c.S * 4);
+    w.unmasked = (uint8_t*)take((size_t)B * c.S);
+    w.total = off;
+    return w;
+}
+
+static int check_cfg(const genie_cfg* c) {
+    GENIE_CHECK_ARG(c != nullptr, "cfg is NULL");
+    GENIE_CHECK_SHAPE(c->num_layers >= 1 && c->num_heads >= 1, "num_layers/num_heads must be >= 1");
+    GENIE_CHECK_SHAPE(c->d_model == c->num_heads * c->head_dim, "d_model %d != num_heads %d * head_dim %d", c->d_model,
+                      c->num_heads, c->head_dim);
+    GENIE_CHECK_SHAPE(c->head_dim == 16 || c->head_dim == 32 || c->head_dim == 64,
+                      "head_dim %d unsupported (16/32/64)", c->head_dim);
+    GENIE_CHECK_SHAPE(c->d_model % 16 == 0 && c->d_model <= 2048, "d_model %d must be a multiple of 16, <= 2048",
+                      c->d_model);
+    GENIE_CHECK_SHAPE(c->hidden % 16 == 0 && c->hidden > 0, "hidden %d must be a positive multiple of 16", c->hidden);
+    GENIE_CHECK_SHAPE(c->T >= 1 && c->T <= 64 && (c->T & (c->T - 1)) == 0, "T=%d must be a power of two <= 64", c->T);
+    GENIE_CHECK_SHAPE(c->S >= 1 && c->S <= 1024, "S=%d must be in [1,1024]", c->S);
+    GENIE_CHECK_SHAPE((size_t)c->S * c->head_dim * 8 <= 160 * 1024, "S=%d x head_dim=%d exceeds LDS", c->S,
+                      c->head_dim);
+    GENIE_CHECK_SHAPE(c->num_factored >= 1 && c->num_factored <= 4, "num_factored %d unsupported", c->num_factored);
+    GENIE_CHECK_SHAPE(c->factored_vocab >= 1, "factored_vocab must be >= 1");
+    GENIE_CHECK_SHAPE(c->precision == GENIE_PREC_EXACT || c->precision == GENIE_PREC_BF16, "unknown precision %d",
+                      c->precision);
+    return GENIE_OK;
+}
+
+static int check_ws(const genie_cfg& c, int B, void* ws, size_t bytes) {
+    GENIE_CHECK_ARG(B >= 1, "B=%d must be >= 1", B);
+    GENIE_CHECK_ARG(ws != nullptr, "workspace is NULL");
+    size_t need = carve(c, B, nullptr).total;
+    GENIE_CHECK_ARG(bytes >= need, "workspace too small: %zu < %zu bytes", bytes, need);
+    return GENIE_OK;
+}
+
+// ---- one SelfAttention + residual: x += proj(attn(qkv(u)))  (attention.py:36-61, st_transformer.py:74,78)
+static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, const float* u, float* x, Workspace& w,
+                           int B, bool temporal, hipStream_t st) {
+    const int d = c.d_model, M = B * c.T * c.S;
+    float* qkv = (float*)w.big;
+    float* ao = (float*)w.xn;  // u may alias w.xn: it is dead once qkv is computed
+    GENIE_TRY(launch_gemm_f32(u, d, 0, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, qkv, 3 * d, 0, M, 3 * d, d, 1,
+                              0, 1.0f, st));
+    const float* nw = c.qk_norm ? aw.norm_w : nullptr;
+    const float* nb = c.qk_norm ? aw.norm_b : nullptr;
+    if (!temporal) {
+        GENIE_TRY(launch_attn_generic(qkv, ao, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
+                                      c.attn_scale, 0, nw, nb, st));
+    } else {
+        GENIE_TRY(launch_attn_generic(qkv, ao, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
+                                      c.head_dim, c.attn_scale, 1, nw, nb, st));
+    }
+    GENIE_TRY(launch_gemm_f32(ao, d, 0, aw.proj_w, d, 0, c.proj_bias ? aw.proj_b : nullptr, x, d, 0, M, d, d, 1,
+                              GEMM_ACCUM, 1.0f, st));
+    return GENIE_OK;
+}
+
+int st_block_exact(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st) {
+    const int d = c.d_model, M = B * c.T * c.S;
+    float* xn = (float*)w.xn;
+    // spatial: x += SpAttn(norm1(x))  (st_transformer.py:73-74)
+    const float* u = x;
+    if (!c.qk_norm) {
+        GENIE_TRY(launch_layer_norm(x, lw.norm1_w, lw.norm1_b, xn, M, d, 1e-5f, st));
+        u = xn;
+    }
+    GENIE_TRY(attention_block(c, lw.spatial, u, x, w, B, false, st));
+    // temporal: x += TmpAttn(x, causal), no pre-norm  (st_transformer.py:77-78)
+    GENIE_TRY(attention_block(c, lw.temporal, x, x, w, B, true, st));
+    // MLP: x += fc2(gelu(fc1(norm2(x))))  (st_transformer.py:81, 16-25)
+    u = x;
+    if (!c.qk_norm) {
+        GENIE_TRY(launch_layer_norm(x, lw.norm2_w, lw.norm2_b, xn, M, d, 1e-5f, st));
+        u = xn;
+    }
+    float* hid = (float*)w.big;
+    GENIE_TRY(launch_gemm_f32(u, d, 0, lw.fc1_w, d, 0, c.mlp_bias ? lw.fc1_b : nullptr, hid, c.hidden, 0, M, c.hidden,
+                              d, 1, GEMM_GELU, 1.0f, st));
+    GENIE_TRY(launch_gemm_f32(hid, c.hidden, 0, lw.fc2_w, c.hidden, 0, c.mlp_bias ? lw.fc2_b : nullptr, x, d, 0, M, d,
+                              c.hidden, 1, GEMM_ACCUM, 1.0f, st));
+    return GENIE_OK;
+}
+
+int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st);
+int readout_bf16(const genie_cfg& c, const genie_weights& wt, const float* x, int B, int t0, int t1, int layout,
+                 float* logits, hipStream_t st);
+
+static int st_block(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st) {
+    if (c.precision == GENIE_PREC_BF16) return st_block_bf16(c, lw, x, w, B, st);
+    return st_block_exact(c, lw, x, w, B, st);
+}
+
+static int decoder(const genie_cfg& c, const genie_weights& wt, float* x, Workspace& w, int B, hipStream_t st) {
+    for (int i = 0; i < c.num_layers; ++i) GENIE_TRY(st_block(c, wt.layers_host[i], x, w, B, st));
+    return GENIE_OK;
+}
+
+// out_x_proj on frames [t0,t1): token-major (B,nt,S,V) or BCTHW (B,V,nt,S) via the operand-swapped GEMM
+static int readout(const genie_cfg& c, const genie_weights& wt, const float* x, int B, int t0, int t1, int layout,
+                   float* logits, hipStream_t st) {
+    if (c.precision == GENIE_PREC_BF16) return readout_bf16(c, wt, x, B, t0, t1, layout, logits, st);
+    const int d = c.d_model, nt = t1 - t0, V = c.factored_vocab * c.num_factored;
+    const long rows = (long)nt * c.S;
+    const float* xa = x + (size_t)t0 * c.S * d;
+    const long strideX = (long)c.T * c.S * d;
+    if (layout == GENIE_LAYOUT_TOKEN_MAJOR) {
+        return launch_gemm_f32(xa, d, strideX, wt.out_w, d, 0, wt.out_b, logits, V, rows * V, (int)rows, V, d, B, 0,
+                               c.readout_mult, st);
+    }
+    return launch_gemm_f32(wt.out_w, d, 0, xa, d, strideX, wt.out_b, logits, rows, rows * V, V, (int)rows, d, B,
+                           GEMM_BIAS_ALONG_M, c.readout_mult, st);
+}
+
+static int mask_count(int step, int steps, int S) {
+    // n = ceil(cos(pi/2 * (step+1)/steps) * S), python float math (st_mask_git.py:17-26,199)
+    double u = (double)(step + 1) / (double)steps;
+    return (int)ceil(cos(u * M_PI / 2.0) * (double)S);
+}
+
+}  // namespace genie
+
+using namespace genie;
+
+extern "C" {
+
+int genie_version(void) { return GENIE_ABI_VERSION; }
+const char* genie_last_error(void) { return g_err; }
+int genie_check_config(const genie_cfg* cfg) { return check_cfg(cfg); }
+
+size_t genie_workspace_bytes(const genie_cfg* cfg, int B) {
+    if (check_cfg(cfg) != GENIE_OK || B < 1) return 0;
+    return carve(*cfg, B, nullptr).total;
+}
+
+int genie_pack_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
+    GENIE_CHECK_ARG(src && dst, "pack_bf16: NULL pointer");
+    return launch_pack_bf16(src, dst, n, as_stream(stream));
+}
+
+int genie_embed(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, float* x, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(w && ids && x && B >= 1, "embed: bad argument");
+    GENIE_CHECK_ARG(w->pos_embed && w->mask_embed && w->embed[0], "embed: weight table incomplete");
+    return launch_embed(*cfg, *w, ids, B, x, as_stream(stream));
+}
+
+int genie_layer_norm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps,
+                     void* stream) {
+    GENIE_CHECK_ARG(x && gamma && beta && y && rows >= 0 && C >= 1, "layer_norm: bad argument");
+    if (rows == 0) return GENIE_OK;
+    return launch_layer_norm(x, gamma, beta, y, rows, C, eps, as_stream(stream));
+}
+
+int genie_linear(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int gelu,
+                 int accumulate, void* stream) {
+    GENIE_CHECK_ARG(x && W && y && M >= 0 && N >= 1 && K >= 1, "linear: bad argument");
+    int flags = (gelu ? GEMM_GELU : 0) | (accumulate ? GEMM_ACCUM : 0);
+    return launch_gemm_f32(x, K, 0, W, K, 0, b, y, N, 0, M, N, K, 1, flags, 1.0f, as_stream(stream));
+}
+
+int genie_spatial_attention(const genie_cfg* cfg, const genie_attn_weights* aw, const float* qkv, float* out, int B,
+                            void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(aw && qkv && out && B >= 1, "spatial_attention: bad argument");
+    const genie_cfg& c = *cfg;
+    return launch_attn_generic(qkv, out, c.S, (long)B * c.T, 1, c.S, 0, 1, c.d_model, c.num_heads, c.head_dim,
+                               c.attn_scale, 0, c.qk_norm ? aw->norm_w : nullptr, c.qk_norm ? aw->norm_b : nullptr,
+                               as_stream(stream));
+}
+
+int genie_temporal_attention(const genie_cfg* cfg, const genie_attn_weights* aw, const float* qkv, float* out, int B,
+                             void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(aw && qkv && out && B >= 1, "temporal_attention: bad argument");
+    const genie_cfg& c = *cfg;
+    return launch_attn_generic(qkv, out, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, c.d_model, c.num_heads,
+                               c.head_dim, c.attn_scale, 1, c.qk_norm ? aw->norm_w : nullptr,
+                               c.qk_norm ? aw->norm_b : nullptr, as_stream(stream));
+}
+
+int genie_attention_core(const float* qkv, float* out, int n_seq, int N, int num_heads, int head_dim, float scale,
+                         int causal, const float* norm_w, const float* norm_b, void* stream) {
+    GENIE_CHECK_ARG(qkv && out && n_seq >= 0 && N >= 1 && num_heads >= 1, "attention_core: bad argument");
+    GENIE_CHECK_ARG((norm_w == nullptr) == (norm_b == nullptr), "attention_core: norm_w/norm_b must come together");
+    if (n_seq == 0) return GENIE_OK;
+    return launch_attn_generic(qkv, out, N, n_seq, 1, N, 0, 1, num_heads * head_dim, num_heads, head_dim, scale,
+                               causal, norm_w, norm_b, as_stream(stream));
+}
+
+int genie_st_block_forward(const genie_cfg* cfg, const genie_layer_weights* lw_host, float* x, int B, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(lw_host && x, "st_block_forward: NULL pointer");
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    Workspace w = carve(*cfg, B, workspace);
+    return st_block(*cfg, *lw_host, x, w, B, as_stream(stream));
+}
+
+int genie_decoder_forward(const genie_cfg* cfg, const genie_weights* wt, float* x, int B, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(wt && wt->layers_host && x, "decoder_forward: NULL pointer");
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    Workspace w = carve(*cfg, B, workspace);
+    return decoder(*cfg, *wt, x, w, B, as_stream(stream));
+}
+
+int genie_readout_logits(const genie_cfg* cfg, const genie_weights* wt, const float* x, int B, int t0, int t1,
+                         int layout, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(wt && x && logits && B >= 1, "readout_logits: bad argument");
+    GENIE_CHECK_ARG(0 <= t0 && t0 <= t1 && t1 <= cfg->T, "readout_logits: bad frame range [%d,%d)", t0, t1);
+    if (t0 == t1) return GENIE_OK;
+    return readout(*cfg, *wt, x, B, t0, t1, layout, logits, as_stream(stream));
+}
+
+int genie_compute_logits(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int t0, int t1,
+                         int layout, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(wt && wt->layers_host && ids && logits, "compute_logits: NULL pointer");
+    GENIE_CHECK_ARG(0 <= t0 && t0 <= t1 && t1 <= cfg->T, "compute_logits: bad frame range [%d,%d)", t0, t1);
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    Workspace w = carve(*cfg, B, workspace);
+    hipStream_t st = as_stream(stream);
+    GENIE_TRY(launch_embed(*cfg, *wt, ids, B, w.x, st));
+    GENIE_TRY(decoder(*cfg, *wt, w.x, w, B, st));
+    if (t0 == t1) return GENIE_OK;
+    return readout(*cfg, *wt, w.x, B, t0, t1, layout, logits, st);
+}
+
+int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, const int64_t* targets,
+                      const int64_t* weight_ids, int B, int t0, int t1, double* sums_out, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(logits && targets && sums_out && B >= 1, "factored_ce: bad argument");
+    GENIE_CHECK_ARG(0 <= t0 && t0 <= t1 && t1 <= cfg->T, "factored_ce: bad frame range [%d,%d)", t0, t1);
+    return launch_factored_ce(*cfg, logits, layout, targets, weight_ids, B, t0, t1, sums_out, as_stream(stream));
+}
+
+int genie_readout_ce(const genie_cfg* cfg, const genie_weights* wt, const float* x, const int64_t* targets,
+                     const int64_t* weight_ids, int B, int t0, int t1, double* sums_out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(wt && x && targets && sums_out, "readout_ce: NULL pointer");
+    GENIE_CHECK_ARG(0 <= t0 && t0 <= t1 && t1 <= cfg->T, "readout_ce: bad frame range [%d,%d)", t0, t1);
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    if (t0 == t1) return GENIE_OK;
+    Workspace w = carve(*cfg, B, workspace);
+    hipStream_t st = as_stream(stream);
+    GENIE_TRY(readout(*cfg, *wt, x, B, t0, t1, GENIE_LAYOUT_TOKEN_MAJOR, w.logits, st));
+    return launch_factored_ce(*cfg, w.logits, GENIE_LAYOUT_TOKEN_MAJOR, targets, weight_ids, B, t0, t1, sums_out, st);
+}
+
+int genie_sample(const genie_cfg* cfg, const float* logits, int layout, int B, float temperature,
+                 const float* uniforms, int64_t* samples, float* conf, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(logits && samples && conf && B >= 1, "sample: bad argument");
+    GENIE_CHECK_ARG(temperature <= 1e-8f || uniforms, "sample: temperature > 0 needs caller-supplied uniforms");
+    return launch_sample(*cfg, logits, layout, B, temperature, uniforms, samples, conf, as_stream(stream));
+}
+
+int genie_mask_step(const float* keys, int n, int last_step, int64_t mask_id, uint8_t* unmasked, int64_t* samples,
+                    int64_t* prompt_frame, int64_t prompt_clip_stride, int B, int S, void* stream) {
+    GENIE_CHECK_ARG(unmasked && samples && prompt_frame && B >= 1 && S >= 1, "mask_step: bad argument");
+    GENIE_CHECK_ARG(last_step || keys, "mask_step: keys required unless last_step");
+    GENIE_CHECK_ARG(last_step || (n >= 0 && n <= S), "mask_step: n=%d out of range", n);
+    return launch_mask_step(keys, n, last_step, mask_id, unmasked, samples, prompt_frame, (long)prompt_clip_stride, B,
+                            S, as_stream(stream));
+}
+
+int genie_maskgit_generate(const genie_cfg* cfg, const genie_weights* wt, int64_t* prompt, int B, int out_t, int steps,
+                           float temperature, int unmask_mode, const float* noise, const float* uniforms,
+                           int64_t* samples_out, float* logits0_out, int layout, int32_t* status_flag,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    const genie_cfg& c = *cfg;
+    GENIE_CHECK_ARG(wt && wt->layers_host && prompt && samples_out, "maskgit_generate: NULL pointer");
+    if (!(out_t >= 1 && out_t < c.T)) {  // assert out_t  (st_mask_git.py:154)
+        set_error("maskgit_generate requires 0 < out_t < T (got %d)", out_t);
+        return GENIE_E_ASSERT;
+    }
+    GENIE_CHECK_ARG(steps >= 1, "maskgit_generate: steps=%d must be >= 1", steps);
+    if (unmask_mode != GENIE_UNMASK_RANDOM && unmask_mode != GENIE_UNMASK_GREEDY) {
+        set_error("Expected `unmask_mode` to be one of ['greedy', 'random']");
+        return GENIE_E_UNSUPPORTED;
+    }
+    GENIE_CHECK_ARG(steps == 1 || unmask_mode == GENIE_UNMASK_GREEDY || noise,
+                    "maskgit_generate: 'random' unmasking with steps > 1 needs the caller's U[0,1) draws");
+    GENIE_CHECK_ARG(temperature <= 1e-8f || uniforms, "maskgit_generate: temperature > 0 needs uniforms");
+    GENIE_TRY(check_ws(c, B, workspace, workspace_bytes));
+    Workspace w = carve(c, B, workspace);
+    hipStream_t st = as_stream(stream);
+    const size_t BS = (size_t)B * c.S;
+    const long V = (long)c.factored_vocab * c.num_factored;
+
+    GENIE_TRY(launch_check_masked(prompt, B, c.T, c.S, out_t, c.image_vocab_size, status_flag, st));
+    if (hipMemsetAsync(w.unmasked, 0, BS, st) != hipSuccess) { set_error("memset failed"); return GENIE_E_LAUNCH; }
+    for (int step = 0; step < steps; ++step) {
+        GENIE_TRY(launch_embed(c, *wt, prompt, B, w.x, st));
+        GENIE_TRY(decoder(c, *wt, w.x, w, B, st));
+        GENIE_TRY(readout(c, *wt, w.x, B, out_t, out_t + 1, GENIE_LAYOUT_TOKEN_MAJOR, w.logits, st));
+        if (step == 0 && logits0_out) {  // orig_logits_CHW: step-0 logits are what is returned (:165,226)
+            if (layout == GENIE_LAYOUT_TOKEN_MAJOR) {
+                if (hipMemcpyAsync(logits0_out, w.logits, BS * V * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                    set_error("memcpy failed");
+                    return GENIE_E_LAUNCH;
+                }
+            } else {
+                GENIE_TRY(launch_transpose(w.logits, logits0_out, B, c.S, (int)V, st));
+            }
+        }
+        const float* u = (temperature > 1e-8f) ? uniforms + (size_t)step * c.num_factored * BS : nullptr;
+        GENIE_TRY(launch_sample(c, w.logits, GENIE_LAYOUT_TOKEN_MAJOR, B, temperature, u, w.samples, w.conf, st));
+        const int last = (step == steps - 1);
+        const float* keys = nullptr;
+        int n = 0;
+        if (!last) {
+            n = mask_count(step, steps, c.S);
+            keys = (unmask_mode == GENIE_UNMASK_GREEDY) ? w.conf : noise + (size_t)step * BS;
+        }
+        GENIE_TRY(launch_mask_step(keys, n, last, c.image_vocab_size, w.unmasked, w.samples,
+                                   prompt + (size_t)out_t * c.S, (long)c.T * c.S, B, c.S, st));
+    }
+    if (hipMemcpyAsync(samples_out, w.samples, BS * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("memcpy failed");
+        return GENIE_E_LAUNCH;
+    }
+    return GENIE_OK;
+}
+
+int genie_bits_from_tokens(const int64_t* ids, float* z, int n, int hw, int bits, void* stream) {
+    GENIE_CHECK_ARG(ids && z && n >= 0 && hw >= 1 && bits >= 1 && bits <= 62, "bits_from_tokens: bad argument");
+    return launch_bits(ids, z, n, hw, bits, as_stream(stream));
+}
+
+}  // extern "C"

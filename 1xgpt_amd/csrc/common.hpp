@@ -1,0 +1,78 @@
+// Shared helpers for the gfx950 kernels.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/genie_hip.h"
+
+namespace genie {
+
+constexpr int WAVE = 64;
+
+void set_error(const char* fmt, ...);
+
+#define GENIE_CHECK_ARG(cond, ...)        \
+    do {                                  \
+        if (!(cond)) {                    \
+            genie::set_error(__VA_ARGS__); \
+            return GENIE_E_ARG;           \
+        }                                 \
+    } while (0)
+
+#define GENIE_CHECK_SHAPE(cond, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            genie::set_error(__VA_ARGS__); \
+            return GENIE_E_SHAPE;         \
+        }                                 \
+    } while (0)
+
+#define GENIE_LAUNCH_CHECK(what)                                                    \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            genie::set_error("%s: HIP error %s", what, hipGetErrorString(e__));      \
+            return GENIE_E_LAUNCH;                                                  \
+        }                                                                           \
+    } while (0)
+
+#define GENIE_TRY(expr)            \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != GENIE_OK) return rc__; \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// (value, index) arg-max with "first max wins" (torch.argmax tie rule).
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+__device__ __forceinline__ float gelu_erf(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+
+// round-to-nearest-even f32 -> bf16 bits
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace genie

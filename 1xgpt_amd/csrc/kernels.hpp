@@ -1,0 +1,36 @@
+// Host-side launchers of the gfx950 kernels (implemented in kernels_exact.hip / kernels_bf16.hip).
+#pragma once
+#include "common.hpp"
+
+namespace genie {
+
+enum { GEMM_GELU = 1, GEMM_ACCUM = 2, GEMM_BIAS_ALONG_M = 4 };
+
+int launch_embed(const genie_cfg& c, const genie_weights& w, const int64_t* ids, int B, float* x, hipStream_t st);
+int launch_layer_norm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps,
+                      hipStream_t st);
+int launch_layer_norm_bf16(const float* x, const float* g, const float* b, uint16_t* y, long rows, int C, float eps,
+                           hipStream_t st);
+// C[batch][M,N] (+)= epi(alpha * A[batch][M,K] . W[batch][N,K]^T + bias)
+int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, const float* bias,
+                    float* C, long ldc, long strideC, int M, int N, int K, int batch, int flags, float alpha,
+                    hipStream_t st);
+int launch_attn_generic(const float* qkv, float* out, int N, long n_seq, int inner, long outer_stride,
+                        long inner_stride, long pos_stride, int d, int H, int Dh, float scale, int causal,
+                        const float* nw, const float* nb, hipStream_t st);
+int launch_attn_generic_bf16(const uint16_t* qkv, uint16_t* out, int N, long n_seq, int inner, long outer_stride,
+                             long inner_stride, long pos_stride, int d, int H, int Dh, float scale, int causal,
+                             const float* nw, const float* nb, hipStream_t st);
+int launch_transpose(const float* in, float* out, int batch, int rows, int cols, hipStream_t st);
+int launch_factored_ce(const genie_cfg& c, const float* logits, int layout, const int64_t* targets,
+                       const int64_t* weight_ids, int B, int t0, int t1, double* sums, hipStream_t st);
+int launch_sample(const genie_cfg& c, const float* logits, int layout, int B, float temperature,
+                  const float* uniforms, int64_t* samples, float* conf, hipStream_t st);
+int launch_mask_step(const float* keys, int n, int last_step, int64_t mask_id, uint8_t* unmasked, int64_t* samples,
+                     int64_t* prompt_frame, long clip_stride, int B, int S, hipStream_t st);
+int launch_check_masked(const int64_t* prompt, int B, int T, int S, int out_t, int64_t mask_id, int32_t* flag,
+                        hipStream_t st);
+int launch_bits(const int64_t* ids, float* z, int n, int hw, int bits, hipStream_t st);
+int launch_pack_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t st);
+
+}  // namespace genie

@@ -1,0 +1,731 @@
+// Exact-precision (f32) kernels of the GENIE path for gfx950: embedding gather, LayerNorm, the f32-MFMA
+// "NT" GEMM with fused bias / erf-GELU / residual epilogue, the generic strided attention, factored CE,
+// MaskGIT sampling and mask step, layout transposes.  Every kernel cites the reference op it replaces.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+// ------------------------------------------------------------------------------------------------
+// a2  FactorizedEmbedding.forward + pos_embed (factorization_utils.py:29-52, st_mask_git.py:257-261)
+// one thread per float4 of the output; ids are read through L1 (d/4 threads share one id).
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ pos,
+                             const float* __restrict__ mask_embed, const float* __restrict__ e0,
+                             const float* __restrict__ e1, const float* __restrict__ e2,
+                             const float* __restrict__ e3, float* __restrict__ x, long n_tok, int TS, int d,
+                             int nfac, int vf, int64_t mask_id) {
+    const int d4 = d >> 2;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_tok * d4) return;
+    long tok = idx / d4;
+    int c = (int)(idx - tok * d4) << 2;
+    int64_t id = ids[tok];
+    float4 v;
+    if (id == mask_id) {
+        v = *reinterpret_cast<const float4*>(mask_embed + c);
+    } else {
+        const float* tabs[4] = {e0, e1, e2, e3};
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t rem = id;
+        for (int j = 0; j < nfac; ++j) {  // factor j = (id // vf^j) % vf  (factorization_utils.py:67-68)
+            int f = (int)(rem % vf);
+            rem /= vf;
+            float4 e = *reinterpret_cast<const float4*>(tabs[j] + (size_t)f * d + c);
+            v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+    }
+    float4 p = *reinterpret_cast<const float4*>(pos + (size_t)(tok % TS) * d + c);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    *reinterpret_cast<float4*>(x + (size_t)tok * d + c) = v;
+}
+
+int launch_embed(const genie_cfg& c, const genie_weights& w, const int64_t* ids, int B, float* x, hipStream_t st) {
+    long n_tok = (long)B * c.T * c.S;
+    long n = n_tok * (c.d_model / 4);
+    int blocks = (int)((n + 255) / 256);
+    embed_kernel<<<blocks, 256, 0, st>>>(ids, w.pos_embed, w.mask_embed, w.embed[0], w.embed[1], w.embed[2],
+                                         w.embed[3], x, n_tok, c.T * c.S, c.d_model, c.num_factored,
+                                         c.factored_vocab, (int64_t)c.image_vocab_size);
+    GENIE_LAUNCH_CHECK("embed");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4  nn.LayerNorm(C, eps): one wavefront per row, two-pass (mean, then centred variance), f32.
+// OutT = float (exact) or uint16_t bf16 (operand of a bf16 GEMM).
+// ------------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ b, OutT* __restrict__ y, long rows,
+                                                         int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float v[32];  // C <= 2048
+    int n = 0;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { v[n] = xr[c]; s += v[n]; ++n; }
+    float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int k = 0; k < n; ++k) { float t = v[k] - mean; q += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    OutT* yr = y + (size_t)row * C;
+    n = 0;
+    for (int c = lane; c < C; c += 64) {
+        float o = (v[n] - mean) * rstd * g[c] + b[c];
+        if constexpr (sizeof(OutT) == 2) yr[c] = f32_to_bf16(o); else yr[c] = o;
+        ++n;
+    }
+}
+
+int launch_layer_norm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps,
+                      hipStream_t st) {
+    GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
+    int blocks = (int)((rows + 3) / 4);
+    layer_norm_kernel<float><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
+    GENIE_LAUNCH_CHECK("layer_norm");
+    return GENIE_OK;
+}
+int launch_layer_norm_bf16(const float* x, const float* g, const float* b, uint16_t* y, long rows, int C, float eps,
+                           hipStream_t st) {
+    GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
+    int blocks = (int)((rows + 3) / 4);
+    layer_norm_kernel<uint16_t><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
+    GENIE_LAUNCH_CHECK("layer_norm_bf16");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// nn.Linear on the f32 matrix cores:  C[M,N] (+)= epilogue( alpha * A[M,K] . W[N,K]^T + bias )
+//
+// v_mfma_f32_32x32x2_f32 is an exact-f32 fmaf chain at 157 TF peak (1/16 of bf16 MFMA), so this GEMM
+// is issue-bound on the matrix pipe, not on LDS/HBM: 128x128 block tile, 4 waves (2x2), each wave
+// 64x64 = 2x2 MFMA tiles (64 accumulator registers), BK = 16, LDS double-buffered, global->register
+// prefetch of the next K-tile while the current one is multiplied.
+//
+// Operand fetch trick: the MFMA wants lane (r = lane&31, h = lane>>5) to supply A[r][k0+h].  Since the
+// K-sum is order-free, lane (r,h) reads ONE float4 = A[r][8*kk + 4h .. +3] and MFMA j (0..3) consumes
+// component j from both halves, i.e. the k-pair {8kk+j, 8kk+4+j}: 1 ds_read_b128 feeds 4 MFMAs.
+// LDS rows are padded to BK+4 floats (80 B): the 16-lane groups of ds_read_b128 then hit 16 distinct
+// 16-byte slots -> conflict-free.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16, GEMM_LDS_LD = GEMM_BK + 4;
+
+__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restrict__ A, long lda, long strideA,
+                                                          const float* __restrict__ W, long ldw, long strideW,
+                                                          const float* __restrict__ bias, float* __restrict__ C,
+                                                          long ldc, long strideC, int M, int N, int K, int flags,
+                                                          float alpha) {
+    __shared__ __attribute__((aligned(16))) float sA[2][GEMM_BM * GEMM_LDS_LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][GEMM_BN * GEMM_LDS_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    // N-tiles vary fastest so that blocks sharing an A row-panel are dispatched together (L2 reuse).
+    const int n_tiles = (N + GEMM_BN - 1) / GEMM_BN;
+    const int m0 = (blockIdx.x / n_tiles) * GEMM_BM, n0 = (blockIdx.x % n_tiles) * GEMM_BN;
+    A += (size_t)blockIdx.y * strideA;
+    W += (size_t)blockIdx.y * strideW;
+    C += (size_t)blockIdx.y * strideC;
+
+    // global->LDS staging: thread t moves float4 (row = t/4 [+64], col4 = t%4) of each operand tile
+    const int lrow = tid >> 2, lcol = (tid & 3) << 2;
+    const float* gA[2];
+    const float* gB[2];
+    bool vA[2], vB[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int ra = m0 + lrow + p * 64, rb = n0 + lrow + p * 64;
+        vA[p] = ra < M;
+        vB[p] = rb < N;
+        gA[p] = A + (size_t)(vA[p] ? ra : 0) * lda + lcol;
+        gB[p] = W + (size_t)(vB[p] ? rb : 0) * ldw + lcol;
+    }
+    float4 ra4[2], rb4[2];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ra4[p] = vA[p] ? *reinterpret_cast<const float4*>(gA[p] + k0) : z4;
+            rb4[p] = vB[p] ? *reinterpret_cast<const float4*>(gB[p] + k0) : z4;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<float4*>(&sA[buf][(lrow + p * 64) * GEMM_LDS_LD + lcol]) = ra4[p];
+            *reinterpret_cast<float4*>(&sB[buf][(lrow + p * 64) * GEMM_LDS_LD + lcol]) = rb4[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = K / GEMM_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * GEMM_BK);
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 8; ++kk) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(&sA[buf][(wm * 64 + i * 32 + r) * GEMM_LDS_LD + kk * 8 + 4 * h]);
+                b[i] = *reinterpret_cast<const float4*>(&sB[buf][(wn * 64 + i * 32 + r) * GEMM_LDS_LD + kk * 8 + 4 * h]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    const bool do_gelu = flags & GEMM_GELU, do_acc = flags & GEMM_ACCUM, bias_m = flags & GEMM_BIAS_ALONG_M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+            if (col >= N) continue;
+            const float bcol = (bias && !bias_m) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[i][j][e] * alpha + ((bias && bias_m) ? bias[row] : bcol);
+                if (do_gelu) v = gelu_erf(v);
+                float* p = C + (size_t)row * ldc + col;
+                if (do_acc) v += *p;
+                *p = v;
+            }
+        }
+}
+
+int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, const float* bias,
+                    float* C, long ldc, long strideC, int M, int N, int K, int batch, int flags, float alpha,
+                    hipStream_t st) {
+    GENIE_CHECK_SHAPE(K % GEMM_BK == 0 && K > 0, "gemm: K=%d must be a positive multiple of %d", K, GEMM_BK);
+    GENIE_CHECK_SHAPE((lda % 4 == 0) && (ldw % 4 == 0), "gemm: leading dims must be multiples of 4 floats");
+    if (M <= 0 || N <= 0 || batch <= 0) return GENIE_OK;
+    int mt = (M + GEMM_BM - 1) / GEMM_BM, nt = (N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid(mt * nt, batch);
+    gemm_f32_nt_kernel<<<grid, 256, 0, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags,
+                                             alpha);
+    GENIE_LAUNCH_CHECK("gemm_f32");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6-a8  Attention core on a packed qkv buffer (attention.py:38-59), generic in sequence geometry:
+//   row(seq, pos) = (seq / inner) * outer_stride + (seq % inner) * inner_stride + pos * pos_stride
+//   spatial : inner = 1, outer_stride = S,   pos_stride = 1, N = S, non-causal
+//   temporal: inner = S, outer_stride = T*S, inner_stride = 1, pos_stride = S, N = T, causal --
+//             the "(B S) T C" view of st_transformer.py:77 without the physical transpose.
+// One thread per query row; K/V rows of the block's sequences staged in LDS (same-address reads
+// broadcast); keys are consumed in chunks of 16 with one softmax rescale per chunk (N <= 16 is exactly
+// the two-pass softmax).  qk-norm (one shared affine, eps 1e-5) and the q*scale of attention.py:42-48
+// are applied on load.  InT/OutT = float or bf16 bits.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float ld_elem(const T* p) {
+    if constexpr (sizeof(T) == 2) return bf16_to_f32(*p); else return *p;
+}
+
+template <int DH, typename InT, typename OutT>
+__global__ void attn_generic_kernel(const InT* __restrict__ qkv, OutT* __restrict__ out, int N, int spb, long n_seq,
+                                    int inner, long outer_stride, long inner_stride, long pos_stride, int d,
+                                    float scale, int causal, const float* __restrict__ nw,
+                                    const float* __restrict__ nb, int round_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;                          // [spb*N][DH]
+    float* sV = smem + (size_t)spb * N * DH;   // [spb*N][DH]
+    const int head = blockIdx.y;
+    const int t = threadIdx.x;
+    const int sl = t / N, i = t - sl * N;
+    const long seq = (long)blockIdx.x * spb + sl;
+    const bool active = (sl < spb) && (seq < n_seq);
+    float q[DH], o[DH];
+    long row = 0;
+    if (active) {
+        row = (seq / inner) * outer_stride + (seq % inner) * inner_stride + (long)i * pos_stride;
+        const InT* base = qkv + (size_t)row * 3 * d + head * DH;
+        float kx[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) { q[c] = ld_elem(base + c); kx[c] = ld_elem(base + d + c); }
+        if (nw) {  // qk-norm in f32 (attention.py:42-47)
+            float mq = 0.f, mk = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) { mq += q[c]; mk += kx[c]; }
+            mq /= DH; mk /= DH;
+            float vq = 0.f, vk = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) { float a = q[c] - mq, b = kx[c] - mk; vq += a * a; vk += b * b; }
+            float rq = 1.0f / sqrtf(vq / DH + 1e-5f), rk = 1.0f / sqrtf(vk / DH + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < DH; ++c) {
+                q[c] = (q[c] - mq) * rq * nw[c] + nb[c];
+                kx[c] = (kx[c] - mk) * rk * nw[c] + nb[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < DH; ++c) {
+            float kc = kx[c], qc = q[c];
+            if (round_bf16) {  // bf16 contract: operands of both matmuls are bf16, scale applied to the scores
+                kc = bf16_to_f32(f32_to_bf16(kc));
+                qc = bf16_to_f32(f32_to_bf16(qc));
+            } else {
+                qc *= scale;  // attention.py:48
+            }
+            q[c] = qc;
+            sK[(size_t)t * DH + c] = kc;
+            sV[(size_t)t * DH + c] = ld_elem(base + 2 * d + c);
+            o[c] = 0.f;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float post = round_bf16 ? scale : 1.0f;
+    const float* Ks = sK + (size_t)sl * N * DH;
+    const float* Vs = sV + (size_t)sl * N * DH;
+    const int jend = causal ? i + 1 : N;
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < jend; j0 += 16) {
+        float s[16];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = j0 + jj;
+            float acc = -INFINITY;
+            if (j < jend) {
+                acc = 0.f;
+                const float* kr = Ks + (size_t)j * DH;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) acc = fmaf(q[c], kr[c], acc);
+                acc *= post;
+            }
+            s[jj] = acc;
+            cm = fmaxf(cm, acc);
+        }
+        const float mn = fmaxf(m, cm);
+        const float alpha = __expf(m - mn);  // m = -inf on the first chunk -> 0
+        l *= alpha;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) o[c] *= alpha;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = j0 + jj;
+            if (j < jend) {
+                float p = expf(s[jj] - mn);
+                l += p;
+                if (round_bf16) p = bf16_to_f32(f32_to_bf16(p));
+                const float* vr = Vs + (size_t)j * DH;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) o[c] = fmaf(p, vr[c], o[c]);
+            }
+        }
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+    OutT* op = out + (size_t)row * d + head * DH;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+        float v = o[c] * inv;
+        if constexpr (sizeof(OutT) == 2) op[c] = f32_to_bf16(v); else op[c] = v;
+    }
+}
+
+template <typename InT, typename OutT>
+static int launch_attn_generic_t(const InT* qkv, OutT* out, int N, long n_seq, int inner, long outer_stride,
+                                 long inner_stride, long pos_stride, int d, int H, int Dh, float scale, int causal,
+                                 const float* nw, const float* nb, int round_bf16, hipStream_t st) {
+    GENIE_CHECK_SHAPE(N >= 1 && N <= 1024, "attention: sequence length %d unsupported", N);
+    int spb = N >= 64 ? 1 : 64 / N;
+    int threads = ((spb * N + 63) / 64) * 64;
+    size_t lds = (size_t)spb * N * Dh * 2 * sizeof(float);
+    GENIE_CHECK_SHAPE(lds <= 160 * 1024, "attention: N=%d x Dh=%d does not fit LDS", N, Dh);
+    dim3 grid((unsigned)((n_seq + spb - 1) / spb), H);
+#define GENIE_ATTN_CASE(DHV)                                                                                   \
+    case DHV:                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)attn_generic_kernel<DHV, InT, OutT>,                                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        attn_generic_kernel<DHV, InT, OutT><<<grid, threads, lds, st>>>(qkv, out, N, spb, n_seq, inner,        \
+                                                                         outer_stride, inner_stride,           \
+                                                                         pos_stride, d, scale, causal, nw, nb, \
+                                                                         round_bf16);                          \
+        break;
+    switch (Dh) {
+        GENIE_ATTN_CASE(8)
+        GENIE_ATTN_CASE(16)
+        GENIE_ATTN_CASE(32)
+        GENIE_ATTN_CASE(64)
+        default:
+            set_error("attention: head_dim %d unsupported (8/16/32/64)", Dh);
+            return GENIE_E_SHAPE;
+    }
+#undef GENIE_ATTN_CASE
+    GENIE_LAUNCH_CHECK("attn_generic");
+    return GENIE_OK;
+}
+
+int launch_attn_generic(const float* qkv, float* out, int N, long n_seq, int inner, long outer_stride,
+                        long inner_stride, long pos_stride, int d, int H, int Dh, float scale, int causal,
+                        const float* nw, const float* nb, hipStream_t st) {
+    return launch_attn_generic_t<float, float>(qkv, out, N, n_seq, inner, outer_stride, inner_stride, pos_stride, d,
+                                               H, Dh, scale, causal, nw, nb, 0, st);
+}
+int launch_attn_generic_bf16(const uint16_t* qkv, uint16_t* out, int N, long n_seq, int inner, long outer_stride,
+                             long inner_stride, long pos_stride, int d, int H, int Dh, float scale, int causal,
+                             const float* nw, const float* nb, hipStream_t st) {
+    return launch_attn_generic_t<uint16_t, uint16_t>(qkv, out, N, n_seq, inner, outer_stride, inner_stride,
+                                                     pos_stride, d, H, Dh, scale, causal, nw, nb, 1, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout: token-major (rows, V) -> (V, rows) per batch ("B T (H W) C -> B C T H W", st_mask_git.py:264)
+// ------------------------------------------------------------------------------------------------
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const float* ib = in + (size_t)blockIdx.z * rows * cols;
+    float* ob = out + (size_t)blockIdx.z * rows * cols;
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        int rr = r0 + k, cc = c0 + threadIdx.x;
+        tile[k][threadIdx.x] = (rr < rows && cc < cols) ? ib[(size_t)rr * cols + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        int cc = c0 + k, rr = r0 + threadIdx.x;
+        if (rr < rows && cc < cols) ob[(size_t)cc * rows + rr] = tile[threadIdx.x][k];
+    }
+}
+
+int launch_transpose(const float* in, float* out, int batch, int rows, int cols, hipStream_t st) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch), block(32, 8);
+    transpose_kernel<<<grid, block, 0, st>>>(in, out, rows, cols);
+    GENIE_LAUNCH_CHECK("transpose");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12  factored cross-entropy + "all factors argmax-correct" (st_mask_git.py:231-253, eval_utils.py:72-77)
+// token-major: one wavefront per token (V contiguous, 2 KB per factor, coalesced).
+// BCTHW: one lane per token, 64 consecutive tokens per wave, loop over the vocab (coalesced across lanes).
+// Partial sums go to 3 doubles with one atomicAdd per block.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_accumulate3(double ce, double hit, double cnt, double* sums) {
+    __shared__ double red[3][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ce += __shfl_xor(ce, o);
+        hit += __shfl_xor(hit, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    if (lane == 0) { red[0][wid] = ce; red[1][wid] = hit; red[2][wid] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0, c = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
+        if (c != 0.0) { atomicAdd(&sums[0], a); atomicAdd(&sums[1], b); atomicAdd(&sums[2], c); }
+    }
+}
+
+// logits token-major (B, nt, S, V): token index n = (b*nt + tt)*S + s
+__global__ __launch_bounds__(256) void ce_token_major_kernel(const float* __restrict__ logits,
+                                                             const int64_t* __restrict__ targets,
+                                                             const int64_t* __restrict__ weight_ids, long n_tok,
+                                                             int nt, int S, int T, int t0, int vf, int nfac,
+                                                             int64_t mask_id, double* sums) {
+    const int lane = threadIdx.x & 63;
+    long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double ce = 0, hit = 0, cnt = 0;
+    if (n < n_tok) {
+        long b = n / ((long)nt * S);
+        long rem = n - b * (long)nt * S;
+        long gi = (b * T + t0) * (long)S + rem;  // index into the full (B,T,S) clip
+        bool counted = weight_ids ? (weight_ids[gi] == mask_id) : true;
+        if (counted) {
+            int64_t tgt = targets[gi];
+            const float* lp = logits + (size_t)n * vf * nfac;
+            float loss = 0.f;
+            bool all_ok = true;
+            for (int f = 0; f < nfac; ++f) {
+                int tf = (int)(tgt % vf);
+                tgt /= vf;
+                float mx = -INFINITY;
+                int mi = 0;
+                for (int k = lane; k < vf; k += 64) {
+                    float v = lp[f * vf + k];
+                    if (v > mx) { mx = v; mi = k; }
+                }
+                wave_argmax(mx, mi);
+                float se = 0.f;
+                for (int k = lane; k < vf; k += 64) se += expf(lp[f * vf + k] - mx);
+                se = wave_sum(se);
+                loss += (logf(se) + mx) - lp[f * vf + tf];
+                all_ok = all_ok && (mi == tf);
+            }
+            if (lane == 0) { ce = loss; hit = all_ok ? 1.0 : 0.0; cnt = 1.0; }
+        }
+    }
+    block_accumulate3(ce, hit, cnt, sums);
+}
+
+// logits BCTHW (B, V, nt, S): element (b, v, tt, s) at ((b*V + v)*nt + tt)*S + s
+__global__ __launch_bounds__(256) void ce_bcthw_kernel(const float* __restrict__ logits,
+                                                       const int64_t* __restrict__ targets,
+                                                       const int64_t* __restrict__ weight_ids, long n_tok, int nt,
+                                                       int S, int T, int t0, int vf, int nfac, int64_t mask_id,
+                                                       double* sums) {
+    long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    double ce = 0, hit = 0, cnt = 0;
+    if (n < n_tok) {
+        long b = n / ((long)nt * S);
+        long rem = n - b * (long)nt * S;  // tt*S + s
+        long gi = (b * T + t0) * (long)S + rem;
+        bool counted = weight_ids ? (weight_ids[gi] == mask_id) : true;
+        if (counted) {
+            int64_t tgt = targets[gi];
+            const long vstride = (long)nt * S;
+            const float* lp = logits + (size_t)b * vf * nfac * vstride + rem;
+            float loss = 0.f;
+            bool all_ok = true;
+            for (int f = 0; f < nfac; ++f) {
+                int tf = (int)(tgt % vf);
+                tgt /= vf;
+                const float* lf = lp + (size_t)f * vf * vstride;
+                float mx = -INFINITY;
+                int mi = 0;
+                for (int k = 0; k < vf; ++k) {
+                    float v = lf[(size_t)k * vstride];
+                    if (v > mx) { mx = v; mi = k; }
+                }
+                float se = 0.f;
+                for (int k = 0; k < vf; ++k) se += expf(lf[(size_t)k * vstride] - mx);
+                loss += (logf(se) + mx) - lf[(size_t)tf * vstride];
+                all_ok = all_ok && (mi == tf);
+            }
+            ce = loss; hit = all_ok ? 1.0 : 0.0; cnt = 1.0;
+        }
+    }
+    block_accumulate3(ce, hit, cnt, sums);
+}
+
+int launch_factored_ce(const genie_cfg& c, const float* logits, int layout, const int64_t* targets,
+                       const int64_t* weight_ids, int B, int t0, int t1, double* sums, hipStream_t st) {
+    int nt = t1 - t0;
+    long n_tok = (long)B * nt * c.S;
+    if (n_tok <= 0) return GENIE_OK;
+    if (layout == GENIE_LAYOUT_TOKEN_MAJOR) {
+        ce_token_major_kernel<<<(unsigned)((n_tok + 3) / 4), 256, 0, st>>>(
+            logits, targets, weight_ids, n_tok, nt, c.S, c.T, t0, c.factored_vocab, c.num_factored,
+            (int64_t)c.image_vocab_size, sums);
+    } else {
+        ce_bcthw_kernel<<<(unsigned)((n_tok + 255) / 256), 256, 0, st>>>(
+            logits, targets, weight_ids, n_tok, nt, c.S, c.T, t0, c.factored_vocab, c.num_factored,
+            (int64_t)c.image_vocab_size, sums);
+    }
+    GENIE_LAUNCH_CHECK("factored_ce");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a13  MaskGIT sampling half (st_mask_git.py:171-190): per factor (most significant first) softmax,
+// argmax (first max wins) or inverse-CDF sample, sample = hi*Vf + lo, conf = prod p[sample].
+// One wavefront per token; strides make it layout-agnostic (vstride = 1 token-major, S for (B,V,S)).
+// Lane l owns the contiguous vocab slice [l*vf/64, (l+1)*vf/64) so the CDF is a wave prefix sum.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, long tok_stride_b,
+                                                     long tok_stride_s, long vstride, int B, int S, int vf,
+                                                     int nfac, float temperature,
+                                                     const float* __restrict__ uniforms,
+                                                     int64_t* __restrict__ samples, float* __restrict__ conf) {
+    const int lane = threadIdx.x & 63;
+    long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= (long)B * S) return;
+    long b = n / S, s = n - b * S;
+    const float* lp = logits + (size_t)b * tok_stride_b + (size_t)s * tok_stride_s;
+    const int per = (vf + 63) / 64;
+    int64_t sample = 0;
+    float cf = 1.0f;
+    for (int k = 0; k < nfac; ++k) {
+        const int f = nfac - 1 - k;  // flip(2): hi factor first (:179)
+        const float* lf = lp + (size_t)f * vf * vstride;
+        float mx = -INFINITY;
+        int mi = 0;
+        for (int q = 0; q < per; ++q) {
+            int idx = lane * per + q;
+            if (idx < vf) {
+                float v = lf[(size_t)idx * vstride];
+                if (v > mx) { mx = v; mi = idx; }
+            }
+        }
+        wave_argmax(mx, mi);
+        float part = 0.f;
+        for (int q = 0; q < per; ++q) {
+            int idx = lane * per + q;
+            if (idx < vf) part += expf(lf[(size_t)idx * vstride] - mx);
+        }
+        const float tot = wave_sum(part);
+        int pick = mi;
+        float p = 1.0f / tot;  // softmax of the arg-max element: exp(0)/sum
+        if (temperature > 1e-8f) {
+            // Categorical(probs / T) renormalises: T only switches argmax -> sampling (:184-186)
+            const float u = uniforms[((size_t)k * B + b) * S + s] * tot;
+            float incl = part;  // inclusive scan of lane partials
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            float run = incl - part;
+            int cntl = 0;  // entries of this lane whose inclusive cdf < u
+            for (int q = 0; q < per; ++q) {
+                int idx = lane * per + q;
+                if (idx < vf) {
+                    run += expf(lf[(size_t)idx * vstride] - mx);
+                    cntl += (run < u) ? 1 : 0;
+                }
+            }
+            int total = cntl;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+            pick = total < vf - 1 ? total : vf - 1;
+            p = expf(lf[(size_t)pick * vstride] - mx) / tot;
+        }
+        sample = sample * vf + pick;
+        cf *= p;
+    }
+    if (lane == 0) { samples[n] = sample; conf[n] = cf; }
+}
+
+int launch_sample(const genie_cfg& c, const float* logits, int layout, int B, float temperature,
+                  const float* uniforms, int64_t* samples, float* conf, hipStream_t st) {
+    long V = (long)c.factored_vocab * c.num_factored;
+    long sb, ss, vs;
+    if (layout == GENIE_LAYOUT_TOKEN_MAJOR) { sb = (long)c.S * V; ss = V; vs = 1; }
+    else { sb = (long)c.S * V; ss = 1; vs = c.S; }
+    long n = (long)B * c.S;
+    sample_kernel<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(logits, sb, ss, vs, B, c.S, c.factored_vocab,
+                                                            c.num_factored, temperature, uniforms, samples, conf);
+    GENIE_LAUNCH_CHECK("sample");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a14  MaskGIT mask half (st_mask_git.py:192-223), one block per clip, S <= 1024 keys in LDS.
+// argsort is replaced by a stable rank-by-count: rank_i = #{j : key_j < key_i or (key_j == key_i and j < i)}.
+// rank < n  -> re-mask (samples = MASK);  rank >= n -> unmasked = true.  Already-unmasked tokens carry
+// key = +inf, so they always rank behind the n still-masked lowest keys, and keep the prompt's value.
+// ------------------------------------------------------------------------------------------------
+__global__ void mask_step_kernel(const float* __restrict__ keys, int n, int last_step, int64_t mask_id,
+                                 uint8_t* __restrict__ unmasked, int64_t* __restrict__ samples,
+                                 int64_t* __restrict__ prompt_frame, long clip_stride, int S) {
+    extern __shared__ float skey[];
+    const int b = blockIdx.x;
+    uint8_t* um = unmasked + (size_t)b * S;
+    int64_t* sm = samples + (size_t)b * S;
+    int64_t* pf = prompt_frame + (size_t)b * clip_stride;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        float k = 0.f;
+        if (!last_step) k = um[i] ? INFINITY : keys[(size_t)b * S + i];
+        skey[i] = k;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        const bool prev = um[i] != 0;
+        int64_t v = sm[i];
+        if (!last_step) {
+            const float ki = skey[i];
+            int rank = 0;
+            for (int j = 0; j < S; ++j) {
+                const float kj = skey[j];
+                rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+            }
+            if (rank < n) v = mask_id; else um[i] = 1;
+        }
+        if (prev) v = pf[i];  // samples_flat[prev_unmasked] = prev_img_flat[prev_unmasked]  (:219)
+        sm[i] = v;
+        pf[i] = v;            // prompt_THW[:, out_t] = samples_HW  (:223)
+    }
+}
+
+int launch_mask_step(const float* keys, int n, int last_step, int64_t mask_id, uint8_t* unmasked, int64_t* samples,
+                     int64_t* prompt_frame, long clip_stride, int B, int S, hipStream_t st) {
+    GENIE_CHECK_SHAPE(S <= 8192, "mask_step: S=%d too large", S);
+    int threads = S >= 256 ? 256 : ((S + 63) / 64) * 64;
+    mask_step_kernel<<<B, threads, S * sizeof(float), st>>>(keys, n, last_step, mask_id, unmasked, samples,
+                                                             prompt_frame, clip_stride, S);
+    GENIE_LAUNCH_CHECK("mask_step");
+    return GENIE_OK;
+}
+
+// assert torch.all(prompt[:, out_t:] == mask)  (st_mask_git.py:155) -- on device, no host sync.
+__global__ void check_masked_kernel(const int64_t* __restrict__ prompt, int B, int T, int S, int out_t,
+                                    int64_t mask_id, int32_t* flag) {
+    long per = (long)(T - out_t) * S;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * per) return;
+    long b = idx / per, r = idx - b * per;
+    if (prompt[(size_t)b * T * S + (size_t)out_t * S + r] != mask_id) atomicExch(flag, GENIE_E_ASSERT);
+}
+
+int launch_check_masked(const int64_t* prompt, int B, int T, int S, int out_t, int64_t mask_id, int32_t* flag,
+                        hipStream_t st) {
+    long n = (long)B * (T - out_t) * S;
+    if (n <= 0 || !flag) return GENIE_OK;
+    check_masked_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(prompt, B, T, S, out_t, mask_id, flag);
+    GENIE_LAUNCH_CHECK("check_masked");
+    return GENIE_OK;
+}
+
+// a18  tokens -> +-1 bit planes, LSB first (lookup_free_quantize.py:181-194 + visualize.py:115)
+__global__ void bits_kernel(const int64_t* __restrict__ ids, float* __restrict__ z, long n, int hw, int bits) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * bits * hw) return;
+    long img = idx / ((long)bits * hw);
+    long r = idx - img * (long)bits * hw;
+    int c = (int)(r / hw), p = (int)(r - (long)c * hw);
+    z[idx] = ((ids[img * hw + p] >> c) & 1) ? 1.0f : -1.0f;
+}
+
+int launch_bits(const int64_t* ids, float* z, int n, int hw, int bits, hipStream_t st) {
+    long tot = (long)n * bits * hw;
+    if (tot <= 0) return GENIE_OK;
+    bits_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(ids, z, n, hw, bits);
+    GENIE_LAUNCH_CHECK("bits_from_tokens");
+    return GENIE_OK;
+}
+
+__global__ void pack_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f32_to_bf16(src[i]);
+}
+int launch_pack_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t st) {
+    if (!n) return GENIE_OK;
+    pack_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, dst, n);
+    GENIE_LAUNCH_CHECK("pack_bf16");
+    return GENIE_OK;
+}
+
+}  // namespace genie

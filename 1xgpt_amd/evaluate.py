@@ -1,0 +1,152 @@
+"""Teacher-forced evaluation harness -- counterpart of the reference's genie/evaluate.py.
+
+``GenieEvaluator.predict_zframe_logits`` has the reference's contract (evaluate.py:82-122): for every
+prefix [frame_0..frame_{t-1}] mask frames >= t and MaskGIT-decode frame t; return the sampled frames
+``(B, T-1, H, W)`` and the step-0 factored logits ``(B, 512, 2, T-1, H, W)``.  Differences: the device
+is synchronised before timing (the reference does not, evaluate.py:172-175), tokens never leave HBM, and
+``evaluate_clips`` adds a data-parallel entry point (one process per GPU, RCCL all-reduce of the metric
+sums) that the reference lacks ("only supports a single GPU", evaluate.py:47).
+
+Run:  python -m 1xgpt_amd.evaluate is not importable by name (leading digit); use
+      python tools/evaluate.py --checkpoint_dir DIR [--val_data_dir DIR | --synthetic N]
+"""
+import time
+
+import torch
+
+from . import _lib
+from .eval_utils import AvgMetric, compute_loss
+from .st_mask_git import STMaskGIT
+
+# Hardcoded values for the v1.1 dataset (evaluate.py:31-32)
+WINDOW_SIZE = 16
+STRIDE = 15
+
+
+class GenieEvaluator:
+    def __init__(self, args, decode_latents=None, device="cuda", model: STMaskGIT = None):
+        if model is None:
+            model = STMaskGIT.from_pretrained(args.checkpoint_dir, precision=getattr(args, "precision", "exact"))
+        self.model = model.to(device=device)
+        self.model.eval()
+        self.decode_latents = decode_latents
+        self.device = device
+        self.args = args
+
+    def predict_zframe_logits(self, input_ids: torch.LongTensor, noise=None, return_logits=True):
+        """input_ids (B, T*H*W) -> (samples (B,T-1,H,W), factored logits (B,512,2,T-1,H,W)).
+
+        Total forward passes = (T-1) * maskgit_steps (evaluate.py:90).
+        noise: optional (T-1, maskgit_steps-1, B, S) replay of the "random" unmasking draws."""
+        T = self.model.config.T
+        h, w = self.args.latent_h, self.args.latent_w
+        inputs_THW = input_ids.to(self.device).to(torch.int64).view(-1, T, h, w)
+        all_samples, all_logits = [], []
+        for k, timestep in enumerate(range(1, T)):
+            inputs_masked = inputs_THW.clone()
+            inputs_masked[:, timestep:] = self.model.mask_token_id
+            samples_HW, factored_logits = self.model.maskgit_generate(
+                inputs_masked, out_t=timestep, maskgit_steps=self.args.maskgit_steps,
+                temperature=self.args.temperature, noise=None if noise is None else noise[k],
+                return_logits=return_logits, check=False)
+            all_samples.append(samples_HW)
+            all_logits.append(factored_logits)
+        samples_THW = torch.stack(all_samples, dim=1)
+        return samples_THW, (torch.stack(all_logits, dim=3) if return_logits else None)
+
+    def predict_next_frames(self, samples_THW) -> torch.Tensor:
+        """Sampled tokens -> RGB frames (B, T-1, 3, 256, 256) uint8 through the on-device MAGVIT2 decoder."""
+        from .eval_utils import decode_tokens
+        if self.decode_latents is None:
+            raise RuntimeError("predict_next_frames needs a decode_latents callable (1xgpt_amd.magvit2)")
+        return decode_tokens(samples_THW, self.decode_latents)
+
+    @torch.no_grad()
+    def evaluate_metric_sums(self, input_ids, labels=None, noise=None):
+        """One batch of the metric loop (evaluate.py:167-179) as device-side sums, no logits materialised
+        for the caller: returns float64 tensor [sum CE, n CE tokens, sum (gt == sample), n sampled tokens,
+        n frames, n clips]."""
+        lib = _lib.load()
+        m = self.model
+        T, S = m.config.T, m.config.S
+        cfg = m._weights()[0]
+        ids = input_ids.to(self.device).to(torch.int64).view(-1, T, m.h, m.w).contiguous()
+        lab = ids if labels is None else labels.to(self.device).to(torch.int64).view(-1, T, m.h, m.w).contiguous()
+        B = ids.shape[0]
+        ce = torch.zeros(3, dtype=torch.float64, device=ids.device)
+        hits = torch.zeros((), dtype=torch.float64, device=ids.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        for k, t in enumerate(range(1, T)):
+            p = ids.clone()
+            p[:, t:] = m.mask_token_id
+            s, fl = m.maskgit_generate(p, out_t=t, maskgit_steps=self.args.maskgit_steps,
+                                       temperature=self.args.temperature,
+                                       noise=None if noise is None else noise[k], check=False)
+            # fl is a permuted view of the contiguous (B, V, H, W) step-0 logits of frame t
+            lg = fl.permute(0, 2, 1, 3, 4)
+            assert lg.is_contiguous()
+            _lib.check(lib.genie_factored_ce(cfg, lg.data_ptr(), _lib.LAYOUT_BCTHW, lab.data_ptr(), 0, B, t, t + 1,
+                                             ce.data_ptr(), stream), "genie_factored_ce")
+            hits += (ids[:, t] == s).sum()
+        n_tok = float(B * (T - 1) * S)
+        return torch.stack([ce[0], ce[2], hits, torch.tensor(n_tok, dtype=torch.float64, device=ids.device),
+                            torch.tensor(float(B * (T - 1)), dtype=torch.float64, device=ids.device),
+                            torch.tensor(float(B), dtype=torch.float64, device=ids.device)])
+
+
+@torch.no_grad()
+def evaluate_clips(evaluator: GenieEvaluator, clips: torch.LongTensor, batch_size=16, noise_seed=None,
+                   distributed=False):
+    """Metric loop over ``clips`` (N, T*H*W) with the reference's AvgMetric weighting (eval_utils.py:16-25).
+
+    With ``distributed=True`` every rank passes ITS shard of the clips; the six sums are all-reduced (SUM)
+    once at the end -- a <= 48-byte message, latency-bound on xGMI -- so the returned means are whole-job
+    means, identical on every rank.  Returns dict(loss, acc, frames, clips, seconds, frames_per_sec)."""
+    dev = evaluator.device
+    total = torch.zeros(6, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = evaluator.model
+    for i in range(0, clips.shape[0], batch_size):
+        batch = clips[i:i + batch_size]
+        noise = None
+        if noise_seed is not None and evaluator.args.maskgit_steps > 1:
+            g = torch.Generator(device="cpu").manual_seed(noise_seed + i)
+            noise = torch.rand(m.config.T - 1, evaluator.args.maskgit_steps - 1, batch.shape[0], m.config.S,
+                               generator=g).to(dev)
+        total += evaluator.evaluate_metric_sums(batch, noise=noise)
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    if distributed:
+        import torch.distributed as dist
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seconds = float(t.item())
+    tot = total.tolist()
+    return dict(loss=tot[0] / tot[1], acc=tot[2] / tot[3], frames=int(tot[4]), clips=int(tot[5]), seconds=seconds,
+                frames_per_sec=tot[4] / seconds)
+
+
+def run_reference_style_loop(evaluator: GenieEvaluator, batches, verbose=True):
+    """The reference's per-batch loop (evaluate.py:167-191) minus LPIPS: gen_time / loss / acc AvgMetrics."""
+    from collections import defaultdict
+    metrics = defaultdict(AvgMetric)
+    T = evaluator.model.config.T
+    for batch in batches:
+        ids = batch["input_ids"]
+        bs = ids.size(0)
+        torch.cuda.synchronize()
+        start = time.time()
+        samples, factored_logits = evaluator.predict_zframe_logits(ids)
+        torch.cuda.synchronize()
+        frames_per_batch = (T - 1) * bs
+        metrics["gen_time"].update((time.time() - start) / frames_per_batch, bs)
+        loss = compute_loss(batch["labels"], factored_logits)
+        gt = ids.to(samples.device).view(bs, T, *samples.shape[-2:])
+        acc = (gt[:, 1:] == samples).float().mean().item()
+        metrics["loss"].update(loss, bs)
+        metrics["acc"].update(acc, bs)
+        if verbose:
+            print({key: f"{val.mean():.4f}" for key, val in metrics.items()})
+    return metrics

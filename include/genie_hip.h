@@ -1,0 +1,206 @@
+/* genie_hip.h -- C ABI of libgenie_hip.so: the MI355X (gfx950) GENIE forward / MaskGIT sampling path.
+ *
+ * The reference (1x-technologies/1xgpt) has no FFI of its own: its seam is the Python nn.Module
+ * surface.  Each entry point below names the reference call it replaces
+ * (file:line relative to the reference tree); the drop-in Python module in 1xgpt_amd/ binds them with
+ * ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative GENIE_E_* code otherwise; nothing throws or aborts;
+ *    genie_last_error() returns a thread-local description of the last failure.
+ *  - all pointers are DEVICE pointers unless the name ends in _host; they are borrowed for the call only.
+ *  - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *  - no allocation: the caller owns the workspace (genie_workspace_bytes) and every output buffer.
+ *  - token ids are int64 (torch.LongTensor), activations/logits float32, flags uint8.
+ *  - activations are token-major (B, T, S, C) row-major; nothing is ever physically transposed to
+ *    (B S) T C (reference st_transformer.py:77,82): the temporal kernel reads frame-strided rows.
+ */
+#ifndef GENIE_HIP_H
+#define GENIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENIE_ABI_VERSION 1
+
+enum {
+    GENIE_OK = 0,
+    GENIE_E_ARG = -1,         /* null pointer / bad size */
+    GENIE_E_SHAPE = -2,       /* shape not supported by the kernels (see genie_check_config) */
+    GENIE_E_UNSUPPORTED = -3, /* feature flag not supported */
+    GENIE_E_LAUNCH = -4,      /* HIP reported a launch / runtime error */
+    GENIE_E_ASSERT = -5       /* a reference `assert` would have fired (st_mask_git.py:154-156) */
+};
+
+enum { GENIE_PREC_EXACT = 0, /* f32 MFMA, f32 everywhere: the parity gate */
+       GENIE_PREC_BF16 = 1   /* bf16 MFMA operands, f32 accumulate/residual/LN/softmax */ };
+
+enum { GENIE_LAYOUT_TOKEN_MAJOR = 0, /* (B, nt, S, V)              */
+       GENIE_LAYOUT_BCTHW = 1        /* (B, V, nt, S) == "B C T H W" (st_mask_git.py:264) */ };
+
+enum { GENIE_UNMASK_RANDOM = 0, GENIE_UNMASK_GREEDY = 1 }; /* st_mask_git.py:200-209 */
+
+/* GenieConfig (genie/config.py:7-55) reduced to what the kernels need. */
+typedef struct genie_cfg {
+    int32_t num_layers, num_heads, head_dim, d_model;
+    int32_t T, S;
+    int32_t hidden;            /* int(d_model * mlp_ratio) */
+    int32_t factored_vocab;    /* 512 */
+    int32_t num_factored;      /* 1 or 2 */
+    int32_t image_vocab_size;  /* == mask token id (st_mask_git.py:51) */
+    int32_t qk_norm, use_mup, qkv_bias, proj_bias, mlp_bias;
+    float attn_scale;          /* use_mup ? 8/Dh : Dh^-0.5 (attention.py:26) */
+    float readout_mult;        /* use_mup ? output_mult/width_mult : 1 (st_mask_git.py:316-323) */
+    int32_t precision;         /* GENIE_PREC_* */
+} genie_cfg;
+
+/* SelfAttention parameters (genie/attention.py:27-34). *_w16 are bf16 copies made by
+ * genie_pack_bf16 (only read when precision == GENIE_PREC_BF16). */
+typedef struct genie_attn_weights {
+    const float* qkv_w;  /* (3d, d) */
+    const float* qkv_b;  /* (3d) or NULL */
+    const float* proj_w; /* (d, d) */
+    const float* proj_b; /* (d) or NULL */
+    const float* norm_w; /* (Dh) qk-norm affine shared by q and k, or NULL */
+    const float* norm_b;
+    const uint16_t* qkv_w16;
+    const uint16_t* proj_w16;
+} genie_attn_weights;
+
+/* STBlock parameters (genie/st_transformer.py:28-68). */
+typedef struct genie_layer_weights {
+    const float* norm1_w; /* (d) or NULL when qk_norm (Identity) */
+    const float* norm1_b;
+    genie_attn_weights spatial;
+    genie_attn_weights temporal;
+    const float* norm2_w;
+    const float* norm2_b;
+    const float* fc1_w; /* (hidden, d) */
+    const float* fc1_b;
+    const float* fc2_w; /* (d, hidden) */
+    const float* fc2_b;
+    const uint16_t* fc1_w16;
+    const uint16_t* fc2_w16;
+} genie_layer_weights;
+
+/* STMaskGIT parameters (genie/st_mask_git.py:36-61); `layers` is a HOST array of num_layers entries. */
+typedef struct genie_weights {
+    const float* pos_embed;  /* (T, S, d) */
+    const float* mask_embed; /* (d) */
+    const float* embed[4];   /* num_factored tables of (factored_vocab, d) */
+    const float* out_w;      /* (num_factored*factored_vocab, d) */
+    const float* out_b;
+    const uint16_t* out_w16;
+    const genie_layer_weights* layers_host;
+} genie_weights;
+
+int genie_version(void);
+const char* genie_last_error(void);
+/* 0 if the kernels support this configuration, GENIE_E_SHAPE otherwise (message in genie_last_error). */
+int genie_check_config(const genie_cfg* cfg);
+/* Bytes of workspace genie_compute_* / genie_maskgit_generate need for a batch of B clips. */
+size_t genie_workspace_bytes(const genie_cfg* cfg, int B);
+
+/* f32 -> bf16 (round-to-nearest-even) weight packing for GENIE_PREC_BF16. */
+int genie_pack_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
+
+/* ---- unit entry points (one reference op each; used by the parity tests) -------------------------- */
+
+/* FactorizedEmbedding.forward + pos-embed add (factorization_utils.py:29-52, st_mask_git.py:257-261).
+ * ids (B,T,S) int64 -> x (B,T,S,d). */
+int genie_embed(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, float* x, void* stream);
+
+/* nn.LayerNorm(C, eps) over the last dim of (rows, C) (st_transformer.py:44,67). */
+int genie_layer_norm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps,
+                     void* stream);
+
+/* nn.Linear: y = x W^T (+b) with optional fused erf-GELU and residual accumulate (y += ...).
+ * x (M,K), W (N,K), y (M,N).  (attention.py:27,29; st_transformer.py:16-25) */
+int genie_linear(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int gelu,
+                 int accumulate, void* stream);
+
+/* softmax(scale q k^T [+causal]) v on a packed qkv buffer (attention.py:38-59).
+ * qkv (B,T,S,3d) with feature index = which*d + head*Dh + i; out (B,T,S,d).
+ * spatial: sequences are the S tokens of one (b,t), non-causal (st_transformer.py:73-74);
+ * temporal: sequences are the T frames of one (b,s), causal (st_transformer.py:77-78). */
+int genie_spatial_attention(const genie_cfg* cfg, const genie_attn_weights* aw, const float* qkv, float* out, int B,
+                            void* stream);
+int genie_temporal_attention(const genie_cfg* cfg, const genie_attn_weights* aw, const float* qkv, float* out, int B,
+                             void* stream);
+
+/* The same core on contiguous sequences: qkv (n_seq, N, 3*H*Dh) -> out (n_seq, N, H*Dh); this is the
+ * body of SelfAttention.forward(x, causal) between the qkv and proj Linears (attention.py:38-59) and the
+ * shape test_attention.py exercises.  norm_w/norm_b NULL = no qk-norm. */
+int genie_attention_core(const float* qkv, float* out, int n_seq, int N, int num_heads, int head_dim, float scale,
+                         int causal, const float* norm_w, const float* norm_b, void* stream);
+
+/* STBlock.forward in place on x (B,T,S,d) (st_transformer.py:70-83). */
+int genie_st_block_forward(const genie_cfg* cfg, const genie_layer_weights* lw_host, float* x, int B, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* STTransformerDecoder.forward in place (st_transformer.py:115-120). */
+int genie_decoder_forward(const genie_cfg* cfg, const genie_weights* w, float* x, int B, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* out_x_proj (+ muP pre-scale) for frames [t0,t1) (st_mask_git.py:60-61,262-264,316-323). */
+int genie_readout_logits(const genie_cfg* cfg, const genie_weights* w, const float* x, int B, int t0, int t1,
+                         int layout, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- whole-path entry points ------------------------------------------------------------------------ */
+
+/* STMaskGIT.compute_logits (st_mask_git.py:255-265): ids (B,T,S) -> logits of frames [t0,t1). */
+int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int t0, int t1,
+                         int layout, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Factored cross-entropy + accuracy partial sums from token-major or BCTHW logits of frames [t0,t1)
+ * (st_mask_git.py:231-253; eval_utils.py:44-77).
+ *   targets (B,T,S) int64 (full clip; frames [t0,t1) are read)
+ *   weight_ids: if non-NULL (B,T,S) int64, a token counts only where weight_ids == mask id
+ *               (STMaskGIT.forward's relevant_mask, st_mask_git.py:276); NULL = every token (compute_loss).
+ *   sums_out: 3 doubles, ACCUMULATED: [sum CE, sum (all factors argmax-correct), n tokens counted].  */
+int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, const int64_t* targets,
+                      const int64_t* weight_ids, int B, int t0, int t1, double* sums_out, void* stream);
+
+/* Fused readout + CE for frames [t0,t1) without materialising logits for the caller. */
+int genie_readout_ce(const genie_cfg* cfg, const genie_weights* w, const float* x, const int64_t* targets,
+                     const int64_t* weight_ids, int B, int t0, int t1, double* sums_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* MaskGIT sampling half (st_mask_git.py:171-190) on one frame's logits.
+ *   logits: (B,S,V) token-major or (B,V,S) BCTHW with nt == 1
+ *   temperature <= 1e-8 -> argmax (first max wins); otherwise inverse-CDF sampling with caller-supplied
+ *   uniforms (num_factored, B, S) float32, factor order = most significant first (flip(2), :179).
+ *   samples (B,S) int64 = hi*Vf + lo;  conf (B,S) float32 = prod p[sample]. */
+int genie_sample(const genie_cfg* cfg, const float* logits, int layout, int B, float temperature,
+                 const float* uniforms, int64_t* samples, float* conf, void* stream);
+
+/* MaskGIT mask half for one step (st_mask_git.py:192-223), one frame of B clips.
+ *   keys (B,S) float32: caller's torch.rand draws ("random") or conf ("greedy"); ignored if last_step
+ *   n: tokens to re-mask (ceil(cos(pi/2 (step+1)/steps) S)); unmasked (B,S) uint8 in/out;
+ *   samples (B,S) int64 in/out; prompt_frame: pointer to prompt[0, out_t, 0], clip stride in elements.
+ *   Writes the final samples back into the prompt frame (in-place semantics of :223). */
+int genie_mask_step(const float* keys, int n, int last_step, int64_t mask_id, uint8_t* unmasked, int64_t* samples,
+                    int64_t* prompt_frame, int64_t prompt_clip_stride, int B, int S, void* stream);
+
+/* STMaskGIT.maskgit_generate (st_mask_git.py:123-229), whole loop on the device, no host sync.
+ *   prompt (B,T,S) int64, frames >= out_t must be all-mask (checked on device: violation sets *status_flag
+ *   (device int32, may be NULL) to GENIE_E_ASSERT); prompt[:, out_t] is overwritten in place.
+ *   noise: (steps-1, B, S) float32 U[0,1) draws for GENIE_UNMASK_RANDOM (NULL allowed when steps == 1 or greedy)
+ *   uniforms: (steps, num_factored, B, S) for temperature > 1e-8, else NULL
+ *   samples_out (B,S) int64; logits0_out: step-0 logits of frame out_t in `layout` (NULL = not wanted). */
+int genie_maskgit_generate(const genie_cfg* cfg, const genie_weights* w, int64_t* prompt, int B, int out_t, int steps,
+                           float temperature, int unmask_mode, const float* noise, const float* uniforms,
+                           int64_t* samples_out, float* logits0_out, int layout, int32_t* status_flag,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* LFQ.get_codebook_entry(...).flip(1) (lookup_free_quantize.py:181-194, visualize.py:115):
+ * ids (n, hw) int64 -> z (n, bits, hw) float32 in {-1,+1}, channel c = bit c (LSB first). */
+int genie_bits_from_tokens(const int64_t* ids, float* z, int n, int hw, int bits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENIE_HIP_H */

@@ -146,3 +146,20 @@ def test_round_bf16():
     import torch
     ref = torch.from_numpy(a).to(torch.bfloat16).float().numpy()
     assert np.array_equal(r, ref)
+
+
+@pytest.mark.parametrize("name", ["anchor_c35", "anchor_c138"])
+def test_full_size_anchor(golden, name):
+    """32-layer shapes (C35 = shipped config, C138-shape = inferred GENIE_138M): forward CE + 2-step MaskGIT ids."""
+    z, cfg, sd = golden(name)
+    W = 16
+    ids = z["ids"]
+    x = ids.reshape(-1, 16, 16, 16).copy()
+    x[:, 8:] = cfg.image_vocab_size
+    loss, acc, logits = O.forward_loss_acc(x.reshape(1, -1), ids, sd, cfg)
+    assert abs(loss - float(z["fwd_loss"])) < 1e-4
+    assert abs(acc - float(z["fwd_acc"])) < 1e-7
+    probe = np.stack([logits[:, :, t, s // W, s % W] for t, s in zip(z["probe_t"], z["probe_s"])], 1)
+    assert np.abs(probe - z["probe_logits"]).max() < 2e-4
+    s, _ = O.maskgit_generate(x.copy(), 8, sd, cfg, 2, noise=z["mg_s2_noise"])
+    assert np.array_equal(s, z["mg_s2_samples"])
