@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libgenie_hip.so")
 PREC_EXACT, PREC_BF16 = 0, 1
 LAYOUT_TOKEN_MAJOR, LAYOUT_BCTHW = 0, 1
 UNMASK_RANDOM, UNMASK_GREEDY = 0, 1
+KC_GEMM, KC_ATTN_SPATIAL, KC_ATTN_TEMPORAL, KC_LAYERNORM, KC_OTHER = range(5)
 E_ARG, E_SHAPE, E_UNSUPPORTED, E_LAUNCH, E_ASSERT = -1, -2, -3, -4, -5
 
 c_f32p = C.c_void_p  # device pointers travel as plain integers
@@ -72,6 +73,9 @@ SIGNATURES = {
     "genie_maskgit_generate": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr, c_ptr,
                                          C.c_size_t, c_ptr]),
+    "genie_profile_enable": (C.c_int, [C.c_int]),
+    "genie_profile_reset": (C.c_int, []),
+    "genie_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "genie_bits_from_tokens": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
 }
 

@@ -20,6 +20,25 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- per-launch event profiler ------------------------------------------------------------------
+static int g_prof_mask = 0;
+static int g_prof_n = 0;
+static hipEvent_t* g_prof_ev = nullptr;  // 2 * GENIE_PROFILE_MAX_LAUNCHES events, created on first enable
+static int g_prof_cls[GENIE_PROFILE_MAX_LAUNCHES];
+static double g_prof_flops[GENIE_PROFILE_MAX_LAUNCHES], g_prof_bytes[GENIE_PROFILE_MAX_LAUNCHES];
+
+ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
+    if (!(g_prof_mask & (1 << cls)) || g_prof_n >= GENIE_PROFILE_MAX_LAUNCHES || !g_prof_ev) return;
+    slot = g_prof_n++;
+    g_prof_cls[slot] = cls;
+    g_prof_flops[slot] = flops;
+    g_prof_bytes[slot] = bytes;
+    (void)hipEventRecord(g_prof_ev[2 * slot], st);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], st);
+}
+
 // Workspace carving.  All offsets 256-byte aligned.
 struct Workspace {
     float* x;        // (M, d)      residual stream, f32 in both precisions
@@ -95,8 +114,12 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
     const float* nw = c.qk_norm ? aw.norm_w : nullptr;
     const float* nb = c.qk_norm ? aw.norm_b : nullptr;
     if (!temporal) {
-        GENIE_TRY(launch_attn_generic(qkv, ao, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
-                                      c.attn_scale, 0, nw, nb, st));
+        int rc = launch_attn_spatial_f32_mfma(qkv, ao, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale,
+                                              nw, nb, st);
+        if (rc == GENIE_E_UNSUPPORTED)  // no MFMA instantiation for this geometry: generic kernel
+            rc = launch_attn_generic(qkv, ao, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
+                                     c.attn_scale, 0, nw, nb, st);
+        GENIE_TRY(rc);
     } else {
         GENIE_TRY(launch_attn_generic(qkv, ao, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
                                       c.head_dim, c.attn_scale, 1, nw, nb, st));
@@ -214,9 +237,13 @@ int genie_spatial_attention(const genie_cfg* cfg, const genie_attn_weights* aw, 
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(aw && qkv && out && B >= 1, "spatial_attention: bad argument");
     const genie_cfg& c = *cfg;
+    const float* nw = c.qk_norm ? aw->norm_w : nullptr;
+    const float* nb = c.qk_norm ? aw->norm_b : nullptr;
+    int rc = launch_attn_spatial_f32_mfma(qkv, out, c.S, (long)B * c.T, c.d_model, c.num_heads, c.head_dim,
+                                          c.attn_scale, nw, nb, as_stream(stream));
+    if (rc != GENIE_E_UNSUPPORTED) return rc;
     return launch_attn_generic(qkv, out, c.S, (long)B * c.T, 1, c.S, 0, 1, c.d_model, c.num_heads, c.head_dim,
-                               c.attn_scale, 0, c.qk_norm ? aw->norm_w : nullptr, c.qk_norm ? aw->norm_b : nullptr,
-                               as_stream(stream));
+                               c.attn_scale, 0, nw, nb, as_stream(stream));
 }
 
 int genie_temporal_attention(const genie_cfg* cfg, const genie_attn_weights* aw, const float* qkv, float* out, int B,
@@ -234,6 +261,11 @@ int genie_attention_core(const float* qkv, float* out, int n_seq, int N, int num
     GENIE_CHECK_ARG(qkv && out && n_seq >= 0 && N >= 1 && num_heads >= 1, "attention_core: bad argument");
     GENIE_CHECK_ARG((norm_w == nullptr) == (norm_b == nullptr), "attention_core: norm_w/norm_b must come together");
     if (n_seq == 0) return GENIE_OK;
+    if (!causal) {
+        int rc = launch_attn_spatial_f32_mfma(qkv, out, N, n_seq, num_heads * head_dim, num_heads, head_dim, scale,
+                                              norm_w, norm_b, as_stream(stream));
+        if (rc != GENIE_E_UNSUPPORTED) return rc;
+    }
     return launch_attn_generic(qkv, out, N, n_seq, 1, N, 0, 1, num_heads * head_dim, num_heads, head_dim, scale,
                                causal, norm_w, norm_b, as_stream(stream));
 }
@@ -375,6 +407,44 @@ int genie_maskgit_generate(const genie_cfg* cfg, const genie_weights* wt, int64_
     if (hipMemcpyAsync(samples_out, w.samples, BS * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
         set_error("memcpy failed");
         return GENIE_E_LAUNCH;
+    }
+    return GENIE_OK;
+}
+
+int genie_profile_enable(int class_mask) {
+    if (class_mask && !g_prof_ev) {
+        g_prof_ev = new hipEvent_t[2 * GENIE_PROFILE_MAX_LAUNCHES];
+        for (int i = 0; i < 2 * GENIE_PROFILE_MAX_LAUNCHES; ++i) {
+            if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) {
+                set_error("profile: hipEventCreate failed at %d", i);
+                return GENIE_E_LAUNCH;
+            }
+        }
+    }
+    g_prof_mask = class_mask;
+    return GENIE_OK;
+}
+
+int genie_profile_reset(void) {
+    g_prof_n = 0;
+    return GENIE_OK;
+}
+
+int genie_profile_read(int kernel_class, double* out4) {
+    GENIE_CHECK_ARG(out4 && kernel_class >= 0 && kernel_class < GENIE_KC_COUNT, "profile_read: bad argument");
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (g_prof_cls[i] != kernel_class) continue;
+        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) { set_error("profile: sync failed"); return GENIE_E_LAUNCH; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess) {
+            set_error("profile: elapsed failed");
+            return GENIE_E_LAUNCH;
+        }
+        out4[0] += 1.0;
+        out4[1] += ms;
+        out4[2] += g_prof_flops[i];
+        out4[3] += g_prof_bytes[i];
     }
     return GENIE_OK;
 }

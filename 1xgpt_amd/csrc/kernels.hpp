@@ -6,6 +6,14 @@ namespace genie {
 
 enum { GEMM_GELU = 1, GEMM_ACCUM = 2, GEMM_BIAS_ALONG_M = 4 };
 
+// Brackets one launch with HIP events when profiling of `cls` is enabled (see genie_profile_* in the ABI).
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    ProfScope(int cls, double flops, double bytes, hipStream_t st);
+    ~ProfScope();
+};
+
 int launch_embed(const genie_cfg& c, const genie_weights& w, const int64_t* ids, int B, float* x, hipStream_t st);
 int launch_layer_norm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps,
                       hipStream_t st);
@@ -21,6 +29,8 @@ int launch_attn_generic(const float* qkv, float* out, int N, long n_seq, int inn
 int launch_attn_generic_bf16(const uint16_t* qkv, uint16_t* out, int N, long n_seq, int inner, long outer_stride,
                              long inner_stride, long pos_stride, int d, int H, int Dh, float scale, int causal,
                              const float* nw, const float* nb, hipStream_t st);
+int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
+                                 const float* nw, const float* nb, hipStream_t st);
 int launch_transpose(const float* in, float* out, int batch, int rows, int cols, hipStream_t st);
 int launch_factored_ce(const genie_cfg& c, const float* logits, int layout, const int64_t* targets,
                        const int64_t* weight_ids, int B, int t0, int t1, double* sums, hipStream_t st);

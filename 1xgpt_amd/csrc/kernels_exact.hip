@@ -84,6 +84,7 @@ int launch_layer_norm(const float* x, const float* g, const float* b, float* y, 
                       hipStream_t st) {
     GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
     int blocks = (int)((rows + 3) / 4);
+    ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * rows * C, 8.0 * rows * C, st);
     layer_norm_kernel<float><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
     GENIE_LAUNCH_CHECK("layer_norm");
     return GENIE_OK;
@@ -92,6 +93,7 @@ int launch_layer_norm_bf16(const float* x, const float* g, const float* b, uint1
                            hipStream_t st) {
     GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
     int blocks = (int)((rows + 3) / 4);
+    ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * rows * C, 6.0 * rows * C, st);
     layer_norm_kernel<uint16_t><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
     GENIE_LAUNCH_CHECK("layer_norm_bf16");
     return GENIE_OK;
@@ -230,6 +232,9 @@ int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long
     if (M <= 0 || N <= 0 || batch <= 0) return GENIE_OK;
     int mt = (M + GEMM_BM - 1) / GEMM_BM, nt = (N + GEMM_BN - 1) / GEMM_BN;
     dim3 grid(mt * nt, batch);
+    const double mnk = (double)M * N * batch;
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * mnk * K,
+                   4.0 * ((double)M * K * batch + (double)N * K + mnk * ((flags & GEMM_ACCUM) ? 2 : 1)), st);
     gemm_f32_nt_kernel<<<grid, 256, 0, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags,
                                              alpha);
     GENIE_LAUNCH_CHECK("gemm_f32");
@@ -364,6 +369,10 @@ static int launch_attn_generic_t(const InT* qkv, OutT* out, int N, long n_seq, i
     size_t lds = (size_t)spb * N * Dh * 2 * sizeof(float);
     GENIE_CHECK_SHAPE(lds <= 160 * 1024, "attention: N=%d x Dh=%d does not fit LDS", N, Dh);
     dim3 grid((unsigned)((n_seq + spb - 1) / spb), H);
+    // algorithmic work: QK^T and PV = 4*N*N*Dh flops per (sequence, head) (causal counted dense);
+    // bytes: read q,k,v + write o once
+    ProfScope prof(causal ? GENIE_KC_ATTN_TEMPORAL : GENIE_KC_ATTN_SPATIAL, 4.0 * N * N * Dh * H * (double)n_seq,
+                   (double)n_seq * N * H * Dh * (3 * sizeof(InT) + sizeof(OutT)), st);
 #define GENIE_ATTN_CASE(DHV)                                                                                   \
     case DHV:                                                                                                  \
         (void)hipFuncSetAttribute((const void*)attn_generic_kernel<DHV, InT, OutT>,                                  \
@@ -725,6 +734,183 @@ int launch_pack_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t st) 
     if (!n) return GENIE_OK;
     pack_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, dst, n);
     GENIE_LAUNCH_CHECK("pack_bf16");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a7  Spatial attention on the f32 matrix cores (exact precision), S = NKT*32 keys, one workgroup per
+// (sequence, head), 8 waves, each wave owns 32 query rows.
+//
+//   S^T = K Q^T   "swapped" so that lane (q = lane&31, h = lane>>5) ends up holding, for ITS query, the
+//                 scores of keys {32*kt + (e&3) + 8*(e>>2) + 4h}: the softmax row-reduction is in-lane
+//                 plus one cross-half exchange, no LDS round trip.
+//   O   = P V     P stays in those registers: register e of tile kt is exactly the A operand of
+//                 v_mfma_f32_32x32x2_f32 for the key pair {k0, k0+4}, with B = V[k0 + 4h][d] read
+//                 row-wise (conflict-free) from LDS.
+// K and V rows (qk-normed on the way in) live in LDS with a +4 float row pad, so the float4 operand
+// fetches of K hit 16 distinct 16-byte slots per ds_read_b128 lane group.
+// ------------------------------------------------------------------------------------------------
+template <int DH, int NKT>
+__global__ __launch_bounds__(512) void attn_spatial_f32_mfma_kernel(const float* __restrict__ qkv,
+                                                                    float* __restrict__ out, int d, float scale,
+                                                                    const float* __restrict__ nw,
+                                                                    const float* __restrict__ nb) {
+    constexpr int S = NKT * 32, LD = DH + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;
+    float* sV = smem + S * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long row0 = (long)blockIdx.x * S;
+    const int head = blockIdx.y;
+    const float* base = qkv + (size_t)row0 * 3 * d + head * DH;
+
+    // ---- stage K (normalised) and V: two adjacent lanes per row, DH/2 contiguous floats each
+    for (int rr = tid >> 1; rr < S; rr += 256) {
+        const int half = tid & 1;
+        const float* kp = base + (size_t)rr * 3 * d + d + half * (DH / 2);
+        const float* vp = kp + d;
+        float kx[DH / 2];
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            float4 t = *reinterpret_cast<const float4*>(kp + 4 * c);
+            kx[4 * c] = t.x; kx[4 * c + 1] = t.y; kx[4 * c + 2] = t.z; kx[4 * c + 3] = t.w;
+            *reinterpret_cast<float4*>(&sV[rr * LD + half * (DH / 2) + 4 * c]) =
+                *reinterpret_cast<const float4*>(vp + 4 * c);
+        }
+        if (nw) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) s += kx[c];
+            s += __shfl_xor(s, 1);
+            const float mu = s / DH;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) { float t = kx[c] - mu; v += t * t; }
+            v += __shfl_xor(v, 1);
+            const float rs = 1.0f / sqrtf(v / DH + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) {
+                const int cc = half * (DH / 2) + c;
+                kx[c] = (kx[c] - mu) * rs * nw[cc] + nb[cc];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c)
+            *reinterpret_cast<float4*>(&sK[rr * LD + half * (DH / 2) + 4 * c]) =
+                make_float4(kx[4 * c], kx[4 * c + 1], kx[4 * c + 2], kx[4 * c + 3]);
+    }
+    __syncthreads();
+
+    for (int qb = wid; qb < NKT; qb += 8) {
+        // ---- Q fragment of this wave's 32 queries: lane (r,h) holds Q[r][8kk + 4h + j]
+        float4 qf[DH / 8];
+        {
+            const float* qp = base + (size_t)(qb * 32 + r) * 3 * d + 4 * h;
+#pragma unroll
+            for (int kk = 0; kk < DH / 8; ++kk) qf[kk] = *reinterpret_cast<const float4*>(qp + 8 * kk);
+            if (nw) {
+                float s = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < DH / 8; ++kk) s += qf[kk].x + qf[kk].y + qf[kk].z + qf[kk].w;
+                s += __shfl_xor(s, 32);
+                const float mu = s / DH;
+                float v = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < DH / 8; ++kk) {
+                    float a = qf[kk].x - mu, b = qf[kk].y - mu, c = qf[kk].z - mu, e = qf[kk].w - mu;
+                    v += a * a + b * b + c * c + e * e;
+                }
+                v += __shfl_xor(v, 32);
+                const float rs = 1.0f / sqrtf(v / DH + 1e-5f);
+#pragma unroll
+                for (int kk = 0; kk < DH / 8; ++kk) {
+                    const int c0 = 8 * kk + 4 * h;
+                    qf[kk].x = (qf[kk].x - mu) * rs * nw[c0] + nb[c0];
+                    qf[kk].y = (qf[kk].y - mu) * rs * nw[c0 + 1] + nb[c0 + 1];
+                    qf[kk].z = (qf[kk].z - mu) * rs * nw[c0 + 2] + nb[c0 + 2];
+                    qf[kk].w = (qf[kk].w - mu) * rs * nw[c0 + 3] + nb[c0 + 3];
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < DH / 8; ++kk) {  // q *= scale  (attention.py:48)
+                qf[kk].x *= scale; qf[kk].y *= scale; qf[kk].z *= scale; qf[kk].w *= scale;
+            }
+        }
+        // ---- S^T tiles
+        f32x16 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < DH / 8; ++kk) {
+                const float4 a = *reinterpret_cast<const float4*>(&sK[(kt * 32 + r) * LD + 8 * kk + 4 * h]);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[kk].x, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[kk].y, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[kk].z, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[kk].w, sc[kt], 0, 0, 0);
+            }
+        }
+        // ---- softmax over the 256 keys of query r (128 in this lane, 128 in lane r^32)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[kt][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sc[kt][e] = expf(sc[kt][e] - mx); sum += sc[kt][e]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // ---- O = P V
+        f32x16 oc[DH / 32];
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oc[dt][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = sc[kt][e] * inv;
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+                for (int dt = 0; dt < DH / 32; ++dt)
+                    oc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p, sV[key * LD + dt * 32 + r], oc[dt], 0, 0, 0);
+            }
+        // ---- store: C/D map row = (e&3) + 8*(e>>2) + 4h (query), col = r (feature)
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int q = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[(size_t)(row0 + q) * d + head * DH + dt * 32 + r] = oc[dt][e];
+            }
+    }
+}
+
+// Spatial attention, contiguous sequences of S rows.  Returns GENIE_E_UNSUPPORTED when the shape has no
+// MFMA instantiation (the caller then uses the generic kernel).
+int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
+                                 const float* nw, const float* nb, hipStream_t st) {
+    if (S != 256 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
+    const size_t lds = (size_t)2 * S * (Dh + 4) * sizeof(float);
+    dim3 grid((unsigned)n_seq, H);
+    ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * Dh * H * (double)n_seq, (double)n_seq * S * H * Dh * 16.0, st);
+    if (Dh == 64) {
+        (void)hipFuncSetAttribute((const void*)attn_spatial_f32_mfma_kernel<64, 8>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attn_spatial_f32_mfma_kernel<64, 8><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb);
+    } else {
+        (void)hipFuncSetAttribute((const void*)attn_spatial_f32_mfma_kernel<32, 8>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attn_spatial_f32_mfma_kernel<32, 8><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb);
+    }
+    GENIE_LAUNCH_CHECK("attn_spatial_f32_mfma");
     return GENIE_OK;
 }
 

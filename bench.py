@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sampled frames/sec + teacher-forced CE of the GENIE path on MI355X.
+
+One "step" = the teacher-forced evaluation of one batch of synthetic 16x256-token clips, exactly the
+reference's metric loop (genie/evaluate.py:82-122, 167-179): for t = 1..15 mask frames >= t and
+MaskGIT-decode frame t (maskgit_steps full forwards each), accumulate the factored CE of the step-0
+logits and the sampled-token accuracy.  15*B frames are sampled per step per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (schema in the task contract) with two extra objects:
+  roofline     -- the dominant kernel (the MFMA GEMM): algorithmic FLOPs / measured launch time (HIP events
+                  recorded on the launch stream inside the timed region) against the MFMA peak of the dtype
+  cpu_baseline -- the NumPy oracle timed on this host's cores on a bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"exact": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32 MFMA / dense bf16 MFMA
+DTYPE = {"exact": "f32", "bf16": "bf16"}
+PUBLISHED_FRAMES_PER_SEC = {"c138": 1.0 / 0.075, "c35": 1.0 / 0.030}  # BASELINE.md section 1 (1x RTX 4090, fp32)
+
+
+def pass_flops(cfg):
+    """Algorithmic FLOPs of one forward pass of one clip."""
+    d, L, S, T = cfg.d_model, cfg.num_layers, cfg.S, cfg.T
+    V = cfg.factored_vocab_size * cfg.num_factored_vocabs
+    return T * S * (L * (32 * d * d + 4 * S * d + 4 * T * d) + 2 * d * V)
+
+
+def cpu_baseline(cfg, sd, clips, maskgit_steps, timesteps=(8,), max_threads=32):
+    """Oracle (NumPy port of the reference path) on the host cores: a bounded sample of the same workload.
+    BLAS threads are capped at `max_threads`: on a 128-core host the 4096x512 GEMMs of one clip do not scale
+    further and oversubscription makes the run slower."""
+    O = importlib.import_module("oracle.genie_oracle")
+    synth = importlib.import_module("1xgpt_amd.synthetic")
+    from threadpoolctl import threadpool_info, threadpool_limits
+    ids = clips[:1]
+    H = W = int(round(cfg.S ** 0.5))
+    x = ids.reshape(1, cfg.T, H, W)
+    noise = synth.make_noise((len(timesteps), max(maskgit_steps - 1, 1), 1, cfg.S), seed=42)
+    cores = min(max_threads, os.cpu_count() or 1)
+    with threadpool_limits(limits=cores):
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+        t0 = time.perf_counter()
+        for k, t in enumerate(timesteps):
+            p = x.copy()
+            p[:, t:] = cfg.image_vocab_size
+            O.maskgit_generate(p, t, sd, cfg, maskgit_steps, 0.0, "random", noise=noise[k])
+        dt = time.perf_counter() - t0
+    return {"value": len(timesteps) / dt, "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "sample": f"NumPy/OpenBLAS f32 oracle, 1 clip, timesteps {list(timesteps)} of 1..15, "
+                      f"{maskgit_steps} MaskGIT steps ({len(timesteps) * maskgit_steps} full forwards), "
+                      f"{dt:.1f} s on {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", choices=["exact", "bf16"], default=os.environ.get("GENIE_BENCH_PRECISION", "exact"))
+    ap.add_argument("--model", choices=["c138", "c35"], default="c138")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step")
+    ap.add_argument("--maskgit-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel-class times")
+    args = ap.parse_args()
+
+    dist_mod = importlib.import_module("1xgpt_amd.distributed")
+    rank, world, local_rank = dist_mod.init_distributed()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfgmod = importlib.import_module("1xgpt_amd.config")
+    synth = importlib.import_module("1xgpt_amd.synthetic")
+    _lib = importlib.import_module("1xgpt_amd._lib")
+    STMaskGIT = importlib.import_module("1xgpt_amd.st_mask_git").STMaskGIT
+    evalmod = importlib.import_module("1xgpt_amd.evaluate")
+    lib = _lib.load()
+
+    cfg = cfgmod.c138() if args.model == "c138" else cfgmod.c35()
+    B = args.batch or (4 if args.precision == "exact" else 32)
+    sd = synth.make_state_dict(cfg, seed=0, law="conditioned")
+    model = STMaskGIT(cfg, precision=args.precision).load_numpy_state_dict(sd).to(dev)
+    all_clips = synth.make_clips(B * world, cfg, seed=1234)
+    lo, hi = dist_mod.shard_range(B * world, rank, world)
+    clips = torch.from_numpy(all_clips[lo:hi]).to(dev)
+    noise = torch.from_numpy(synth.make_noise((cfg.T - 1, max(args.maskgit_steps - 1, 1), hi - lo, cfg.S),
+                                              seed=42 + rank)).to(dev)
+    ev_args = argparse.Namespace(maskgit_steps=args.maskgit_steps, temperature=0.0, latent_h=model.h,
+                                 latent_w=model.w)
+    ev = evalmod.GenieEvaluator(ev_args, None, dev, model=model)
+
+    def step():
+        sums = ev.evaluate_metric_sums(clips, noise=noise)
+        dist_mod.reduce_metric_sums(sums)  # RCCL all-reduce of the metric sums (no-op at N=1)
+        return sums
+
+    for _ in range(args.warmup):
+        step()
+    # timed region: exactly K steps, GEMM launches bracketed by HIP events on the launch stream
+    _lib.check(lib.genie_profile_enable(1 << _lib.KC_GEMM), "profile_enable")
+    lib.genie_profile_reset()
+    dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sums = None
+    for _ in range(args.steps):
+        sums = step()
+    torch.cuda.synchronize()
+    dist_mod.barrier()
+    seconds = time.perf_counter() - t0
+    tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    seconds = float(tt.item())
+    prof = (ctypes.c_double * 4)()
+    _lib.check(lib.genie_profile_read(_lib.KC_GEMM, prof), "profile_read")
+    lib.genie_profile_enable(0)
+    gemm_launches, gemm_ms, gemm_flops, gemm_bytes = list(prof)
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        lib.genie_profile_enable(0x1F)
+        lib.genie_profile_reset()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        names = ["gemm", "attn_spatial", "attn_temporal", "layernorm", "other"]
+        breakdown = {"step_ms": tb * 1e3}
+        for i, n in enumerate(names):
+            lib.genie_profile_read(i, prof)
+            breakdown[n] = {"launches": int(prof[0]), "ms": round(prof[1], 3),
+                            "tflops": round(prof[2] / max(prof[1], 1e-9) / 1e9, 2),
+                            "gbps": round(prof[3] / max(prof[1], 1e-9) / 1e6, 1)}
+        lib.genie_profile_enable(0)
+
+    if rank != 0:
+        return
+    m = dist_mod.means_from_sums(sums.tolist())
+    frames_per_step = (cfg.T - 1) * B * world
+    value = frames_per_step * args.steps / seconds
+    passes_per_step = (cfg.T - 1) * args.maskgit_steps * B  # per GPU
+    F = pass_flops(cfg)
+    peak = PEAK_TFLOPS[args.precision]
+    achieved = gemm_flops / max(gemm_ms, 1e-9) / 1e9  # TFLOP/s over all timed GEMM launches
+    out = {
+        "metric": "sampled frames/sec (whole node) + teacher-forced CE, GENIE_138M 16x256 tokens",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": value / PUBLISHED_FRAMES_PER_SEC[args.model],
+        "baseline_note": "BASELINE.md section 1: reference README 0.075 s/frame (GENIE_138M, 2 MaskGIT steps) on 1x RTX 4090, "
+                         "fp32, batch 16, unsynchronised timing; different hardware",
+        "dtype": DTYPE[args.precision], "data": "synthetic",
+        "config": {"workload": f"teacher-forced evaluate (predict_zframe_logits semantics): 15 timesteps x "
+                               f"{args.maskgit_steps} MaskGIT steps, temperature 0, {B} clips/GPU/step, "
+                               f"{'GENIE_138M-shape L=32 H=8 d=512 (shape inferred: config.json is hub-only)' if args.model == 'c138' else 'GENIE_35M magvit_n32_h8_d256'}",
+                   "clips_per_gpu": B, "global_clips": B * world, "maskgit_steps": args.maskgit_steps,
+                   "forward_passes_per_step_per_gpu": passes_per_step, "parallelism": f"dp{world}",
+                   "precision": args.precision, "weights": "synthetic PCG64 seed 0, 'conditioned' law"},
+        "ce": m["loss"], "sampled_token_acc": m["acc"],
+        "model_tflops_per_gpu": passes_per_step * F * args.steps / seconds / 1e12,
+        "model_frac_of_mfma_peak": passes_per_step * F * args.steps / seconds / 1e12 / peak,
+        "roofline": {
+            "kernel": "gemm_f32_nt_kernel (v_mfma_f32_32x32x2_f32)" if args.precision == "exact"
+                      else "gemm_bf16_nt_kernel (v_mfma_f32_32x32x16_bf16)",
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "launches": int(gemm_launches), "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
+            "flops_per_launch": gemm_flops / max(gemm_launches, 1),
+            "gemm_share_of_step_time": gemm_ms / 1e3 / seconds, "traffic": None},
+    }
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                out["roofline"]["traffic"] = json.load(f).get(args.precision)
+        except Exception:
+            pass
+    if breakdown:
+        out["breakdown"] = breakdown
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, all_clips, args.maskgit_steps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

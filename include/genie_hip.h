@@ -196,6 +196,19 @@ int genie_maskgit_generate(const genie_cfg* cfg, const genie_weights* w, int64_t
                            int64_t* samples_out, float* logits0_out, int layout, int32_t* status_flag,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- optional per-launch timing (bench.py's roofline leg) ------------------------------------------------
+ * When enabled, every launch of a kernel whose class bit is set in `class_mask` is bracketed by a pair of
+ * HIP events recorded on the launch stream.  genie_profile_read synchronises those events and returns, for
+ * one class, out[0..3] = {launches, total milliseconds, total algorithmic FLOPs, total algorithmic bytes}.
+ * Process-global, not thread-safe; at most GENIE_PROFILE_MAX_LAUNCHES launches are timed between resets
+ * (later ones run untimed and are not counted). */
+enum { GENIE_KC_GEMM = 0, GENIE_KC_ATTN_SPATIAL = 1, GENIE_KC_ATTN_TEMPORAL = 2, GENIE_KC_LAYERNORM = 3,
+       GENIE_KC_OTHER = 4, GENIE_KC_COUNT = 5 };
+#define GENIE_PROFILE_MAX_LAUNCHES 32768
+int genie_profile_enable(int class_mask); /* 0 disables */
+int genie_profile_reset(void);
+int genie_profile_read(int kernel_class, double* out4);
+
 /* LFQ.get_codebook_entry(...).flip(1) (lookup_free_quantize.py:181-194, visualize.py:115):
  * ids (n, hw) int64 -> z (n, bits, hw) float32 in {-1,+1}, channel c = bit c (LSB first). */
 int genie_bits_from_tokens(const int64_t* ids, float* z, int n, int hw, int bits, void* stream);
