@@ -121,8 +121,12 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
                                      c.attn_scale, 0, nw, nb, st);
         GENIE_TRY(rc);
     } else {
-        GENIE_TRY(launch_attn_generic(qkv, ao, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
-                                      c.head_dim, c.attn_scale, 1, nw, nb, st));
+        int rc = launch_attn_temporal_f32_mfma(qkv, ao, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nw, nb,
+                                               st);
+        if (rc == GENIE_E_UNSUPPORTED)
+            rc = launch_attn_generic(qkv, ao, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
+                                     c.head_dim, c.attn_scale, 1, nw, nb, st);
+        GENIE_TRY(rc);
     }
     GENIE_TRY(launch_gemm_f32(ao, d, 0, aw.proj_w, d, 0, c.proj_bias ? aw.proj_b : nullptr, x, d, 0, M, d, d, 1,
                               GEMM_ACCUM, 1.0f, st));
@@ -251,9 +255,13 @@ int genie_temporal_attention(const genie_cfg* cfg, const genie_attn_weights* aw,
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(aw && qkv && out && B >= 1, "temporal_attention: bad argument");
     const genie_cfg& c = *cfg;
+    const float* nw = c.qk_norm ? aw->norm_w : nullptr;
+    const float* nb = c.qk_norm ? aw->norm_b : nullptr;
+    int rc = launch_attn_temporal_f32_mfma(qkv, out, B, c.T, c.S, c.d_model, c.num_heads, c.head_dim, c.attn_scale, nw,
+                                           nb, as_stream(stream));
+    if (rc != GENIE_E_UNSUPPORTED) return rc;
     return launch_attn_generic(qkv, out, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, c.d_model, c.num_heads,
-                               c.head_dim, c.attn_scale, 1, c.qk_norm ? aw->norm_w : nullptr,
-                               c.qk_norm ? aw->norm_b : nullptr, as_stream(stream));
+                               c.head_dim, c.attn_scale, 1, nw, nb, as_stream(stream));
 }
 
 int genie_attention_core(const float* qkv, float* out, int n_seq, int N, int num_heads, int head_dim, float scale,

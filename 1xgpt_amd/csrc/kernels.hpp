@@ -31,6 +31,8 @@ int launch_attn_generic_bf16(const uint16_t* qkv, uint16_t* out, int N, long n_s
                              const float* nw, const float* nb, hipStream_t st);
 int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
                                  const float* nw, const float* nb, hipStream_t st);
+int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
+                                  const float* nw, const float* nb, hipStream_t st);
 int launch_transpose(const float* in, float* out, int batch, int rows, int cols, hipStream_t st);
 int launch_factored_ce(const genie_cfg& c, const float* logits, int layout, const int64_t* targets,
                        const int64_t* weight_ids, int B, int t0, int t1, double* sums, hipStream_t st);

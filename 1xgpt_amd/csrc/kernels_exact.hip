@@ -914,4 +914,108 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
     return GENIE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// a8  Temporal causal attention on the f32 matrix cores, T = 16 frames, one wavefront per (b, s, head),
+// operands straight from HBM into MFMA fragments -- no LDS, no "(B S) T C" transpose (st_transformer.py:77).
+//
+//   S^T = K Q^T : v_mfma_f32_16x16x4_f32, lane (r = lane&15, g = lane>>4) holds K[r][16g..16g+15] and
+//                 Q[r][16g..16g+15] (4 float4 each, 256 B contiguous per token across the 4 lane groups);
+//                 MFMA step s consumes element s of every lane, i.e. k in {s, 16+s, 32+s, 48+s}: the k-sum
+//                 is order-free so 16 steps cover Dh = 64.  Result: lane (i = r, g) holds scores of query i
+//                 against keys j = 4g + e -> causal mask + softmax = 4 in-lane values + 2 cross-group shuffles.
+//   O = P V     : same trick on the key axis: step e feeds P[i][4g+e] and V[4g+e][16*dt + r].
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float* __restrict__ qkv,
+                                                                     float* __restrict__ out, long n_bs, int S,
+                                                                     int d, int H, float scale,
+                                                                     const float* __restrict__ nw,
+                                                                     const float* __restrict__ nb) {
+    constexpr int T = 16, PER = DH / 4;  // floats per lane per row
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long bs = wave / H;
+    const int head = (int)(wave - bs * H);
+    if (bs >= n_bs) return;
+    const long b = bs / S, s = bs - b * S;
+    const long tok_stride = (long)S * 3 * d;                       // frame t -> t+1
+    const float* base = qkv + ((size_t)(b * T) * S + s) * 3 * d + head * DH;
+    const float* qp = base + (size_t)r * tok_stride + g * PER;     // row t = r
+    float q[PER], k[PER];
+#pragma unroll
+    for (int c = 0; c < PER / 4; ++c) {
+        float4 a = *reinterpret_cast<const float4*>(qp + 4 * c);
+        float4 bb = *reinterpret_cast<const float4*>(qp + d + 4 * c);
+        q[4 * c] = a.x; q[4 * c + 1] = a.y; q[4 * c + 2] = a.z; q[4 * c + 3] = a.w;
+        k[4 * c] = bb.x; k[4 * c + 1] = bb.y; k[4 * c + 2] = bb.z; k[4 * c + 3] = bb.w;
+    }
+    if (nw) {  // qk-norm, f32, one shared affine (attention.py:42-47); row spread over the 4 lane groups
+        float sq = 0.f, sk = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER; ++c) { sq += q[c]; sk += k[c]; }
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        sk += __shfl_xor(sk, 16); sk += __shfl_xor(sk, 32);
+        const float mq = sq / DH, mk = sk / DH;
+        float vq = 0.f, vk = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER; ++c) { float a = q[c] - mq, bb = k[c] - mk; vq += a * a; vk += bb * bb; }
+        vq += __shfl_xor(vq, 16); vq += __shfl_xor(vq, 32);
+        vk += __shfl_xor(vk, 16); vk += __shfl_xor(vk, 32);
+        const float rq = 1.0f / sqrtf(vq / DH + 1e-5f), rk = 1.0f / sqrtf(vk / DH + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < PER; ++c) {
+            const float w_ = nw[g * PER + c], b_ = nb[g * PER + c];
+            q[c] = (q[c] - mq) * rq * w_ + b_;
+            k[c] = (k[c] - mk) * rk * w_ + b_;
+        }
+    }
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T: row = key j = 4g + e, col = query i = r
+#pragma unroll
+    for (int c = 0; c < PER; ++c) st = __builtin_amdgcn_mfma_f32_16x16x4f32(k[c], q[c] * scale, st, 0, 0, 0);
+    // causal mask (attention.py:51-55: -finfo.max before softmax -> exact zeros) + softmax over j
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (4 * g + e > r) st[e] = -INFINITY;
+        mx = fmaxf(mx, st[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { st[e] = expf(st[e] - mx); sum += st[e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    // O = P V
+    const float* vp = base + 2 * d + (size_t)(4 * g) * tok_stride + r;
+    float* op = out + ((size_t)(b * T) * S + s) * d + head * DH + r;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[e] * inv, vp[(size_t)e * tok_stride + dt * 16], o, 0, 0, 0);
+        // C/D map of the 16x16 MFMA: col = lane&15 (feature), row = 4*(lane>>4) + e (query frame)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) op[(size_t)(4 * g + e) * S * d + dt * 16] = o[e];
+    }
+}
+
+// Temporal attention over T = 16 frames on a (B,T,S,3d) buffer; GENIE_E_UNSUPPORTED for other geometries.
+int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
+                                  const float* nw, const float* nb, hipStream_t st) {
+    if (T != 16 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
+    const long n_bs = (long)B * S, waves = n_bs * H;
+    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 16.0, st);
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb);
+    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb);
+    GENIE_LAUNCH_CHECK("attn_temporal_f32_mfma");
+    return GENIE_OK;
+}
+
 }  // namespace genie
