@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgenie_hip.so")
 
-PREC_EXACT, PREC_BF16 = 0, 1
+PREC_EXACT, PREC_BF16, PREC_F16X3 = 0, 1, 2
 LAYOUT_TOKEN_MAJOR, LAYOUT_BCTHW = 0, 1
 UNMASK_RANDOM, UNMASK_GREEDY = 0, 1
 KC_GEMM, KC_ATTN_SPATIAL, KC_ATTN_TEMPORAL, KC_LAYERNORM, KC_OTHER = range(5)
@@ -48,9 +48,12 @@ SIGNATURES = {
     "genie_check_config": (C.c_int, [C.POINTER(GenieCfg)]),
     "genie_workspace_bytes": (C.c_size_t, [C.POINTER(GenieCfg), C.c_int]),
     "genie_pack_bf16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_pack_split_f16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_embed": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, c_ptr, c_ptr]),
     "genie_layer_norm": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
     "genie_linear": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "genie_linear_lowp": (C.c_int, [C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    c_ptr]),
     "genie_spatial_attention": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, c_ptr]),
     "genie_temporal_attention": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, c_ptr]),
     "genie_attention_core": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_ptr,

@@ -39,18 +39,7 @@ ProfScope::~ProfScope() {
     if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], st);
 }
 
-// Workspace carving.  All offsets 256-byte aligned.
-struct Workspace {
-    float* x;        // (M, d)      residual stream, f32 in both precisions
-    void* xn;        // (M, d)      LayerNorm output, then attention output (f32 | bf16)
-    void* big;       // (M, max(3d, hidden))  qkv, later the MLP hidden (f32 | bf16)
-    float* logits;   // (M, V)      token-major logits scratch
-    int64_t* samples;  // (B, S)
-    float* conf;       // (B, S)
-    uint8_t* unmasked; // (B, S)
-    size_t total;
-};
-
+// Workspace carving (struct Workspace: kernels.hpp).  All offsets 256-byte aligned.
 static Workspace carve(const genie_cfg& c, int B, void* base) {
     Workspace w;
     const size_t M = (size_t)B * c.T * c.S;
@@ -70,6 +59,7 @@ static Workspace carve(const genie_cfg& c, int B, void* base) {
     w.samples = (int64_t*)take((size_t)B * c.S * 8);
     w.conf = (float*)take((size_t)B * c.S * 4);
     w.unmasked = (uint8_t*)take((size_t)B * c.S);
+    w.aux = take(M * c.d_model * 4);
     w.total = off;
     return w;
 }
@@ -90,8 +80,13 @@ static int check_cfg(const genie_cfg* c) {
                       c->head_dim);
     GENIE_CHECK_SHAPE(c->num_factored >= 1 && c->num_factored <= 4, "num_factored %d unsupported", c->num_factored);
     GENIE_CHECK_SHAPE(c->factored_vocab >= 1, "factored_vocab must be >= 1");
-    GENIE_CHECK_SHAPE(c->precision == GENIE_PREC_EXACT || c->precision == GENIE_PREC_BF16, "unknown precision %d",
-                      c->precision);
+    GENIE_CHECK_SHAPE(c->precision == GENIE_PREC_EXACT || c->precision == GENIE_PREC_BF16 ||
+                          c->precision == GENIE_PREC_F16X3,
+                      "unknown precision %d", c->precision);
+    if (c->precision == GENIE_PREC_BF16)
+        GENIE_CHECK_SHAPE(c->d_model % 64 == 0 && c->hidden % 64 == 0, "bf16 precision needs d_model, hidden %% 64 == 0");
+    if (c->precision == GENIE_PREC_F16X3)
+        GENIE_CHECK_SHAPE(c->d_model % 32 == 0 && c->hidden % 32 == 0, "f16x3 precision needs d_model, hidden %% 32 == 0");
     return GENIE_OK;
 }
 
@@ -160,23 +155,35 @@ int st_block_exact(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
 }
 
 int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st);
-int readout_bf16(const genie_cfg& c, const genie_weights& wt, const float* x, int B, int t0, int t1, int layout,
-                 float* logits, hipStream_t st);
+int prepare_bf16(const genie_cfg& c, const float* x, Workspace& w, int B, hipStream_t st);
+int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st);
+int prepare_f16x3(const genie_cfg& c, const float* x, Workspace& w, int B, hipStream_t st);
+int readout_f16x3(const genie_cfg& c, const genie_weights& wt, const float* x, Workspace& w, int B, int t0, int t1,
+                  int layout, float* logits, hipStream_t st);
+int launch_pack_split(const float* src, uint16_t* dst, size_t n, hipStream_t st);
+int launch_linear_lowp(int precision, const uint16_t* x16, const uint16_t* W16, const float* b, float* y, int M, int N,
+                       int K, int gelu, int accumulate, hipStream_t st);
+int readout_bf16(const genie_cfg& c, const genie_weights& wt, const float* x, Workspace& w, int B, int t0, int t1,
+                 int layout, float* logits, hipStream_t st);
 
 static int st_block(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st) {
     if (c.precision == GENIE_PREC_BF16) return st_block_bf16(c, lw, x, w, B, st);
+    if (c.precision == GENIE_PREC_F16X3) return st_block_f16x3(c, lw, x, w, B, st);
     return st_block_exact(c, lw, x, w, B, st);
 }
 
 static int decoder(const genie_cfg& c, const genie_weights& wt, float* x, Workspace& w, int B, hipStream_t st) {
+    if (c.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c, x, w, B, st));
+    if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, x, w, B, st));
     for (int i = 0; i < c.num_layers; ++i) GENIE_TRY(st_block(c, wt.layers_host[i], x, w, B, st));
     return GENIE_OK;
 }
 
 // out_x_proj on frames [t0,t1): token-major (B,nt,S,V) or BCTHW (B,V,nt,S) via the operand-swapped GEMM
-static int readout(const genie_cfg& c, const genie_weights& wt, const float* x, int B, int t0, int t1, int layout,
-                   float* logits, hipStream_t st) {
-    if (c.precision == GENIE_PREC_BF16) return readout_bf16(c, wt, x, B, t0, t1, layout, logits, st);
+static int readout(const genie_cfg& c, const genie_weights& wt, const float* x, Workspace& w, int B, int t0, int t1,
+                   int layout, float* logits, hipStream_t st) {
+    if (c.precision == GENIE_PREC_BF16) return readout_bf16(c, wt, x, w, B, t0, t1, layout, logits, st);
+    if (c.precision == GENIE_PREC_F16X3) return readout_f16x3(c, wt, x, w, B, t0, t1, layout, logits, st);
     const int d = c.d_model, nt = t1 - t0, V = c.factored_vocab * c.num_factored;
     const long rows = (long)nt * c.S;
     const float* xa = x + (size_t)t0 * c.S * d;
@@ -213,6 +220,11 @@ size_t genie_workspace_bytes(const genie_cfg* cfg, int B) {
 int genie_pack_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
     GENIE_CHECK_ARG(src && dst, "pack_bf16: NULL pointer");
     return launch_pack_bf16(src, dst, n, as_stream(stream));
+}
+
+int genie_pack_split_f16(const float* src, uint16_t* dst, size_t n, void* stream) {
+    GENIE_CHECK_ARG(src && dst, "pack_split_f16: NULL pointer");
+    return launch_pack_split(src, dst, n, as_stream(stream));
 }
 
 int genie_embed(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, float* x, void* stream) {
@@ -264,6 +276,12 @@ int genie_temporal_attention(const genie_cfg* cfg, const genie_attn_weights* aw,
                                c.head_dim, c.attn_scale, 1, nw, nb, as_stream(stream));
 }
 
+int genie_linear_lowp(int precision, const uint16_t* x16, const uint16_t* W16, const float* b, float* y, int M, int N,
+                      int K, int gelu, int accumulate, void* stream) {
+    GENIE_CHECK_ARG(x16 && W16 && y && M >= 0 && N >= 1 && K >= 1, "linear_lowp: bad argument");
+    return launch_linear_lowp(precision, x16, W16, b, y, M, N, K, gelu, accumulate, as_stream(stream));
+}
+
 int genie_attention_core(const float* qkv, float* out, int n_seq, int N, int num_heads, int head_dim, float scale,
                          int causal, const float* norm_w, const float* norm_b, void* stream) {
     GENIE_CHECK_ARG(qkv && out && n_seq >= 0 && N >= 1 && num_heads >= 1, "attention_core: bad argument");
@@ -284,6 +302,8 @@ int genie_st_block_forward(const genie_cfg* cfg, const genie_layer_weights* lw_h
     GENIE_CHECK_ARG(lw_host && x, "st_block_forward: NULL pointer");
     GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
     Workspace w = carve(*cfg, B, workspace);
+    if (cfg->precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(*cfg, x, w, B, as_stream(stream)));
+    if (cfg->precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(*cfg, x, w, B, as_stream(stream)));
     return st_block(*cfg, *lw_host, x, w, B, as_stream(stream));
 }
 
@@ -298,12 +318,13 @@ int genie_decoder_forward(const genie_cfg* cfg, const genie_weights* wt, float* 
 
 int genie_readout_logits(const genie_cfg* cfg, const genie_weights* wt, const float* x, int B, int t0, int t1,
                          int layout, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(wt && x && logits && B >= 1, "readout_logits: bad argument");
     GENIE_CHECK_ARG(0 <= t0 && t0 <= t1 && t1 <= cfg->T, "readout_logits: bad frame range [%d,%d)", t0, t1);
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    Workspace w = carve(*cfg, B, workspace);
     if (t0 == t1) return GENIE_OK;
-    return readout(*cfg, *wt, x, B, t0, t1, layout, logits, as_stream(stream));
+    return readout(*cfg, *wt, x, w, B, t0, t1, layout, logits, as_stream(stream));
 }
 
 int genie_compute_logits(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int t0, int t1,
@@ -317,7 +338,7 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* wt, const in
     GENIE_TRY(launch_embed(*cfg, *wt, ids, B, w.x, st));
     GENIE_TRY(decoder(*cfg, *wt, w.x, w, B, st));
     if (t0 == t1) return GENIE_OK;
-    return readout(*cfg, *wt, w.x, B, t0, t1, layout, logits, st);
+    return readout(*cfg, *wt, w.x, w, B, t0, t1, layout, logits, st);
 }
 
 int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, const int64_t* targets,
@@ -338,7 +359,7 @@ int genie_readout_ce(const genie_cfg* cfg, const genie_weights* wt, const float*
     if (t0 == t1) return GENIE_OK;
     Workspace w = carve(*cfg, B, workspace);
     hipStream_t st = as_stream(stream);
-    GENIE_TRY(readout(*cfg, *wt, x, B, t0, t1, GENIE_LAYOUT_TOKEN_MAJOR, w.logits, st));
+    GENIE_TRY(readout(*cfg, *wt, x, w, B, t0, t1, GENIE_LAYOUT_TOKEN_MAJOR, w.logits, st));
     return launch_factored_ce(*cfg, w.logits, GENIE_LAYOUT_TOKEN_MAJOR, targets, weight_ids, B, t0, t1, sums_out, st);
 }
 
@@ -389,7 +410,7 @@ int genie_maskgit_generate(const genie_cfg* cfg, const genie_weights* wt, int64_
     for (int step = 0; step < steps; ++step) {
         GENIE_TRY(launch_embed(c, *wt, prompt, B, w.x, st));
         GENIE_TRY(decoder(c, *wt, w.x, w, B, st));
-        GENIE_TRY(readout(c, *wt, w.x, B, out_t, out_t + 1, GENIE_LAYOUT_TOKEN_MAJOR, w.logits, st));
+        GENIE_TRY(readout(c, *wt, w.x, w, B, out_t, out_t + 1, GENIE_LAYOUT_TOKEN_MAJOR, w.logits, st));
         if (step == 0 && logits0_out) {  // orig_logits_CHW: step-0 logits are what is returned (:165,226)
             if (layout == GENIE_LAYOUT_TOKEN_MAJOR) {
                 if (hipMemcpyAsync(logits0_out, w.logits, BS * V * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {

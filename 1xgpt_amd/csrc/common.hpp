@@ -72,6 +72,17 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// f32 -> (hi, lo) f16 pair with a ~ hi + lo/2048 (GENIE_PREC_F16X3).  hi is flushed to zero below the f16 normal
+// range so that nothing depends on how the matrix core treats f16 subnormals.
+__device__ __forceinline__ void split_f16(float a, uint16_t& hi, uint16_t& lo) {
+    _Float16 h = (_Float16)a;
+    float hf = (float)h;
+    if (fabsf(hf) < 6.103515625e-05f) { h = (_Float16)0.0f; hf = 0.0f; }
+    _Float16 l = (_Float16)((a - hf) * 2048.0f);
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, l);
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

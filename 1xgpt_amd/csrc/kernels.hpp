@@ -6,6 +6,20 @@ namespace genie {
 
 enum { GEMM_GELU = 1, GEMM_ACCUM = 2, GEMM_BIAS_ALONG_M = 4 };
 
+// Workspace carving shared by api.hip and the precision-specific layer drivers (see carve() in api.hip).
+struct Workspace {
+    float* x;          // (M, d)   residual stream, f32 in every precision; offset 0 of the workspace
+    void* xn;          // (M, d) x 4 bytes: exact = LayerNorm / attention output (f32);
+                       //                   bf16  = [bf16 shadow of x | bf16 LayerNorm / attention output]
+    void* big;         // (M, max(3d, hidden)) x 4 bytes: qkv, later the MLP hidden
+    float* logits;     // (M, V)   token-major logits scratch
+    int64_t* samples;  // (B, S)
+    float* conf;       // (B, S)
+    uint8_t* unmasked; // (B, S)
+    void* aux;         // (M, d) x 4 bytes: f16x3 = split planes of the LayerNorm / attention output
+    size_t total;
+};
+
 // Brackets one launch with HIP events when profiling of `cls` is enabled (see genie_profile_* in the ABI).
 struct ProfScope {
     int slot;
@@ -29,10 +43,17 @@ int launch_attn_generic(const float* qkv, float* out, int N, long n_seq, int inn
 int launch_attn_generic_bf16(const uint16_t* qkv, uint16_t* out, int N, long n_seq, int inner, long outer_stride,
                              long inner_stride, long pos_stride, int d, int H, int Dh, float scale, int causal,
                              const float* nw, const float* nb, hipStream_t st);
+// out16 != NULL: write the result 16-bit instead of f32 `out`: plane != 0 -> f16 split planes (hi at out16, lo at
+// out16 + plane); plane == 0 -> bf16
 int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
-                                 const float* nw, const float* nb, hipStream_t st);
+                                 const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
+                                 size_t plane = 0);
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
-                                  const float* nw, const float* nb, hipStream_t st);
+                                  const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
+                                  size_t plane = 0);
+int launch_layer_norm_split(const float* x, const float* g, const float* b, uint16_t* y, size_t plane, long rows, int C,
+                            float eps, hipStream_t st);
+int launch_split_f16(const float* src, uint16_t* dst, size_t plane, size_t n, hipStream_t st);
 int launch_transpose(const float* in, float* out, int batch, int rows, int cols, hipStream_t st);
 int launch_factored_ce(const genie_cfg& c, const float* logits, int layout, const int64_t* targets,
                        const int64_t* weight_ids, int B, int t0, int t1, double* sums, hipStream_t st);

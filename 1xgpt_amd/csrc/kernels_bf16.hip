@@ -1,15 +1,401 @@
-// bf16-MFMA ("fast") precision path -- placeholder until the kernels land.
+// 16-bit matrix-core path of the GENIE forward for gfx950.
+//
+// gemm16_nt_kernel<NPL, BK>:  C[M,N] (+)= epilogue( alpha * A[M,K] . W[N,K]^T + bias ) on v_mfma_f32_32x32x16
+//   NPL = 1  operands are bf16 (one product)                     -> GENIE_PREC_BF16, the throughput mode
+//   NPL = 2  operands are f16 split pairs  a = hi + lo * 2^-11   -> 3 products hi.hi + (hi.lo + lo.hi) 2^-11,
+//            22-bit effective mantissa: f32-class results at 1/3 of the f16 MFMA rate (5x the f32 MFMA peak)
+// 128x128 block tile, 4 waves (2x2), wave tile 64x64 = 2x2 MFMA tiles, K-tile BK, LDS double-buffered and
+// filled by global_load_lds (16 B per lane, HBM -> LDS without a register round trip).  The LDS image of
+// a tile is lane-linear (that is what global_load_lds writes), so bank conflicts of the 16-byte fragment
+// reads are removed by an XOR swizzle applied on the SOURCE address (which 16-byte slot of its row a lane
+// fetches) and mirrored on the fragment read:  phys_slot = slot ^ ((row / rows_per_256B) % slots_per_row).
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace genie {
-struct Workspace;
-int st_block_bf16(const genie_cfg&, const genie_layer_weights&, float*, Workspace&, int, hipStream_t) {
-    set_error("GENIE_PREC_BF16 is not built yet");
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+enum { G16_GELU = 1, G16_ACCUM = 2, G16_OUT16 = 4, G16_OUTF32 = 8 };
+
+constexpr float SPLIT_INV = 1.0f / 2048.0f;
+
+template <int NPL>
+__device__ __forceinline__ void store16(uint16_t* base, size_t plane_stride, size_t idx, float v) {
+    if constexpr (NPL == 1) {
+        base[idx] = f32_to_bf16(v);
+    } else {
+        uint16_t hi, lo;
+        split_f16(v, hi, lo);
+        base[idx] = hi;
+        base[plane_stride + idx] = lo;
+    }
+}
+
+template <int NPL, int BK>
+__global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
+                                                        const uint16_t* __restrict__ W, long ldw, long planeW,
+                                                        const float* __restrict__ bias, float* __restrict__ Cf,
+                                                        uint16_t* __restrict__ C16, long plane16, long ldc, int M,
+                                                        int N, int K, int flags, float alpha, long strideA,
+                                                        long strideC) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int ROWB = BK * 2;              // bytes per tile row
+    constexpr int SPR = ROWB / 16;            // 16-byte slots per row
+    constexpr int RPB = 256 / ROWB;           // rows per 256-byte LDS bank row
+    constexpr int TILE_B = BM * ROWB;         // bytes of one operand plane tile
+    constexpr int CHUNK_ROWS = 1024 / ROWB;   // rows moved by one wave-wide global_load_lds
+    constexpr int NCHUNK = BM / CHUNK_ROWS;   // chunks per plane tile (split over the 4 waves)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: [buf][operand A/W][plane][TILE_B]
+    auto tile_ptr = [&](int buf, int op, int pl) { return smem + ((buf * 2 + op) * NPL + pl) * TILE_B; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tiles = (N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
+    A += (size_t)blockIdx.y * strideA;
+    if (Cf) Cf += (size_t)blockIdx.y * strideC;
+    if (C16) C16 += (size_t)blockIdx.y * strideC;
+
+    // ---- staging addresses: wave w moves chunks w*NCHUNK/4 .. of every plane tile
+    constexpr int CPW = NCHUNK / 4;  // chunks per wave per plane tile
+    const int c_row = lane / SPR, c_phys = lane % SPR;
+    const uint16_t* gsrcA[CPW];
+    const uint16_t* gsrcW[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int row_local = (wid * CPW + c) * CHUNK_ROWS + c_row;
+        const int slot = c_phys ^ ((row_local / RPB) % SPR);
+        int ra = m0 + row_local; ra = ra < M ? ra : M - 1;   // clamp: rows past the edge are never stored
+        int rw = n0 + row_local; rw = rw < N ? rw : N - 1;
+        gsrcA[c] = A + (size_t)ra * lda + slot * 8;
+        gsrcW[c] = W + (size_t)rw * ldw + slot * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int off = (wid * CPW + c) * 1024;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(gsrcA[c] + (size_t)pl * planeA + k0),
+                    (__attribute__((address_space(3))) void*)(tile_ptr(buf, 0, pl) + off), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(gsrcW[c] + (size_t)pl * planeW + k0),
+                    (__attribute__((address_space(3))) void*)(tile_ptr(buf, 1, pl) + off), 16, 0, 0);
+            }
+    };
+
+    f32x16 acc[2][2], corr[NPL == 2 ? 2 : 1][NPL == 2 ? 2 : 1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if constexpr (NPL == 2) corr[i][j][e] = 0.f;
+            }
+
+    // fragment read offsets (bytes) within a plane tile for k-step kk: lane (r,h) reads slot 2*kk + h of its row
+    int fragA[2], fragB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fragA[i] = (wm * 64 + i * 32 + r);
+        fragB[i] = (wn * 64 + i * 32 + r);
+    }
+    auto frag_off = [&](int row_local, int kk) {
+        const int slot = 2 * kk + h;
+        return row_local * ROWB + ((slot ^ ((row_local / RPB) % SPR)) << 4);
+    };
+
+    const int nk = K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if constexpr (NPL == 1) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *reinterpret_cast<const bf16x8*>(tile_ptr(buf, 0, 0) + frag_off(fragA[i], kk));
+                    b[i] = *reinterpret_cast<const bf16x8*>(tile_ptr(buf, 1, 0) + frag_off(fragB[i], kk));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(tile_ptr(buf, 0, 0) + frag_off(fragA[i], kk));
+                    al[i] = *reinterpret_cast<const f16x8*>(tile_ptr(buf, 0, 1) + frag_off(fragA[i], kk));
+                    bh[i] = *reinterpret_cast<const f16x8*>(tile_ptr(buf, 1, 0) + frag_off(fragB[i], kk));
+                    bl[i] = *reinterpret_cast<const f16x8*>(tile_ptr(buf, 1, 1) + frag_off(fragB[i], kk));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], corr[i][j], 0, 0, 0);
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], corr[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();  // drains this wave's global_load_lds (vmcnt) and orders the buffer swap
+    }
+
+    const bool do_gelu = flags & G16_GELU, do_acc = flags & G16_ACCUM;
+    const bool out16 = flags & G16_OUT16, outf = flags & G16_OUTF32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+            if (col >= N) continue;
+            const float bcol = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[i][j][e];
+                if constexpr (NPL == 2) v += corr[i][j][e] * SPLIT_INV;
+                v = v * alpha + bcol;
+                if (do_gelu) v = gelu_erf(v);
+                const size_t idx = (size_t)row * ldc + col;
+                if (do_acc) v += Cf[idx];
+                if (outf) Cf[idx] = v;
+                if (out16) store16<NPL>(C16, (size_t)plane16, idx, v);
+            }
+        }
+}
+
+// A, W: 16-bit operands (NPL planes each, plane strides in elements); Cf f32 (ACCUM / OUTF32), C16 16-bit out.
+template <int NPL>
+static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
+                         const float* bias, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,
+                         int flags, float alpha, hipStream_t st, int batch = 1, long strideA = 0, long strideC = 0) {
+    constexpr int BK = NPL == 1 ? 64 : 32;
+    GENIE_CHECK_SHAPE(K % BK == 0 && K > 0, "gemm16: K=%d must be a positive multiple of %d", K, BK);
+    GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
+    if (M <= 0 || N <= 0) return GENIE_OK;
+    const int mt = (M + 127) / 128, nt = (N + 127) / 128;
+    const size_t lds = (size_t)2 * 2 * NPL * 128 * BK * 2;
+    const double mn = (double)M * N * batch;
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
+                   2.0 * NPL * ((double)M * K * batch + (double)N * K) +
+                       mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) + (flags & G16_OUT16 ? 2 * NPL : 0)),
+                   st);
+    (void)hipFuncSetAttribute((const void*)gemm16_nt_kernel<NPL, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    gemm16_nt_kernel<NPL, BK><<<dim3(mt * nt, batch), 256, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,
+                                                                      plane16, ldc, M, N, K, flags, alpha, strideA,
+                                                                      strideC);
+    GENIE_LAUNCH_CHECK("gemm16");
+    return GENIE_OK;
+}
+
+// ---- elementwise helpers -----------------------------------------------------------------------
+__global__ void cast16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f32_to_bf16(src[i]);
+}
+
+// bf16 precision contract (mirrored by oracle.genie_oracle.BF16_MFMA):
+//   * every nn.Linear operand is bf16 (weights packed once; activations rounded by their producer)
+//   * accumulation, bias, GELU, LayerNorm and the residual stream are f32
+//   * qkv leaves its GEMM as f32 and the attention core runs on the f32-MFMA kernels of the exact path (its
+//     output is rounded to bf16 for the out-projection) -- attention is ~6 % of the FLOPs.
+int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st) {
+    const int d = c.d_model, M = B * c.T * c.S;
+    uint16_t* x16 = (uint16_t*)w.xn;              // bf16 shadow of the residual stream
+    uint16_t* xn16 = x16 + (size_t)M * d;         // LayerNorm output, then attention output
+    float* qkv = (float*)w.big;                   // f32 qkv
+    uint16_t* big16 = (uint16_t*)w.big;           // later: bf16 MLP hidden
+    GENIE_CHECK_ARG(lw.spatial.qkv_w16 && lw.spatial.proj_w16 && lw.temporal.qkv_w16 && lw.temporal.proj_w16 &&
+                        lw.fc1_w16 && lw.fc2_w16,
+                    "bf16 precision needs packed bf16 weights (genie_pack_bf16)");
+    const float* nws = c.qk_norm ? lw.spatial.norm_w : nullptr;
+    const float* nbs = c.qk_norm ? lw.spatial.norm_b : nullptr;
+    const float* nwt = c.qk_norm ? lw.temporal.norm_w : nullptr;
+    const float* nbt = c.qk_norm ? lw.temporal.norm_b : nullptr;
+    // spatial
+    const uint16_t* u = x16;
+    if (!c.qk_norm) {
+        GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
+        u = xn16;
+    }
+    GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.spatial.qkv_w16, d, 0, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv, nullptr,
+                               0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+    int rc = launch_attn_spatial_f32_mfma(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
+                                          nbs, st, xn16, 0);
+    if (rc == GENIE_E_UNSUPPORTED) {
+        GENIE_TRY(launch_attn_generic(qkv, w.logits, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
+                                      c.attn_scale, 0, nws, nbs, st));
+        rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
+    }
+    GENIE_TRY(rc);
+    GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.spatial.proj_w16, d, 0, c.proj_bias ? lw.spatial.proj_b : nullptr, x, x16,
+                               0, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+    // temporal (no pre-norm): operand = bf16 shadow of x
+    GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, qkv,
+                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+    rc = launch_attn_temporal_f32_mfma(qkv, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt, st,
+                                       xn16, 0);
+    if (rc == GENIE_E_UNSUPPORTED) {
+        GENIE_TRY(launch_attn_generic(qkv, w.logits, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
+                                      c.head_dim, c.attn_scale, 1, nwt, nbt, st));
+        rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
+    }
+    GENIE_TRY(rc);
+    GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.temporal.proj_w16, d, 0, c.proj_bias ? lw.temporal.proj_b : nullptr, x,
+                               x16, 0, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+    // MLP
+    u = x16;
+    if (!c.qk_norm) {
+        GENIE_TRY(launch_layer_norm_bf16(x, lw.norm2_w, lw.norm2_b, xn16, M, d, 1e-5f, st));
+        u = xn16;
+    }
+    GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.fc1_w16, d, 0, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, big16, 0, c.hidden,
+                               M, c.hidden, d, G16_GELU | G16_OUT16, 1.0f, st));
+    GENIE_TRY(launch_gemm16<1>(big16, c.hidden, 0, lw.fc2_w16, c.hidden, 0, c.mlp_bias ? lw.fc2_b : nullptr, x, x16, 0,
+                               d, M, d, c.hidden, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+    return GENIE_OK;
+}
+
+// The bf16 shadow of x must exist before the first layer when the block has no pre-norm (qk_norm configs).
+int prepare_bf16(const genie_cfg& c, const float* x, Workspace& w, int B, hipStream_t st) {
+    const size_t n = (size_t)B * c.T * c.S * c.d_model;
+    cast16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(x, (uint16_t*)w.xn, n);
+    GENIE_LAUNCH_CHECK("cast16");
+    return GENIE_OK;
+}
+
+// out_x_proj on frames [t0,t1) from the bf16 shadow; logits f32.  BCTHW goes through the token-major scratch.
+int readout_bf16(const genie_cfg& c, const genie_weights& wt, const float* x, Workspace& w, int B, int t0, int t1,
+                 int layout, float* logits, hipStream_t st) {
+    GENIE_CHECK_ARG(wt.out_w16, "bf16 precision needs packed bf16 weights (genie_pack_bf16)");
+    const int d = c.d_model, nt = t1 - t0, V = c.factored_vocab * c.num_factored;
+    const long rows = (long)nt * c.S;
+    GENIE_CHECK_ARG((const void*)x == (const void*)w.x, "bf16 readout reads the workspace's own hidden state");
+    const uint16_t* x16 = (const uint16_t*)w.xn;
+    float* dst = (layout == GENIE_LAYOUT_TOKEN_MAJOR) ? logits : w.logits;
+    GENIE_TRY(launch_gemm16<1>(x16 + (size_t)t0 * c.S * d, d, 0, wt.out_w16, d, 0, wt.out_b, dst, nullptr, 0, V,
+                               (int)rows, V, d, G16_OUTF32, c.readout_mult, st, B, (long)c.T * c.S * d, rows * V));
+    if (layout != GENIE_LAYOUT_TOKEN_MAJOR) GENIE_TRY(launch_transpose(w.logits, logits, B, (int)rows, V, st));
+    return GENIE_OK;
+}
+
+// ---- GENIE_PREC_F16X3 ---------------------------------------------------------------------------
+// Every Linear runs on the f16 matrix cores with split operands (3 MFMAs per K-step); everything else is
+// the exact path: f32 qkv -> f32-MFMA attention kernels -> outputs re-split for the next Linear.
+// Buffers: w.xn  = split planes of the residual stream x (hi | lo), M*d each
+//          w.aux = split planes of the LayerNorm output, then of the attention output
+//          w.big = qkv as f32 (M*3d), later the split planes of the MLP hidden (M*hidden each)
+int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, hipStream_t st) {
+    const int d = c.d_model, M = B * c.T * c.S, hid = c.hidden;
+    const size_t pd = (size_t)M * d, ph = (size_t)M * hid;
+    uint16_t* xs = (uint16_t*)w.xn;
+    uint16_t* as = (uint16_t*)w.aux;
+    float* qkv = (float*)w.big;
+    uint16_t* hs = (uint16_t*)w.big;
+    GENIE_CHECK_ARG(lw.spatial.qkv_w16 && lw.spatial.proj_w16 && lw.temporal.qkv_w16 && lw.temporal.proj_w16 &&
+                        lw.fc1_w16 && lw.fc2_w16,
+                    "f16x3 precision needs split-f16 weights (genie_pack_split_f16)");
+    const size_t pw_qkv = (size_t)3 * d * d, pw_proj = (size_t)d * d, pw_fc = (size_t)hid * d;
+    const float* nws = c.qk_norm ? lw.spatial.norm_w : nullptr;
+    const float* nbs = c.qk_norm ? lw.spatial.norm_b : nullptr;
+    const float* nwt = c.qk_norm ? lw.temporal.norm_w : nullptr;
+    const float* nbt = c.qk_norm ? lw.temporal.norm_b : nullptr;
+    // ---- spatial
+    const uint16_t* u = xs;
+    if (!c.qk_norm) {
+        GENIE_TRY(launch_layer_norm_split(x, lw.norm1_w, lw.norm1_b, as, pd, M, d, 1e-5f, st));
+        u = as;
+    }
+    GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.spatial.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv,
+                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+    int rc = launch_attn_spatial_f32_mfma(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
+                                          nbs, st, as, pd);
+    if (rc == GENIE_E_UNSUPPORTED) {  // generic kernel writes f32 into x-sized scratch (logits region), then split
+        float* tmp = w.logits;
+        GENIE_TRY(launch_attn_generic(qkv, tmp, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
+                                      c.attn_scale, 0, nws, nbs, st));
+        rc = launch_split_f16(tmp, as, pd, pd, st);
+    }
+    GENIE_TRY(rc);
+    GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.spatial.proj_w16, d, pw_proj, c.proj_bias ? lw.spatial.proj_b : nullptr, x,
+                               xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+    // ---- temporal
+    GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, qkv,
+                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+    rc = launch_attn_temporal_f32_mfma(qkv, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt, st,
+                                       as, pd);
+    if (rc == GENIE_E_UNSUPPORTED) {
+        float* tmp = w.logits;
+        GENIE_TRY(launch_attn_generic(qkv, tmp, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
+                                      c.head_dim, c.attn_scale, 1, nwt, nbt, st));
+        rc = launch_split_f16(tmp, as, pd, pd, st);
+    }
+    GENIE_TRY(rc);
+    GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.temporal.proj_w16, d, pw_proj, c.proj_bias ? lw.temporal.proj_b : nullptr,
+                               x, xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+    // ---- MLP
+    u = xs;
+    if (!c.qk_norm) {
+        GENIE_TRY(launch_layer_norm_split(x, lw.norm2_w, lw.norm2_b, as, pd, M, d, 1e-5f, st));
+        u = as;
+    }
+    GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.fc1_w16, d, pw_fc, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, hs, ph, hid, M,
+                               hid, d, G16_GELU | G16_OUT16, 1.0f, st));
+    GENIE_TRY(launch_gemm16<2>(hs, hid, ph, lw.fc2_w16, hid, pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, xs, pd, d, M, d,
+                               hid, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+    return GENIE_OK;
+}
+
+int prepare_f16x3(const genie_cfg& c, const float* x, Workspace& w, int B, hipStream_t st) {
+    const size_t n = (size_t)B * c.T * c.S * c.d_model;
+    return launch_split_f16(x, (uint16_t*)w.xn, n, n, st);
+}
+
+int readout_f16x3(const genie_cfg& c, const genie_weights& wt, const float* x, Workspace& w, int B, int t0, int t1,
+                  int layout, float* logits, hipStream_t st) {
+    GENIE_CHECK_ARG(wt.out_w16, "f16x3 precision needs split-f16 weights (genie_pack_split_f16)");
+    const int d = c.d_model, nt = t1 - t0, V = c.factored_vocab * c.num_factored;
+    const long rows = (long)nt * c.S;
+    GENIE_CHECK_ARG((const void*)x == (const void*)w.x, "f16x3 readout reads the workspace's own hidden state");
+    const size_t pd = (size_t)B * c.T * c.S * d;
+    const uint16_t* xs = (const uint16_t*)w.xn;
+    float* dst = (layout == GENIE_LAYOUT_TOKEN_MAJOR) ? logits : w.logits;
+    GENIE_TRY(launch_gemm16<2>(xs + (size_t)t0 * c.S * d, d, pd, wt.out_w16, d, (size_t)V * d, wt.out_b, dst, nullptr, 0,
+                               V, (int)rows, V, d, G16_OUTF32, c.readout_mult, st, B, (long)c.T * c.S * d, rows * V));
+    if (layout != GENIE_LAYOUT_TOKEN_MAJOR) GENIE_TRY(launch_transpose(w.logits, logits, B, (int)rows, V, st));
+    return GENIE_OK;
+}
+
+int launch_pack_split(const float* src, uint16_t* dst, size_t n, hipStream_t st) { return launch_split_f16(src, dst, n, n, st); }
+
+int launch_linear_lowp(int precision, const uint16_t* x16, const uint16_t* W16, const float* b, float* y, int M, int N,
+                       int K, int gelu, int accumulate, hipStream_t st) {
+    const int flags = G16_OUTF32 | (gelu ? G16_GELU : 0) | (accumulate ? G16_ACCUM : 0);
+    if (precision == GENIE_PREC_BF16)
+        return launch_gemm16<1>(x16, K, 0, W16, K, 0, b, y, nullptr, 0, N, M, N, K, flags, 1.0f, st);
+    if (precision == GENIE_PREC_F16X3)
+        return launch_gemm16<2>(x16, K, (size_t)M * K, W16, K, (size_t)N * K, b, y, nullptr, 0, N, M, N, K, flags, 1.0f,
+                                st);
+    set_error("linear_lowp: precision %d has no 16-bit GEMM", precision);
     return GENIE_E_UNSUPPORTED;
 }
-int readout_bf16(const genie_cfg&, const genie_weights&, const float*, int, int, int, int, float*, hipStream_t) {
-    set_error("GENIE_PREC_BF16 is not built yet");
-    return GENIE_E_UNSUPPORTED;
-}
+
 }  // namespace genie

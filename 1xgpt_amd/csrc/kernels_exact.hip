@@ -55,10 +55,10 @@ int launch_embed(const genie_cfg& c, const genie_weights& w, const int64_t* ids,
 // a4  nn.LayerNorm(C, eps): one wavefront per row, two-pass (mean, then centred variance), f32.
 // OutT = float (exact) or uint16_t bf16 (operand of a bf16 GEMM).
 // ------------------------------------------------------------------------------------------------
-template <typename OutT>
+template <typename OutT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ b, OutT* __restrict__ y, long rows,
-                                                         int C, float eps) {
+                                                         int C, float eps, size_t plane = 0) {
     const int lane = threadIdx.x & 63;
     long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     n = 0;
     for (int c = lane; c < C; c += 64) {
         float o = (v[n] - mean) * rstd * g[c] + b[c];
-        if constexpr (sizeof(OutT) == 2) yr[c] = f32_to_bf16(o); else yr[c] = o;
+        if constexpr (SPLIT) { uint16_t hi, lo; split_f16(o, hi, lo); yr[c] = hi; yr[plane + c] = lo; }
+        else if constexpr (sizeof(OutT) == 2) yr[c] = f32_to_bf16(o);
+        else yr[c] = o;
         ++n;
     }
 }
@@ -96,6 +98,27 @@ int launch_layer_norm_bf16(const float* x, const float* g, const float* b, uint1
     ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * rows * C, 6.0 * rows * C, st);
     layer_norm_kernel<uint16_t><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
     GENIE_LAUNCH_CHECK("layer_norm_bf16");
+    return GENIE_OK;
+}
+
+int launch_layer_norm_split(const float* x, const float* g, const float* b, uint16_t* y, size_t plane, long rows, int C,
+                            float eps, hipStream_t st) {
+    GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
+    int blocks = (int)((rows + 3) / 4);
+    ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * rows * C, 8.0 * rows * C, st);
+    layer_norm_kernel<uint16_t, true><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps, plane);
+    GENIE_LAUNCH_CHECK("layer_norm_split");
+    return GENIE_OK;
+}
+
+__global__ void split_f16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t plane, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uint16_t hi, lo; split_f16(src[i], hi, lo); dst[i] = hi; dst[plane + i] = lo; }
+}
+int launch_split_f16(const float* src, uint16_t* dst, size_t plane, size_t n, hipStream_t st) {
+    if (!n) return GENIE_OK;
+    split_f16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, dst, plane, n);
+    GENIE_LAUNCH_CHECK("split_f16");
     return GENIE_OK;
 }
 
@@ -754,7 +777,8 @@ template <int DH, int NKT>
 __global__ __launch_bounds__(512) void attn_spatial_f32_mfma_kernel(const float* __restrict__ qkv,
                                                                     float* __restrict__ out, int d, float scale,
                                                                     const float* __restrict__ nw,
-                                                                    const float* __restrict__ nb) {
+                                                                    const float* __restrict__ nb,
+                                                                    uint16_t* __restrict__ out16, size_t plane) {
     constexpr int S = NKT * 32, LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sK = smem;
@@ -888,7 +912,10 @@ __global__ __launch_bounds__(512) void attn_spatial_f32_mfma_kernel(const float*
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int q = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                out[(size_t)(row0 + q) * d + head * DH + dt * 32 + r] = oc[dt][e];
+                const size_t oi = (size_t)(row0 + q) * d + head * DH + dt * 32 + r;
+                if (!out16) out[oi] = oc[dt][e];
+                else if (plane) { uint16_t hi, lo; split_f16(oc[dt][e], hi, lo); out16[oi] = hi; out16[plane + oi] = lo; }
+                else out16[oi] = f32_to_bf16(oc[dt][e]);
             }
     }
 }
@@ -896,7 +923,7 @@ __global__ __launch_bounds__(512) void attn_spatial_f32_mfma_kernel(const float*
 // Spatial attention, contiguous sequences of S rows.  Returns GENIE_E_UNSUPPORTED when the shape has no
 // MFMA instantiation (the caller then uses the generic kernel).
 int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
-                                 const float* nw, const float* nb, hipStream_t st) {
+                                 const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
     if (S != 256 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
     const size_t lds = (size_t)2 * S * (Dh + 4) * sizeof(float);
     dim3 grid((unsigned)n_seq, H);
@@ -904,11 +931,11 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
     if (Dh == 64) {
         (void)hipFuncSetAttribute((const void*)attn_spatial_f32_mfma_kernel<64, 8>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attn_spatial_f32_mfma_kernel<64, 8><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb);
+        attn_spatial_f32_mfma_kernel<64, 8><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane);
     } else {
         (void)hipFuncSetAttribute((const void*)attn_spatial_f32_mfma_kernel<32, 8>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attn_spatial_f32_mfma_kernel<32, 8><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb);
+        attn_spatial_f32_mfma_kernel<32, 8><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane);
     }
     GENIE_LAUNCH_CHECK("attn_spatial_f32_mfma");
     return GENIE_OK;
@@ -932,7 +959,8 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
                                                                      float* __restrict__ out, long n_bs, int S,
                                                                      int d, int H, float scale,
                                                                      const float* __restrict__ nw,
-                                                                     const float* __restrict__ nb) {
+                                                                     const float* __restrict__ nb,
+                                                                     uint16_t* __restrict__ out16, size_t plane) {
     constexpr int T = 16, PER = DH / 4;  // floats per lane per row
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -992,7 +1020,7 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     const float inv = 1.0f / sum;
     // O = P V
     const float* vp = base + 2 * d + (size_t)(4 * g) * tok_stride + r;
-    float* op = out + ((size_t)(b * T) * S + s) * d + head * DH + r;
+    const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + r;
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -1001,19 +1029,24 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[e] * inv, vp[(size_t)e * tok_stride + dt * 16], o, 0, 0, 0);
         // C/D map of the 16x16 MFMA: col = lane&15 (feature), row = 4*(lane>>4) + e (query frame)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) op[(size_t)(4 * g + e) * S * d + dt * 16] = o[e];
+        for (int e = 0; e < 4; ++e) {
+            const size_t oi = obase + (size_t)(4 * g + e) * S * d + dt * 16;
+            if (!out16) out[oi] = o[e];
+            else if (plane) { uint16_t hi, lo; split_f16(o[e], hi, lo); out16[oi] = hi; out16[plane + oi] = lo; }
+            else out16[oi] = f32_to_bf16(o[e]);
+        }
     }
 }
 
 // Temporal attention over T = 16 frames on a (B,T,S,3d) buffer; GENIE_E_UNSUPPORTED for other geometries.
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
-                                  const float* nw, const float* nb, hipStream_t st) {
+                                  const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
     if (T != 16 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
     const long n_bs = (long)B * S, waves = n_bs * H;
     ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 16.0, st);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb);
-    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb);
+    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb, out16, plane);
+    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb, out16, plane);
     GENIE_LAUNCH_CHECK("attn_temporal_f32_mfma");
     return GENIE_OK;
 }

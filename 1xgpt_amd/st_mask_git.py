@@ -10,7 +10,8 @@ There is no CPU fallback: calling a method with CPU tensors raises.
 Differences that are deliberate and visible:
   * ``maskgit_generate`` takes two optional extras, ``noise`` (the U[0,1) draws the reference takes from
     ``torch.rand_like``, :206) and ``uniforms`` (for temperature > 0), so a test can replay an exact stream.
-  * ``precision``: "exact" (f32 MFMA; the parity gate) or "bf16" (bf16 MFMA operands, f32 accumulate).
+  * ``precision``: "exact" (f32 MFMA), "f16x3" (split-f16 operands on the f16 matrix cores, f32-class
+    results: the parity-grade fast mode) or "bf16" (bf16 MFMA operands, f32 accumulate: throughput mode).
 """
 import json
 import math
@@ -24,7 +25,8 @@ from .config import GenieConfig
 from .factorization_utils import FactorizedEmbedding
 from .st_transformer import STTransformerDecoder
 
-_PRECISIONS = {"exact": _lib.PREC_EXACT, "f32": _lib.PREC_EXACT, "bf16": _lib.PREC_BF16, "fast": _lib.PREC_BF16}
+_PRECISIONS = {"exact": _lib.PREC_EXACT, "f32": _lib.PREC_EXACT, "bf16": _lib.PREC_BF16, "fast": _lib.PREC_BF16,
+               "f16x3": _lib.PREC_F16X3}
 
 
 def cosine_schedule(u):
@@ -112,12 +114,20 @@ class STMaskGIT(nn.Module):
         _lib.check(lib.genie_check_config(cfg), "genie_check_config")
         keep = []
         packed = None
+        st = torch.cuda.current_stream().cuda_stream
         if self._prec == _lib.PREC_BF16:
-            st = torch.cuda.current_stream().cuda_stream
 
             def packed(wt):
                 t = torch.empty(wt.shape, dtype=torch.bfloat16, device=dev)
                 _lib.check(lib.genie_pack_bf16(wt.data_ptr(), t.data_ptr(), wt.numel(), st), "genie_pack_bf16")
+                keep.append(t)
+                return t.data_ptr()
+        elif self._prec == _lib.PREC_F16X3:
+
+            def packed(wt):  # [hi plane | lo plane], wt ~ hi + lo/2048
+                t = torch.empty((2,) + tuple(wt.shape), dtype=torch.float16, device=dev)
+                _lib.check(lib.genie_pack_split_f16(wt.data_ptr(), t.data_ptr(), wt.numel(), st),
+                           "genie_pack_split_f16")
                 keep.append(t)
                 return t.data_ptr()
 

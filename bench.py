@@ -30,8 +30,8 @@ if REPO not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"exact": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32 MFMA / dense bf16 MFMA
-DTYPE = {"exact": "f32", "bf16": "bf16"}
+PEAK_TFLOPS = {"exact": 157.3, "f16x3": 2500.0, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32 MFMA / dense f16, bf16 MFMA
+DTYPE = {"exact": "f32", "f16x3": "f16x3 (split-f16 operands, f32-class results)", "bf16": "bf16"}
 PUBLISHED_FRAMES_PER_SEC = {"c138": 1.0 / 0.075, "c35": 1.0 / 0.030}  # BASELINE.md section 1 (1x RTX 4090, fp32)
 
 
@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", choices=["exact", "bf16"], default=os.environ.get("GENIE_BENCH_PRECISION", "exact"))
+    ap.add_argument("--precision", choices=["exact", "f16x3", "bf16"], default=os.environ.get("GENIE_BENCH_PRECISION", "exact"))
     ap.add_argument("--model", choices=["c138", "c35"], default="c138")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step")
     ap.add_argument("--maskgit-steps", type=int, default=2)
@@ -95,7 +95,7 @@ def main():
     lib = _lib.load()
 
     cfg = cfgmod.c138() if args.model == "c138" else cfgmod.c35()
-    B = args.batch or (4 if args.precision == "exact" else 32)
+    B = args.batch or {"exact": 4, "f16x3": 16, "bf16": 32}[args.precision]
     sd = synth.make_state_dict(cfg, seed=0, law="conditioned")
     model = STMaskGIT(cfg, precision=args.precision).load_numpy_state_dict(sd).to(dev)
     all_clips = synth.make_clips(B * world, cfg, seed=1234)
@@ -180,8 +180,9 @@ def main():
         "model_tflops_per_gpu": passes_per_step * F * args.steps / seconds / 1e12,
         "model_frac_of_mfma_peak": passes_per_step * F * args.steps / seconds / 1e12 / peak,
         "roofline": {
-            "kernel": "gemm_f32_nt_kernel (v_mfma_f32_32x32x2_f32)" if args.precision == "exact"
-                      else "gemm_bf16_nt_kernel (v_mfma_f32_32x32x16_bf16)",
+            "kernel": {"exact": "gemm_f32_nt_kernel (v_mfma_f32_32x32x2_f32)",
+                       "f16x3": "gemm16_nt_kernel<2,32> (3x v_mfma_f32_32x32x16_f16 per K-step)",
+                       "bf16": "gemm16_nt_kernel<1,64> (v_mfma_f32_32x32x16_bf16)"}[args.precision],
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "launches": int(gemm_launches), "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
             "flops_per_launch": gemm_flops / max(gemm_launches, 1),

@@ -36,8 +36,11 @@ enum {
     GENIE_E_ASSERT = -5       /* a reference `assert` would have fired (st_mask_git.py:154-156) */
 };
 
-enum { GENIE_PREC_EXACT = 0, /* f32 MFMA, f32 everywhere: the parity gate */
-       GENIE_PREC_BF16 = 1   /* bf16 MFMA operands, f32 accumulate/residual/LN/softmax */ };
+enum { GENIE_PREC_EXACT = 0, /* f32 MFMA (v_mfma_f32_32x32x2_f32), f32 everywhere */
+       GENIE_PREC_BF16 = 1,  /* bf16 MFMA operands, f32 accumulate/residual/LN/softmax: throughput mode */
+       GENIE_PREC_F16X3 = 2  /* every Linear on the f16 matrix cores with split operands a = hi + lo/2048:
+                                hi.hi + (hi.lo + lo.hi)/2048 in f32 = 22-bit operands, f32-class results at
+                                1/3 of the f16 MFMA rate; attention, LN, softmax, residual stay f32 */ };
 
 enum { GENIE_LAYOUT_TOKEN_MAJOR = 0, /* (B, nt, S, V)              */
        GENIE_LAYOUT_BCTHW = 1        /* (B, V, nt, S) == "B C T H W" (st_mask_git.py:264) */ };
@@ -107,6 +110,9 @@ size_t genie_workspace_bytes(const genie_cfg* cfg, int B);
 
 /* f32 -> bf16 (round-to-nearest-even) weight packing for GENIE_PREC_BF16. */
 int genie_pack_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
+/* f32 -> f16 split planes for GENIE_PREC_F16X3: dst[0..n) = hi, dst[n..2n) = lo with src ~ hi + lo/2048.
+ * In that precision the *_w16 pointers of the weight tables point at such 2n-element buffers. */
+int genie_pack_split_f16(const float* src, uint16_t* dst, size_t n, void* stream);
 
 /* ---- unit entry points (one reference op each; used by the parity tests) -------------------------- */
 
@@ -122,6 +128,12 @@ int genie_layer_norm(const float* x, const float* gamma, const float* beta, floa
  * x (M,K), W (N,K), y (M,N).  (attention.py:27,29; st_transformer.py:16-25) */
 int genie_linear(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int gelu,
                  int accumulate, void* stream);
+
+/* The same Linear on the 16-bit matrix cores with PRE-PACKED operands (unit entry for parity tests and tuning):
+ * GENIE_PREC_BF16: x16 (M,K), W16 (N,K) bf16 (genie_pack_bf16);  GENIE_PREC_F16X3: split planes [hi | lo] of
+ * each (genie_pack_split_f16).  y (M,N) f32. */
+int genie_linear_lowp(int precision, const uint16_t* x16, const uint16_t* W16, const float* b, float* y, int M, int N,
+                      int K, int gelu, int accumulate, void* stream);
 
 /* softmax(scale q k^T [+causal]) v on a packed qkv buffer (attention.py:38-59).
  * qkv (B,T,S,3d) with feature index = which*d + head*Dh + i; out (B,T,S,d).

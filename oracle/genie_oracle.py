@@ -37,17 +37,23 @@ def round_bf16(a: np.ndarray) -> np.ndarray:
 class Numerics:
     """dtype + optional operand rounding applied at every GEMM/attention-matmul input."""
 
-    def __init__(self, dtype=np.float32, gemm_in=None):
+    def __init__(self, dtype=np.float32, gemm_in=None, attn_in=False):
         self.dtype = np.dtype(dtype)
-        self.gemm_in = gemm_in  # e.g. round_bf16 for the bf16-MFMA contract
+        self.gemm_in = gemm_in  # rounding of every nn.Linear operand (e.g. round_bf16)
+        self.attn_in = attn_in  # True: the attention matmuls also take rounded operands (bf16 contract);
+        #                         False: attention is f32 in the reference's order (exact / f16x3 contract)
 
     def r(self, a):
         return a if self.gemm_in is None else self.gemm_in(a).astype(self.dtype, copy=False)
 
+    def ra(self, a):
+        return self.r(a) if self.attn_in else a
+
 
 F32 = Numerics(np.float32)
 F64 = Numerics(np.float64)
-BF16_MFMA = Numerics(np.float32, round_bf16)
+BF16_MFMA = Numerics(np.float32, round_bf16)  # Linear operands bf16; attention core f32 (HIP bf16 contract)
+BF16_ALL = Numerics(np.float32, round_bf16, attn_in=True)  # attention matmuls on bf16 operands as well
 
 
 # ----------------------------------------------------------------------------------------------
@@ -119,19 +125,31 @@ def self_attention(x_BNC, sd, prefix, cfg, causal, nm=F32, chunk=64):
         qkv = nm.r(x) @ Wqkv.T  # (b,N,3C), no bias unless cfg.qkv_bias
         if cfg.qkv_bias:
             qkv = qkv + sd[prefix + "qkv.bias"].astype(dt)
+        qkv = nm.ra(qkv)  # bf16 contract: the qkv buffer itself is stored rounded (f32 otherwise)
         qkv = qkv.reshape(b, N, 3, H, Dh).transpose(2, 0, 3, 1, 4)  # (3,b,H,N,Dh)  attention.py:38
         q, k, v = qkv[0], qkv[1], qkv[2]
         if cfg.qk_norm:  # one shared affine for q and k  (attention.py:42-47)
             g, bb = sd[prefix + "norm.weight"], sd[prefix + "norm.bias"]
             q = layer_norm(q, g, bb)
             k = layer_norm(k, g, bb)
-        q = q * scale  # attention.py:48
-        attn = nm.r(q) @ nm.r(k).transpose(0, 1, 3, 2)  # (b,H,N,N)
+        if not nm.attn_in:
+            q = q * scale  # attention.py:48
+            attn = q @ k.transpose(0, 1, 3, 2)  # (b,H,N,N)
+        else:
+            # 16-bit matrix-core contract of the HIP fast path: q, k are rounded operands and the scale
+            # multiplies the f32 scores (same math, different rounding point)
+            attn = (nm.r(q) @ nm.r(k).transpose(0, 1, 3, 2)) * scale
         if causal:  # attention.py:51-55
             mask = ~np.tril(np.ones((N, N), dtype=bool))
             attn = np.where(mask, -np.finfo(dt).max, attn)
-        attn = _softmax_last(attn)
-        o = (nm.r(attn) @ nm.r(v)).transpose(0, 2, 1, 3).reshape(b, N, C)  # attention.py:59
+        if not nm.attn_in:
+            attn = _softmax_last(attn)
+            o = attn @ v
+        else:
+            # ... and the un-normalised probabilities are the rounded operand of P.V; the f32 row sum divides after
+            e = np.exp(attn - attn.max(-1, keepdims=True))
+            o = (nm.r(e) @ nm.r(v)) / e.sum(-1, keepdims=True)
+        o = o.transpose(0, 2, 1, 3).reshape(b, N, C)  # attention.py:59
         o = nm.r(o) @ Wp.T
         if cfg.proj_bias:
             o = o + sd[prefix + "proj.bias"].astype(dt)
@@ -191,9 +209,13 @@ def readout(x_BTSC, sd, cfg, nm=F32):
     """token-major logits (B,T,S,V); muP: Linear(output_mult*x/width_mult) (st_mask_git.py:316-323)."""
     dt = nm.dtype
     x = x_BTSC
-    if cfg.use_mup:
-        x = x * dt.type(cfg.readout_mult)
-    return nm.r(x) @ nm.r(sd["out_x_proj.weight"].astype(dt)).T + sd["out_x_proj.bias"].astype(dt)
+    if nm.gemm_in is None:
+        if cfg.use_mup:
+            x = x * dt.type(cfg.readout_mult)
+        return x @ sd["out_x_proj.weight"].astype(dt).T + sd["out_x_proj.bias"].astype(dt)
+    # 16-bit contract: the muP factor scales the f32 accumulator
+    return (nm.r(x) @ nm.r(sd["out_x_proj.weight"].astype(dt)).T) * dt.type(cfg.readout_mult) \
+        + sd["out_x_proj.bias"].astype(dt)
 
 
 def compute_logits(ids_BTHW, sd, cfg, nm=F32):
@@ -399,3 +421,20 @@ def bits_from_tokens(ids_BHW, codebook_dim=18, dtype=np.float32):
     ids = np.asarray(ids_BHW, dtype=np.int64)
     bits = (ids[:, None] >> np.arange(codebook_dim, dtype=np.int64)[None, :, None, None]) & 1
     return (bits * 2 - 1).astype(dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# f16 split-pair emulation used to pin the "f16x3" HIP precision: a ~ hi + lo/2048 with hi, lo in f16
+# (hi flushed to zero below the f16 normal range), i.e. a 22-bit operand; the kernel forms
+# hi.hi + (hi.lo + lo.hi)/2048 in f32 and drops the lo.lo term (2^-22 relative).
+# ----------------------------------------------------------------------------------------------
+def round_f16_split(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        hi = a.astype(np.float16).astype(np.float32)
+    hi = np.where(np.abs(hi) < np.float32(6.103515625e-05), np.float32(0), hi)
+    lo = ((a - hi) * np.float32(2048.0)).astype(np.float16).astype(np.float32)
+    return hi + lo * np.float32(1.0 / 2048.0)
+
+
+F16X3 = Numerics(np.float32, round_f16_split)
