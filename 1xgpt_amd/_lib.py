@@ -80,6 +80,9 @@ SIGNATURES = {
     "genie_profile_reset": (C.c_int, []),
     "genie_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "genie_bits_from_tokens": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "genie_rescale_u8_bf16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_rescale_u8_f32": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_tokens_from_bits": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
 }
 
 _lib = None

@@ -483,4 +483,17 @@ int genie_bits_from_tokens(const int64_t* ids, float* z, int n, int hw, int bits
     return launch_bits(ids, z, n, hw, bits, as_stream(stream));
 }
 
+int genie_rescale_u8_bf16(const uint16_t* x, uint8_t* out, size_t n, void* stream) {
+    GENIE_CHECK_ARG(x && out, "rescale_u8: NULL pointer");
+    return launch_rescale_u8(x, 1, out, n, as_stream(stream));
+}
+int genie_rescale_u8_f32(const float* x, uint8_t* out, size_t n, void* stream) {
+    GENIE_CHECK_ARG(x && out, "rescale_u8: NULL pointer");
+    return launch_rescale_u8(x, 0, out, n, as_stream(stream));
+}
+int genie_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, void* stream) {
+    GENIE_CHECK_ARG(h && ids && n >= 0 && hw >= 1 && bits >= 1 && bits <= 62, "tokens_from_bits: bad argument");
+    return launch_tokens_from_bits(h, ids, n, hw, bits, as_stream(stream));
+}
+
 }  // extern "C"

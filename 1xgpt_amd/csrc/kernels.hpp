@@ -64,6 +64,8 @@ int launch_mask_step(const float* keys, int n, int last_step, int64_t mask_id, u
 int launch_check_masked(const int64_t* prompt, int B, int T, int S, int out_t, int64_t mask_id, int32_t* flag,
                         hipStream_t st);
 int launch_bits(const int64_t* ids, float* z, int n, int hw, int bits, hipStream_t st);
+int launch_rescale_u8(const void* x, int is_bf16, uint8_t* out, size_t n, hipStream_t st);
+int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, hipStream_t st);
 int launch_pack_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t st);
 
 }  // namespace genie

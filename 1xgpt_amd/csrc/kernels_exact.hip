@@ -1051,4 +1051,48 @@ int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, in
     return GENIE_OK;
 }
 
+// rescale_magvit_output (visualize.py:84-92) with the reference's bf16 intermediate roundings
+__global__ void rescale_u8_bf16_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = bf16_to_f32(x[i]);
+    v = bf16_to_f32(f32_to_bf16(v + 1.0f));
+    v = bf16_to_f32(f32_to_bf16(v * 127.5f));
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    out[i] = (uint8_t)v;  // truncating cast
+}
+__global__ void rescale_u8_f32_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = (x[i] + 1.0f) * 127.5f;
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    out[i] = (uint8_t)v;
+}
+int launch_rescale_u8(const void* x, int is_bf16, uint8_t* out, size_t n, hipStream_t st) {
+    if (!n) return GENIE_OK;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (is_bf16) rescale_u8_bf16_kernel<<<blocks, 256, 0, st>>>((const uint16_t*)x, out, n);
+    else rescale_u8_f32_kernel<<<blocks, 256, 0, st>>>((const float*)x, out, n);
+    GENIE_LAUNCH_CHECK("rescale_u8");
+    return GENIE_OK;
+}
+
+// encoder output (n, bits, hw) -> dataset-convention token ids, bit c = [h_c > 0]
+__global__ void tokens_from_bits_kernel(const float* __restrict__ h, int64_t* __restrict__ ids, long n, int hw,
+                                        int bits) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * hw) return;
+    long img = idx / hw, p = idx - img * hw;
+    int64_t id = 0;
+    for (int c = 0; c < bits; ++c) id |= (int64_t)(h[(img * bits + c) * hw + p] > 0.0f) << c;
+    ids[idx] = id;
+}
+int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, hipStream_t st) {
+    long tot = (long)n * hw;
+    if (tot <= 0) return GENIE_OK;
+    tokens_from_bits_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(h, ids, n, hw, bits);
+    GENIE_LAUNCH_CHECK("tokens_from_bits");
+    return GENIE_OK;
+}
+
 }  // namespace genie

@@ -1,0 +1,303 @@
+"""MAGVIT2 frame tokenizer, inference subset, on the same device as the world model.
+
+Counterpart of the reference's magvit2/ package restricted to what the hot path needs:
+``Decoder`` (18 x 16 x 16 +-1 bits -> 3 x 256 x 256), ``Encoder`` (the mirror), the LFQ bit (un)packing and the
+``decode_latents_wrapper`` of visualize.py:95-122.  State-dict keys equal the reference's ``encoder.*`` /
+``decoder.*`` keys, so a Lightning ``magvit2.ckpt`` loads with ``load_tokenizer_ckpt``.
+
+Round-1 slice: the conv stack runs on PyTorch-ROCm convolutions (MIOpen) -- GroupNorm(32, eps 1e-6), x*sigmoid(x),
+3x3/1x1 convs, DCR depth-to-space -- while the integer/byte ends of the pipeline are HIP kernels behind the C ABI:
+``genie_bits_from_tokens`` (tokens -> +-1 planes), ``genie_rescale_u8_*`` (the truncating u8 rescale with the
+reference's bf16 roundings) and ``genie_tokens_from_bits``.  Tokens and frames never leave HBM (the reference
+round-trips through numpy and PIL, eval_utils.py:39-41).  Hand-written implicit-GEMM MFMA convs are the next step
+(SURVEY.md section 8f rank 2).
+"""
+import json
+import math
+import zlib
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+@dataclass
+class VQConfig:
+    """Architecture fields of the reference's magvit2/config.py:9-43 (loss/training fields are accepted and ignored)."""
+    in_channels: int = 3
+    z_channels: int = 18
+    out_channels: int = 3
+    base_channels: int = 128
+    ch_mult: tuple = (1, 1, 2, 2, 4)
+    num_res_blocks: int = 2
+    num_codebooks: int = 1
+    codebook_size: int = 262144
+    token_factorization: bool = False
+
+    @classmethod
+    def from_pretrained(cls, json_path):
+        with open(json_path) as f:
+            raw = json.load(f)
+        known = {"in_channels", "z_channels", "out_channels", "base_channels", "ch_mult", "num_res_blocks",
+                 "num_codebooks", "codebook_size", "token_factorization"}
+        kw = {k: v for k, v in raw.items() if k in known}
+        if "ch_mult" in kw:
+            kw["ch_mult"] = tuple(kw["ch_mult"])
+        return cls(**kw)
+
+
+def swish(x):
+    return x * torch.sigmoid(x)  # improved_model.py:7-9
+
+
+class ResBlock(nn.Module):
+    """GN32 -> swish -> conv3x3 -> GN32 -> swish -> conv3x3 (+ 1x1 shortcut on channel change), no conv biases
+    (improved_model.py:12-51)."""
+
+    def __init__(self, in_filters, out_filters):
+        super().__init__()
+        self.in_filters, self.out_filters = in_filters, out_filters
+        self.norm1 = nn.GroupNorm(32, in_filters, eps=1e-6)
+        self.norm2 = nn.GroupNorm(32, out_filters, eps=1e-6)
+        self.conv1 = nn.Conv2d(in_filters, out_filters, kernel_size=(3, 3), padding=1, bias=False)
+        self.conv2 = nn.Conv2d(out_filters, out_filters, kernel_size=(3, 3), padding=1, bias=False)
+        if in_filters != out_filters:
+            self.nin_shortcut = nn.Conv2d(in_filters, out_filters, kernel_size=(1, 1), padding=0, bias=False)
+
+    def forward(self, x):
+        residual = x
+        x = self.conv1(swish(self.norm1(x)))
+        x = self.conv2(swish(self.norm2(x)))
+        if self.in_filters != self.out_filters:
+            residual = self.nin_shortcut(residual)
+        return x + residual
+
+
+def depth_to_space(x: torch.Tensor, block_size: int) -> torch.Tensor:
+    """DCR depth-to-space: channel (i*bs + j)*C' + c -> pixel (bs*h + i, bs*w + j), channel c (improved_model.py:185-218)."""
+    c, h, w = x.shape[-3:]
+    s = block_size ** 2
+    if c % s != 0:
+        raise ValueError(f"Expecting a channels-first (*CHW) tensor with C divisible by {s}, but got C={c} channels")
+    outer = x.shape[:-3]
+    x = x.reshape(-1, block_size, block_size, c // s, h, w).permute(0, 3, 4, 1, 5, 2)
+    return x.reshape(*outer, c // s, h * block_size, w * block_size)
+
+
+class Upsampler(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv1 = nn.Conv2d(dim, dim * 4, (3, 3), padding=1)
+
+    def forward(self, x):
+        return depth_to_space(self.conv1(x), 2)
+
+
+class _Level(nn.Module):
+    pass
+
+
+class Encoder(nn.Module):
+    """improved_model.py:54-121."""
+
+    def __init__(self, config: VQConfig):
+        super().__init__()
+        self.num_res_blocks, self.num_blocks = config.num_res_blocks, len(config.ch_mult)
+        self.conv_in = nn.Conv2d(config.in_channels, config.base_channels, kernel_size=(3, 3), padding=1, bias=False)
+        self.down = nn.ModuleList()
+        in_ch_mult = (1,) + tuple(config.ch_mult)
+        block_in = block_out = config.base_channels
+        for i_level in range(self.num_blocks):
+            block = nn.ModuleList()
+            block_in = config.base_channels * in_ch_mult[i_level]
+            block_out = config.base_channels * config.ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResBlock(block_in, block_out))
+                block_in = block_out
+            down = _Level()
+            down.block = block
+            if i_level < self.num_blocks - 1:
+                down.downsample = nn.Conv2d(block_out, block_out, kernel_size=(3, 3), stride=(2, 2), padding=1)
+            self.down.append(down)
+        self.mid_block = nn.ModuleList([ResBlock(block_in, block_in) for _ in range(self.num_res_blocks)])
+        self.norm_out = nn.GroupNorm(32, block_out, eps=1e-6)
+        self.conv_out = nn.Conv2d(block_out, config.z_channels, kernel_size=(1, 1))
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for i_level in range(self.num_blocks):
+            for blk in self.down[i_level].block:
+                x = blk(x)
+            if i_level < self.num_blocks - 1:
+                x = self.down[i_level].downsample(x)
+        for blk in self.mid_block:
+            x = blk(x)
+        return self.conv_out(swish(self.norm_out(x)))
+
+
+class Decoder(nn.Module):
+    """improved_model.py:124-182."""
+
+    def __init__(self, config: VQConfig):
+        super().__init__()
+        self.num_blocks, self.num_res_blocks = len(config.ch_mult), config.num_res_blocks
+        block_in = config.base_channels * config.ch_mult[self.num_blocks - 1]
+        self.conv_in = nn.Conv2d(config.z_channels, block_in, kernel_size=(3, 3), padding=1, bias=True)
+        self.mid_block = nn.ModuleList([ResBlock(block_in, block_in) for _ in range(self.num_res_blocks)])
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_blocks)):
+            block = nn.ModuleList()
+            block_out = config.base_channels * config.ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResBlock(block_in, block_out))
+                block_in = block_out
+            up = _Level()
+            up.block = block
+            if i_level > 0:
+                up.upsample = Upsampler(block_in)
+            self.up.insert(0, up)
+        self.norm_out = nn.GroupNorm(32, block_in, eps=1e-6)
+        self.conv_out = nn.Conv2d(block_in, config.out_channels, kernel_size=(3, 3), padding=1)
+
+    def forward(self, z):
+        z = self.conv_in(z)
+        for blk in self.mid_block:
+            z = blk(z)
+        for i_level in reversed(range(self.num_blocks)):
+            for blk in self.up[i_level].block:
+                z = blk(z)
+            if i_level > 0:
+                z = self.up[i_level].upsample(z)
+        return self.conv_out(swish(self.norm_out(z)))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def bits_from_tokens(ids: torch.LongTensor, codebook_dim: int = 18) -> torch.Tensor:
+    """(n, h, w) int64 -> (n, codebook_dim, h, w) f32 in {-1,+1}, channel c = bit c (LSB first): what
+    ``LFQ.get_codebook_entry(...).flip(1)`` yields (lookup_free_quantize.py:181-194, visualize.py:114-115)."""
+    if not ids.is_cuda:
+        raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): move tokens to cuda")
+    ids = ids.to(torch.int64).contiguous()
+    n, h, w = ids.shape
+    z = torch.empty(n, codebook_dim, h, w, dtype=torch.float32, device=ids.device)
+    lib = _lib.load()
+    _lib.check(lib.genie_bits_from_tokens(ids.data_ptr(), z.data_ptr(), n, h * w, codebook_dim, _stream()),
+               "genie_bits_from_tokens")
+    return z
+
+
+def tokens_from_bits(hcode: torch.Tensor) -> torch.LongTensor:
+    """Encoder output (n, bits, h, w) -> dataset-convention ids (n, h, w): bit c = [h_c > 0] (LSB first)."""
+    if not hcode.is_cuda:
+        raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback)")
+    hc = hcode.float().contiguous()
+    n, bits, h, w = hc.shape
+    ids = torch.empty(n, h, w, dtype=torch.int64, device=hc.device)
+    lib = _lib.load()
+    _lib.check(lib.genie_tokens_from_bits(hc.data_ptr(), ids.data_ptr(), n, h * w, bits, _stream()),
+               "genie_tokens_from_bits")
+    return ids
+
+
+def rescale_magvit_output(x: torch.Tensor) -> torch.Tensor:
+    """[-1,1] -> uint8 [0,255], clamp then truncate, on the device (visualize.py:84-92).  bf16 input reproduces the
+    reference's bf16 intermediate roundings bit for bit."""
+    if not x.is_cuda:
+        raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback)")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    lib = _lib.load()
+    if x.dtype == torch.bfloat16:
+        _lib.check(lib.genie_rescale_u8_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "genie_rescale_u8")
+    else:
+        x = x.float()
+        _lib.check(lib.genie_rescale_u8_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "genie_rescale_u8")
+    return out
+
+
+class VQModel(nn.Module):
+    """Encoder + Decoder + LFQ bit packing (inference subset of models/lfqgan.py:21-133)."""
+
+    def __init__(self, config: VQConfig = None):
+        super().__init__()
+        self.config = config or VQConfig()
+        self.encoder = Encoder(self.config)
+        self.decoder = Decoder(self.config)
+        self.codebook_dim = int(math.log2(self.config.codebook_size))
+        self.requires_grad_(False)
+
+    def decode(self, quant):
+        return self.decoder(quant)
+
+    @torch.no_grad()
+    def decode_tokens(self, ids_nhw: torch.LongTensor) -> torch.Tensor:
+        """(n, h, w) token ids -> (n, 3, H, W) uint8, in the module's dtype (the reference uses bf16)."""
+        dt = next(self.parameters()).dtype
+        z = bits_from_tokens(ids_nhw, self.codebook_dim).to(dt)
+        return rescale_magvit_output(self.decoder(z))
+
+    @torch.no_grad()
+    def encode_tokens(self, frames_u8: torch.Tensor) -> torch.LongTensor:
+        """(n, 3, H, W) uint8 -> (n, h, w) ids with the dataset bit convention."""
+        dt = next(self.parameters()).dtype
+        x = (frames_u8.to(torch.float32) / 127.5 - 1.0).to(dt)
+        return tokens_from_bits(self.encoder(x))
+
+
+def load_tokenizer_ckpt(model: VQModel, path: str):
+    """Lightning checkpoint -> encoder.* / decoder.* (lfqgan.py:85-119; EMA == raw weights at inference)."""
+    sd = torch.load(path, map_location="cpu")["state_dict"]
+    own = model.state_dict()
+    picked = {k: v for k, v in sd.items() if k in own}
+    missing = [k for k in own if k not in picked]
+    if missing:
+        raise KeyError(f"tokenizer checkpoint lacks {len(missing)} keys, e.g. {missing[:3]}")
+    model.load_state_dict(picked, strict=True)
+    return model
+
+
+def decode_latents_wrapper(batch_size=16, tokenizer_ckpt="data/magvit2.ckpt", max_images=None, model: VQModel = None,
+                           device="cuda", dtype=torch.bfloat16):
+    """visualize.py:95-122, device-resident: returns ``decode_latents(tokens (b,h,w)) -> uint8 (b,3,H,W)`` tensor."""
+    if model is None:
+        model = load_tokenizer_ckpt(VQModel(VQConfig()), tokenizer_ckpt)
+    model = model.to(device=device, dtype=dtype).eval()
+
+    @torch.no_grad()
+    def decode_latents(video_data):
+        if isinstance(video_data, np.ndarray):
+            video_data = torch.from_numpy(video_data.astype(np.int64))
+        video_data = video_data.to(device)
+        outs = []
+        for s in range(0, video_data.shape[0], batch_size):
+            outs.append(model.decode_tokens(video_data[s:s + batch_size]))
+            if max_images and len(outs) * batch_size >= max_images:
+                break
+        return torch.cat(outs)
+
+    return decode_latents
+
+
+# ---- synthetic tokenizer weights (no magvit2.ckpt offline): PCG64 streams keyed by (seed, crc32(key)) ------------
+def make_vq_state_dict(model: VQModel, seed: int = 1) -> dict:
+    """{key: f32 ndarray}: conv weights N(0, 1/sqrt(fan_in)), biases N(0, 0.05), GroupNorm gamma 1 + 0.1 N, beta 0.05 N."""
+    out = {}
+    for k, v in model.state_dict().items():
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, zlib.crc32(k.encode())])))
+        z = g.standard_normal(tuple(v.shape), dtype=np.float32)
+        if v.dim() == 4:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            w = z * np.float32(1.0 / math.sqrt(fan_in))
+        elif k.endswith("weight"):  # GroupNorm gamma
+            w = np.float32(1.0) + z * np.float32(0.1)
+        else:
+            w = z * np.float32(0.05)
+        out[k] = np.ascontiguousarray(w, dtype=np.float32)
+    return out

@@ -225,6 +225,18 @@ int genie_profile_read(int kernel_class, double* out4);
  * ids (n, hw) int64 -> z (n, bits, hw) float32 in {-1,+1}, channel c = bit c (LSB first). */
 int genie_bits_from_tokens(const int64_t* ids, float* z, int n, int hw, int bits, void* stream);
 
+/* rescale_magvit_output (visualize.py:84-92): u8 = trunc(clamp((x + 1) * 127.5, 0, 255)).  The reference applies
+ * it to the decoder's bf16 output with bf16 arithmetic (each op rounds to bf16); `x` holds bf16 bits and the same
+ * roundings are reproduced, so the bytes are identical for identical decoder outputs.  n elements. */
+int genie_rescale_u8_bf16(const uint16_t* x, uint8_t* out, size_t n, void* stream);
+/* f32 variant (no intermediate bf16 rounding), for an f32 decoder. */
+int genie_rescale_u8_f32(const float* x, uint8_t* out, size_t n, void* stream);
+
+/* Dataset-compatible LFQ index of an encoder output h (n, bits, hw) f32: id = sum_c [h_c > 0] << c (LSB first;
+ * the inverse of genie_bits_from_tokens; cf. lookup_free_quantize.py:241-257 which packs MSB-first and is NOT
+ * the dataset convention).  ids (n, hw) int64. */
+int genie_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -438,3 +438,25 @@ def round_f16_split(a: np.ndarray) -> np.ndarray:
 
 
 F16X3 = Numerics(np.float32, round_f16_split)
+
+
+# ----------------------------------------------------------------------------------------------
+# a19 epilogue / a20 epilogue: byte and integer ends of the tokenizer path
+# ----------------------------------------------------------------------------------------------
+def rescale_u8_bf16(x_bf16_as_f32):
+    """rescale_magvit_output on a bf16 tensor (visualize.py:84-92): every op rounds to bf16, then clamp, truncate."""
+    v = round_bf16(np.asarray(x_bf16_as_f32, np.float32) + np.float32(1.0))
+    v = round_bf16(v * np.float32(127.5))
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def rescale_u8_f32(x):
+    v = (np.asarray(x, np.float32) + np.float32(1.0)) * np.float32(127.5)
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def tokens_from_bits(h_nchw):
+    """Dataset-convention index of an encoder output: id = sum_c [h_c > 0] << c (inverse of bits_from_tokens)."""
+    h = np.asarray(h_nchw)
+    bits = (h > 0).astype(np.int64)
+    return (bits << np.arange(h.shape[1], dtype=np.int64)[None, :, None, None]).sum(1)

@@ -32,15 +32,37 @@ def models(golden):
     return get
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 192, 64), (100, 70, 64), (512, 1024, 256), (4096, 1536, 512), (300, 64, 2048)])
-def test_gemm16_bf16_vs_rounded_operands(M, N, K):
-    """One linear layer through a 1-layer-free path: use the model-free bf16 GEMM via a tiny STMaskGIT readout."""
-    C = pkg("config")
-    # readout of a d=K model: logits = bf16(x) . bf16(W)^T + b   (f32 accumulate)
-    if N != 1024 or K % 64:
-        pytest.skip("readout shape only")
-    cfg = C.GenieConfig(num_layers=1, num_heads=K // 64, d_model=K, T=4, S=16, num_factored_vocabs=2, qk_norm=False)
-    assert cfg.factored_vocab_size == 512
+@pytest.mark.parametrize("prec", ["bf16", "f16x3"])
+@pytest.mark.parametrize("M,N,K", [(128, 192, 64), (100, 70, 64), (513, 1024, 256), (4096, 1536, 512), (37, 64, 2048)])
+def test_linear_lowp(prec, M, N, K):
+    """genie_linear_lowp on pre-packed operands vs float64 on the SAME rounded operands (asymmetric, ragged M/N)."""
+    lib_mod = pkg("_lib")
+    L = lib_mod.load()
+    g = np.random.default_rng(M + N + K)
+    x = g.standard_normal((M, K), dtype=np.float32)
+    W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = g.standard_normal(N, dtype=np.float32)
+    y0 = g.standard_normal((M, N), dtype=np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    npl, code, pack, rnd = (1, lib_mod.PREC_BF16, L.genie_pack_bf16, O.round_bf16) if prec == "bf16" else \
+        (2, lib_mod.PREC_F16X3, L.genie_pack_split_f16, O.round_f16_split)
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    x16 = torch.empty(npl, M, K, dtype=torch.float16, device="cuda")
+    W16 = torch.empty(npl, N, K, dtype=torch.float16, device="cuda")
+    lib_mod.check(pack(xd.data_ptr(), x16.data_ptr(), x.size, st), "pack")
+    lib_mod.check(pack(Wd.data_ptr(), W16.data_ptr(), W.size, st), "pack")
+    ref = rnd(x).astype(np.float64) @ rnd(W).astype(np.float64).T + b
+    y = torch.empty(M, N, device="cuda")
+    lib_mod.check(L.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N, K, 0, 0,
+                                      st), "lowp")
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(y.cpu().numpy() - ref).max() < tol
+    if prec == "f16x3":  # and it is f32-class against the UNROUNDED operands
+        exact = x.astype(np.float64) @ W.astype(np.float64).T + b
+        assert np.abs(y.cpu().numpy() - exact).max() < tol
+    yd = dev(y0.copy())
+    lib_mod.check(L.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), 0, yd.data_ptr(), M, N, K, 1, 1, st), "lowp")
+    assert np.abs(yd.cpu().numpy() - (y0 + O.gelu_erf(ref - b))).max() < 2 * tol
 
 
 @pytest.mark.parametrize("name", ["tiny_ln", "tiny_qknorm", "tiny_mup", "tiny_qknorm_mup"])

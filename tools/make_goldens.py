@@ -301,9 +301,116 @@ def shape_fixture(name, cfg_kwargs, wseed, gap_thr, do_eval=True, B=1, steps_lis
           f"ev_loss={out.get('ev_loss', float('nan')):.6f}")
 
 
+def harness_fixture():
+    """generate.py semantics (prompt 2 -> 2 frames, [prompt | generated | gt]) and the RawTokenDataset filters,
+    produced by the reference's own data.py and the body of generate.py:77-103 driven on the tiny model."""
+    import tempfile
+    import data as ref_data
+    cfg_kwargs = dict(num_layers=2, num_heads=2, d_model=64, T=4, S=16, num_factored_vocabs=2, qk_norm=False,
+                      use_mup=False)
+    model, cfg = build_ref_model(cfg_kwargs, 11)
+    g = np.random.default_rng(321)
+    n_img, side = 60, 4
+    tokens = g.integers(0, 262144, size=(n_img, side, side)).astype(np.uint32)
+    seg = np.sort(g.integers(0, 4, size=n_img)).astype(np.int32)
+    out = {"tokens": tokens, "segment_ids": seg, "cfg": np.array(repr(cfg_kwargs)), "weight_seed": 11}
+    with tempfile.TemporaryDirectory() as d:
+        tokens.tofile(os.path.join(d, "video.bin"))
+        seg.tofile(os.path.join(d, "segment_ids.bin"))
+        with open(os.path.join(d, "metadata.json"), "w") as f:
+            import json
+            json.dump({"num_images": n_img, "s": side, "vocab_size": 262144, "hz": 30, "token_dtype": "uint32"}, f)
+        for name, kw in [("w4s3", dict(window_size=4, stride=3)),
+                         ("w4s3_overlap", dict(window_size=4, stride=3, filter_overlaps=True)),
+                         ("w4s1_nointerrupt", dict(window_size=4, stride=1, filter_interrupts=False)),
+                         ("w4s2_overlap", dict(window_size=4, stride=2, filter_overlaps=True))]:
+            ds = ref_data.RawTokenDataset(d, **kw)
+            out["ds_" + name + "_starts"] = np.array(ds.valid_start_inds, dtype=np.int64)
+            out["ds_" + name + "_item0"] = ds[0]["input_ids"].numpy()
+            out["ds_" + name + "_item_last"] = ds[len(ds) - 1]["input_ids"].numpy()
+        ds = ref_data.RawTokenDataset(d, window_size=4, stride=3)
+        # generate.py:70-103 on example 1 (window 4, 2 prompt frames, 2 maskgit steps, temperature 0)
+        example = ds[1]["input_ids"].reshape(1, 4, side, side)
+        for tf in (False, True):
+            with Recorder(model) as rec:
+                torch.manual_seed(5)
+                samples = []
+                prompt = example.clone()
+                prompt[:, 2:] = model.mask_token_id
+                for t in range(2, 4):
+                    if tf:
+                        prompt = example.clone()
+                        prompt[:, t:] = model.mask_token_id  # what generate.py:86 means (image_mask_token is a bug)
+                    s_hw, _ = model.maskgit_generate(prompt, out_t=t, maskgit_steps=2, temperature=0)
+                    samples.append(s_hw)
+                    if not tf:
+                        prompt[:, t] = s_hw
+                outs = torch.cat([example[:, :2], torch.stack(samples, 1), example[:, 2:]], 1)
+            key = "gen_tf" if tf else "gen_ar"
+            out[key + "_outputs"] = outs.numpy()
+            out[key + "_noise"] = np.stack(rec.noise).reshape(2, 1, 1, side * side)
+        out["gen_example"] = example.numpy()
+    np.savez_compressed(os.path.join(OUT, "harness.npz"), **out)
+    print("harness: dataset windows", {k: v.shape for k, v in out.items() if k.endswith("_starts")})
+
+
+def magvit_fixture():
+    """MAGVIT2 inference pieces from the reference: LFQ bit order, ResBlock/Upsampler/Decoder/Encoder I/O on a small
+    VQConfig, and rescale_magvit_output on bf16 (visualize.py)."""
+    from magvit2.config import VQConfig as RefVQ
+    from magvit2.modules.diffusionmodules.improved_model import Encoder as RefEnc, Decoder as RefDec
+    from magvit2.modules.vqvae.lookup_free_quantize import LFQ
+    mv = importlib.import_module("1xgpt_amd.magvit2")
+    small = dict(base_channels=32, ch_mult=(1, 2), num_res_blocks=1)
+    rcfg = RefVQ(**small)
+    mine = mv.VQModel(mv.VQConfig(**small))
+    sd = mv.make_vq_state_dict(mine, seed=1)
+    enc, dec = RefEnc(rcfg), RefDec(rcfg)
+    enc.load_state_dict({k[len("encoder."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("encoder.")})
+    dec.load_state_dict({k[len("decoder."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("decoder.")})
+    enc.eval(), dec.eval()
+    g = np.random.default_rng(9)
+    out = {"cfg": np.array(repr(small)), "weight_seed": 1}
+    # a18: token -> bits (LFQ on the full 2^18 codebook config)
+    lfq = LFQ(RefVQ())
+    ids = g.integers(0, 262144, size=(3, 16)).astype(np.int64)
+    ids[0, :4] = [0, 1, 2, 262143]
+    quant = lfq.get_codebook_entry(torch.from_numpy(ids), bhwc=(3, 4, 4, 18)).flip(1)
+    out["bits_ids"], out["bits_z"] = ids.reshape(3, 4, 4), quant.numpy().astype(np.float32)
+    # decoder: tokens -> frames, f32 and bf16 (the reference decodes in bf16, visualize.py:97-101)
+    tok = g.integers(0, 262144, size=(2, 4, 4)).astype(np.int64)
+    z = lfq.get_codebook_entry(torch.from_numpy(tok.reshape(2, 16)), bhwc=(2, 4, 4, 18)).flip(1).float()
+    y32 = dec(z)
+    out["dec_tokens"], out["dec_out_f32"] = tok, y32.numpy()
+    import visualize as ref_vis
+    out["dec_u8_f32"] = ref_vis.rescale_magvit_output(y32).numpy()
+    dec16 = RefDec(rcfg)
+    dec16.load_state_dict(dec.state_dict())
+    dec16 = dec16.to(torch.bfloat16).eval()
+    y16 = dec16(z.to(torch.bfloat16))
+    out["dec_out_bf16_as_f32"] = y16.float().numpy()
+    out["dec_u8_bf16"] = ref_vis.rescale_magvit_output(y16).numpy()
+    # rescale alone on arbitrary bf16 values (bit-exact target)
+    r = (torch.from_numpy(g.standard_normal(4096).astype(np.float32)) * 1.3).to(torch.bfloat16)
+    out["rescale_in_bf16_as_f32"] = r.float().numpy()
+    out["rescale_out"] = ref_vis.rescale_magvit_output(r).numpy()
+    # encoder: frames -> code (pre-quantisation) -> sign bits
+    frames = g.integers(0, 256, size=(2, 3, 8, 8)).astype(np.uint8)
+    xin = torch.from_numpy(frames).float() / 127.5 - 1.0
+    hcode = enc(xin)
+    out["enc_frames"], out["enc_h"] = frames, hcode.numpy()
+    out["enc_min_abs_h"] = np.float64(hcode.abs().min().item())
+    np.savez_compressed(os.path.join(OUT, "magvit_small.npz"), **out)
+    print("magvit_small: dec out range", float(y32.min()), float(y32.max()), "enc |h| min", out["enc_min_abs_h"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "shape", "c35", "c138"]
+    which = sys.argv[1:] or ["tiny", "shape", "c35", "c138", "harness", "magvit"]
+    if "harness" in which:
+        harness_fixture()
+    if "magvit" in which:
+        magvit_fixture()
     base = dict(num_layers=2, num_heads=2, d_model=64, T=4, S=16, num_factored_vocabs=2)
     if "tiny" in which:
         tiny_fixture("tiny_ln", dict(base, qk_norm=False, use_mup=False), 11)
