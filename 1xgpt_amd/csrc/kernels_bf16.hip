@@ -181,6 +181,206 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm16_v2_kernel: the same contraction, restructured for the model's shapes (M = 4096*B rows, K = 512..2048):
+//   * 256x128 block tile, 8 waves (4x2), wave tile 64x64: 1.5x the operand reuse of the 128x128 tile
+//   * 3-stage LDS ring of 48 KB stages (A 256 rows + W 128 rows, x NPL planes), filled by global_load_lds;
+//     the wave waits with a COUNTED vmcnt (the next stage stays in flight across the barrier) and a raw
+//     s_barrier -- the 2-stage / vmcnt(0)-per-iteration structure above is load-latency-bound at K = 512
+//   * XCD-aware block order: the 8 m-tiles of a group go to the 8 XCDs and each XCD walks the n-tiles of ITS
+//     m-tile, so the big operand (A) is fetched into one L2 only; W (<= 2 MB) is resident in every L2.
+// ------------------------------------------------------------------------------------------------
+template <int NPL, int BK>
+__global__ __launch_bounds__(512, 1) void gemm16_v2_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
+                                                           const uint16_t* __restrict__ W, long ldw, long planeW,
+                                                           const float* __restrict__ bias, float* __restrict__ Cf,
+                                                           uint16_t* __restrict__ C16, long plane16, long ldc, int M,
+                                                           int N, int K, int flags, float alpha, long strideA,
+                                                           long strideC) {
+    constexpr int BM = 256, BN = 128, NST = 3;
+    constexpr int ROWB = BK * 2, SPR = ROWB / 16, RPB = 256 / ROWB;
+    constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB;
+    constexpr int STAGE_B = NPL * (A_TILE + W_TILE);       // 48 KB
+    constexpr int NCH = STAGE_B / 1024;                     // 1 KB chunks per stage (48)
+    constexpr int CPW = NCH / 8;                            // per wave (6)
+    constexpr int CHUNK_ROWS = 1024 / ROWB;
+    static_assert(STAGE_B == 48 * 1024 && CPW * 8 == NCH, "stage geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order (see header)
+    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    int bid = blockIdx.x, m_tile, n_tile;
+    const int full = (mt / 8) * 8 * nt;
+    if (bid < full) {
+        const int grp = bid / (8 * nt), rem = bid - grp * 8 * nt;
+        m_tile = grp * 8 + (rem & 7);
+        n_tile = rem >> 3;
+    } else {
+        const int rem = bid - full;
+        m_tile = (mt / 8) * 8 + rem / nt;
+        n_tile = rem % nt;
+    }
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    A += (size_t)blockIdx.y * strideA;
+    if (Cf) Cf += (size_t)blockIdx.y * strideC;
+    if (C16) C16 += (size_t)blockIdx.y * strideC;
+
+    // ---- staging: chunk c = wid + 8*i of the stage image [A pl0 .. | W pl0 ..]
+    const uint16_t* gsrc[CPW];
+    int ldsoff[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = wid + 8 * i;
+        int off = c * 1024;
+        const bool isA = off < NPL * A_TILE;
+        if (!isA) off -= NPL * A_TILE;
+        const int tile_b = isA ? A_TILE : W_TILE;
+        const int pl = off / tile_b;
+        const int in_tile = off - pl * tile_b;
+        const int row_local = in_tile / ROWB + lane / SPR;
+        const int slot = (lane % SPR) ^ ((row_local / RPB) % SPR);
+        if (isA) {
+            int ra = m0 + row_local; ra = ra < M ? ra : M - 1;
+            gsrc[i] = A + (size_t)pl * planeA + (size_t)ra * lda + slot * 8;
+        } else {
+            int rw = n0 + row_local; rw = rw < N ? rw : N - 1;
+            gsrc[i] = W + (size_t)pl * planeW + (size_t)rw * ldw + slot * 8;
+        }
+        ldsoff[i] = c * 1024;
+    }
+    auto stage = [&](int st, int k0) {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(smem + st * STAGE_B + ldsoff[i]),
+                                             16, 0, 0);
+    };
+
+    f32x16 acc[2][2], corr[NPL == 2 ? 2 : 1][NPL == 2 ? 2 : 1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if constexpr (NPL == 2) corr[i][j][e] = 0.f;
+            }
+    int rowA[2], rowB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { rowA[i] = wm * 64 + i * 32 + r; rowB[i] = wn * 64 + i * 32 + r; }
+    auto frag_off = [&](int row_local, int kk) {
+        const int slot = 2 * kk + h;
+        return row_local * ROWB + ((slot ^ ((row_local / RPB) % SPR)) << 4);
+    };
+
+    const int nk = K / BK;
+    stage(0, 0);
+    if (nk > 1) stage(1, BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt must have landed: at most the CPW loads of stage kt+1 may still be in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's share of stage kt is visible; stage kt-1's buffer is free
+        if (kt + 2 < nk) stage((kt + 2) % NST, (kt + 2) * BK);
+        const unsigned char* sa = smem + (kt % NST) * STAGE_B;
+        const unsigned char* sw = sa + NPL * A_TILE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if constexpr (NPL == 1) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *reinterpret_cast<const bf16x8*>(sa + frag_off(rowA[i], kk));
+                    b[i] = *reinterpret_cast<const bf16x8*>(sw + frag_off(rowB[i], kk));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(sa + frag_off(rowA[i], kk));
+                    al[i] = *reinterpret_cast<const f16x8*>(sa + A_TILE + frag_off(rowA[i], kk));
+                    bh[i] = *reinterpret_cast<const f16x8*>(sw + frag_off(rowB[i], kk));
+                    bl[i] = *reinterpret_cast<const f16x8*>(sw + W_TILE + frag_off(rowB[i], kk));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], corr[i][j], 0, 0, 0);
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], corr[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue.  The accumulators hold one COLUMN per lane (C/D map of the 32x32 MFMA), which would make
+    // every global access a 4-byte-per-lane row fragment (store-issue-bound: measured ~2x the K=512 main loop).
+    // Each wave transposes its 64x64 tile through its own 16 KB of the (now free) LDS ring and then works on
+    // whole rows: 16 lanes x float4 = one 256-byte row segment per quarter-wave for the residual read, the f32
+    // store and the 16-bit operand store.
+    __syncthreads();  // every wave is done with the stage buffers (and has drained its loads)
+    float* ct = reinterpret_cast<float*>(smem) + wid * (64 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e];
+                if constexpr (NPL == 2) v += corr[i][j][e] * SPLIT_INV;
+                ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = v;
+            }
+    const bool do_gelu = flags & G16_GELU, do_acc = flags & G16_ACCUM;
+    const bool out16 = flags & G16_OUT16, outf = flags & G16_OUTF32;
+    const int c4 = (lane & 15) << 2;
+    const int col = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && col < N) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + rl;
+        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+        if (row >= M || col >= N) continue;
+        v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
+        if (do_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        const size_t idx = (size_t)row * ldc + col;
+        if (do_acc) {
+            const float4 o = *reinterpret_cast<const float4*>(Cf + idx);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
+        if (out16) {
+            if constexpr (NPL == 1) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>(C16 + idx) = pk;
+            } else {
+                uint16_t h0, l0, h1, l1, h2, l2, h3, l3;
+                split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3);
+                uint2 ph, pl;
+                ph.x = (uint32_t)h0 | ((uint32_t)h1 << 16); ph.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                pl.x = (uint32_t)l0 | ((uint32_t)l1 << 16); pl.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
+                *reinterpret_cast<uint2*>(C16 + idx) = ph;
+                *reinterpret_cast<uint2*>(C16 + (size_t)plane16 + idx) = pl;
+            }
+        }
+    }
+}
+
 // A, W: 16-bit operands (NPL planes each, plane strides in elements); Cf f32 (ACCUM / OUTF32), C16 16-bit out.
 template <int NPL>
 static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
@@ -190,9 +390,25 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
     GENIE_CHECK_SHAPE(K % BK == 0 && K > 0, "gemm16: K=%d must be a positive multiple of %d", K, BK);
     GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
     if (M <= 0 || N <= 0) return GENIE_OK;
+    const double mn = (double)M * N * batch;
+    if (M >= 256 && N % 4 == 0 && ldc % 4 == 0) {
+        const int mt2 = (M + 255) / 256, nt2 = (N + 127) / 128;
+        const size_t lds2 = 3 * 48 * 1024;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
+                       2.0 * NPL * ((double)M * K * batch + (double)N * K) +
+                           mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) +
+                                 (flags & G16_OUT16 ? 2 * NPL : 0)),
+                       st);
+        (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds2);
+        gemm16_v2_kernel<NPL, BK><<<dim3(mt2 * nt2, batch), 512, lds2, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf,
+                                                                              C16, plane16, ldc, M, N, K, flags,
+                                                                              alpha, strideA, strideC);
+        GENIE_LAUNCH_CHECK("gemm16_v2");
+        return GENIE_OK;
+    }
     const int mt = (M + 127) / 128, nt = (N + 127) / 128;
     const size_t lds = (size_t)2 * 2 * NPL * 128 * BK * 2;
-    const double mn = (double)M * N * batch;
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
                    2.0 * NPL * ((double)M * K * batch + (double)N * K) +
                        mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) + (flags & G16_OUT16 ? 2 * NPL : 0)),
