@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--maskgit-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel-class times")
+    ap.add_argument("--no-events", action="store_true",
+                    help="do not bracket GEMM launches with HIP events (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
     dist_mod = importlib.import_module("1xgpt_amd.distributed")
@@ -115,8 +117,9 @@ def main():
     for _ in range(args.warmup):
         step()
     # timed region: exactly K steps, GEMM launches bracketed by HIP events on the launch stream
-    _lib.check(lib.genie_profile_enable(1 << _lib.KC_GEMM), "profile_enable")
-    lib.genie_profile_reset()
+    if not args.no_events:
+        _lib.check(lib.genie_profile_enable(1 << _lib.KC_GEMM), "profile_enable")
+        lib.genie_profile_reset()
     dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
