@@ -61,6 +61,8 @@ static Workspace carve(const genie_cfg& c, int B, void* base) {
     w.unmasked = (uint8_t*)take((size_t)B * c.S);
     w.aux = take(M * c.d_model * 4);
     w.total = off;
+    w.tqkv = nullptr;
+    w.tcache = nullptr;
     return w;
 }
 
@@ -102,7 +104,7 @@ static int check_ws(const genie_cfg& c, int B, void* ws, size_t bytes) {
 static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, const float* u, float* x, Workspace& w,
                            int B, bool temporal, hipStream_t st) {
     const int d = c.d_model, M = B * c.T * c.S;
-    float* qkv = (float*)w.big;
+    float* qkv = (temporal && w.tqkv) ? w.tqkv : (float*)w.big;
     float* ao = (float*)w.xn;  // u may alias w.xn: it is dead once qkv is computed
     GENIE_TRY(launch_gemm_f32(u, d, 0, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, qkv, 3 * d, 0, M, 3 * d, d, 1,
                               0, 1.0f, st));
@@ -115,6 +117,9 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
             rc = launch_attn_generic(qkv, ao, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
                                      c.attn_scale, 0, nw, nb, st);
         GENIE_TRY(rc);
+    } else if (w.tcache) {
+        GENIE_TRY(launch_attn_temporal_prefix(qkv, w.tcache, ao, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
+                                              nw, nb, st));
     } else {
         int rc = launch_attn_temporal_f32_mfma(qkv, ao, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nw, nb,
                                                st);
@@ -339,6 +344,52 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* wt, const in
     GENIE_TRY(decoder(*cfg, *wt, w.x, w, B, st));
     if (t0 == t1) return GENIE_OK;
     return readout(*cfg, *wt, w.x, w, B, t0, t1, layout, logits, st);
+}
+
+// ---- teacher-forced prefix reuse ---------------------------------------------------------------------
+size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B) {
+    if (check_cfg(cfg) != GENIE_OK || B < 1) return 0;
+    return (size_t)cfg->num_layers * B * cfg->T * cfg->S * 3 * cfg->d_model * sizeof(float);
+}
+
+static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int64_t* ids, int B, float* cache,
+                          bool clean, Workspace& w, hipStream_t st) {
+    const size_t per_layer = (size_t)B * c.T * c.S * 3 * c.d_model;
+    GENIE_TRY(launch_embed(c, wt, ids, B, w.x, st));
+    if (c.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c, w.x, w, B, st));
+    if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, w.x, w, B, st));
+    for (int i = 0; i < c.num_layers; ++i) {
+        if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; }
+        else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; }
+        int rc = st_block(c, wt.layers_host[i], w.x, w, B, st);
+        w.tqkv = nullptr;
+        w.tcache = nullptr;
+        GENIE_TRY(rc);
+    }
+    return GENIE_OK;
+}
+
+int genie_clean_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, float* cache,
+                     size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(wt && wt->layers_host && ids && cache, "clean_pass: NULL pointer");
+    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "clean_pass: cache too small");
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    Workspace w = carve(*cfg, B, workspace);
+    return prefix_forward(*cfg, *wt, ids, B, cache, true, w, as_stream(stream));
+}
+
+int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frames, int B,
+                               const float* cache, size_t cache_bytes, float* logits, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(wt && wt->layers_host && frames && cache && logits, "masked_frames_logits: NULL pointer");
+    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "masked_frames_logits: cache too small");
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    Workspace w = carve(*cfg, B, workspace);
+    hipStream_t st = as_stream(stream);
+    GENIE_TRY(prefix_forward(*cfg, *wt, frames, B, const_cast<float*>(cache), false, w, st));
+    return readout(*cfg, *wt, w.x, w, B, 0, cfg->T, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
 }
 
 int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, const int64_t* targets,

@@ -18,6 +18,9 @@ struct Workspace {
     uint8_t* unmasked; // (B, S)
     void* aux;         // (M, d) x 4 bytes: f16x3 = split planes of the LayerNorm / attention output
     size_t total;
+    // teacher-forced prefix reuse (set per layer by the prefix entry points, NULL otherwise):
+    float* tqkv;         // where the temporal qkv GEMM writes (clean pass: this layer's slice of the cache)
+    const float* tcache; // non-NULL: temporal attention takes keys j < i from this cached qkv (masked-frames pass)
 };
 
 // Brackets one launch with HIP events when profiling of `cls` is enabled (see genie_profile_* in the ABI).
@@ -51,6 +54,9 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
                                   const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
                                   size_t plane = 0);
+int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
+                                int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
+                                uint16_t* out16 = nullptr, size_t plane = 0);
 int launch_layer_norm_split(const float* x, const float* g, const float* b, uint16_t* y, size_t plane, long rows, int C,
                             float eps, hipStream_t st);
 int launch_split_f16(const float* src, uint16_t* dst, size_t plane, size_t n, hipStream_t st);

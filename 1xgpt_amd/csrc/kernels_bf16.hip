@@ -465,14 +465,25 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.spatial.proj_w16, d, 0, c.proj_bias ? lw.spatial.proj_b : nullptr, x, x16,
                                0, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
     // temporal (no pre-norm): operand = bf16 shadow of x
-    GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, qkv,
+    float* tq = w.tqkv ? w.tqkv : qkv;
+    GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
-    rc = launch_attn_temporal_f32_mfma(qkv, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt, st,
-                                       xn16, 0);
-    if (rc == GENIE_E_UNSUPPORTED) {
-        GENIE_TRY(launch_attn_generic(qkv, w.logits, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
-                                      c.head_dim, c.attn_scale, 1, nwt, nbt, st));
-        rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
+    if (w.tcache) {
+        rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
+                                         nwt, nbt, st, xn16, 0);
+        if (rc == GENIE_E_UNSUPPORTED) {
+            GENIE_TRY(launch_attn_temporal_prefix(tq, w.tcache, w.logits, B, c.T, c.S, d, c.num_heads, c.head_dim,
+                                                  c.attn_scale, nwt, nbt, st));
+            rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
+        }
+    } else {
+        rc = launch_attn_temporal_f32_mfma(tq, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt,
+                                           st, xn16, 0);
+        if (rc == GENIE_E_UNSUPPORTED) {
+            GENIE_TRY(launch_attn_generic(tq, w.logits, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
+                                          c.head_dim, c.attn_scale, 1, nwt, nbt, st));
+            rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
+        }
     }
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.temporal.proj_w16, d, 0, c.proj_bias ? lw.temporal.proj_b : nullptr, x,
@@ -554,15 +565,26 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.spatial.proj_w16, d, pw_proj, c.proj_bias ? lw.spatial.proj_b : nullptr, x,
                                xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
     // ---- temporal
-    GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, qkv,
+    float* tq = w.tqkv ? w.tqkv : qkv;
+    GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
-    rc = launch_attn_temporal_f32_mfma(qkv, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt, st,
-                                       as, pd);
-    if (rc == GENIE_E_UNSUPPORTED) {
-        float* tmp = w.logits;
-        GENIE_TRY(launch_attn_generic(qkv, tmp, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
-                                      c.head_dim, c.attn_scale, 1, nwt, nbt, st));
-        rc = launch_split_f16(tmp, as, pd, pd, st);
+    if (w.tcache) {
+        rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
+                                         nwt, nbt, st, as, pd);
+        if (rc == GENIE_E_UNSUPPORTED) {
+            GENIE_TRY(launch_attn_temporal_prefix(tq, w.tcache, w.logits, B, c.T, c.S, d, c.num_heads, c.head_dim,
+                                                  c.attn_scale, nwt, nbt, st));
+            rc = launch_split_f16(w.logits, as, pd, pd, st);
+        }
+    } else {
+        rc = launch_attn_temporal_f32_mfma(tq, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt,
+                                           st, as, pd);
+        if (rc == GENIE_E_UNSUPPORTED) {
+            float* tmp = w.logits;
+            GENIE_TRY(launch_attn_generic(tq, tmp, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
+                                          c.head_dim, c.attn_scale, 1, nwt, nbt, st));
+            rc = launch_split_f16(tmp, as, pd, pd, st);
+        }
     }
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.temporal.proj_w16, d, pw_proj, c.proj_bias ? lw.temporal.proj_b : nullptr,

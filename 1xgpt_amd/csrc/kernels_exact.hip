@@ -1095,4 +1095,207 @@ int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bit
     return GENIE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Teacher-forced prefix reuse: temporal attention of "frame t in timeline t".
+// In the evaluator's timeline t the frames < t are ground truth, and because temporal attention is causal
+// and everything else is per-frame, their activations are those of ONE clean pass over the ground-truth clip.
+// So query frame i attends keys j < i taken from the clean pass's cached temporal qkv (`cache`, same layout
+// (B,T,S,3d)) and key j = i from the current buffer `cur`; current frames never see each other.
+//   scores_j<i = scale q_i . kc_j   (MFMA, as attn_temporal_f32_mfma_kernel)      diag = scale q_i . k_i
+//   o_i = sum_j<i p_ij vc_j  +  p_ii v_i
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
+    const float* __restrict__ cur, const float* __restrict__ cache, float* __restrict__ out, long n_bs, int S, int d,
+    int H, float scale, const float* __restrict__ nw, const float* __restrict__ nb, uint16_t* __restrict__ out16,
+    size_t plane) {
+    constexpr int T = 16, PER = DH / 4;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long bs = wave / H;
+    const int head = (int)(wave - bs * H);
+    if (bs >= n_bs) return;
+    const long b = bs / S, s = bs - b * S;
+    const long tok_stride = (long)S * 3 * d;
+    const size_t off0 = ((size_t)(b * T) * S + s) * 3 * d + head * DH;
+    const float* qp = cur + off0 + (size_t)r * tok_stride + g * PER;
+    const float* kcp = cache + off0 + (size_t)r * tok_stride + d + g * PER;
+    float q[PER], k[PER], kc[PER];
+#pragma unroll
+    for (int c = 0; c < PER / 4; ++c) {
+        float4 a = *reinterpret_cast<const float4*>(qp + 4 * c);
+        float4 bb = *reinterpret_cast<const float4*>(qp + d + 4 * c);
+        float4 cc = *reinterpret_cast<const float4*>(kcp + 4 * c);
+        q[4 * c] = a.x; q[4 * c + 1] = a.y; q[4 * c + 2] = a.z; q[4 * c + 3] = a.w;
+        k[4 * c] = bb.x; k[4 * c + 1] = bb.y; k[4 * c + 2] = bb.z; k[4 * c + 3] = bb.w;
+        kc[4 * c] = cc.x; kc[4 * c + 1] = cc.y; kc[4 * c + 2] = cc.z; kc[4 * c + 3] = cc.w;
+    }
+    if (nw) {
+        float sq = 0.f, sk = 0.f, sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER; ++c) { sq += q[c]; sk += k[c]; sc += kc[c]; }
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        sk += __shfl_xor(sk, 16); sk += __shfl_xor(sk, 32);
+        sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
+        const float mq = sq / DH, mk = sk / DH, mc = sc / DH;
+        float vq = 0.f, vk = 0.f, vc = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER; ++c) {
+            float a = q[c] - mq, bb = k[c] - mk, cc = kc[c] - mc;
+            vq += a * a; vk += bb * bb; vc += cc * cc;
+        }
+        vq += __shfl_xor(vq, 16); vq += __shfl_xor(vq, 32);
+        vk += __shfl_xor(vk, 16); vk += __shfl_xor(vk, 32);
+        vc += __shfl_xor(vc, 16); vc += __shfl_xor(vc, 32);
+        const float rq = 1.0f / sqrtf(vq / DH + 1e-5f), rk = 1.0f / sqrtf(vk / DH + 1e-5f),
+                    rc = 1.0f / sqrtf(vc / DH + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < PER; ++c) {
+            const float w_ = nw[g * PER + c], b_ = nb[g * PER + c];
+            q[c] = (q[c] - mq) * rq * w_ + b_;
+            k[c] = (k[c] - mk) * rk * w_ + b_;
+            kc[c] = (kc[c] - mc) * rc * w_ + b_;
+        }
+    }
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};  // row = cached key j = 4g + e, col = query i = r
+    float dg = 0.f;                   // diagonal: q_i . k_i (same q*scale products as the MFMA path)
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+        const float qs = q[c] * scale;
+        st = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[c], qs, st, 0, 0, 0);
+        dg = fmaf(k[c], qs, dg);
+    }
+    dg += __shfl_xor(dg, 16);
+    dg += __shfl_xor(dg, 32);
+    float mx = dg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (4 * g + e >= r) st[e] = -INFINITY;  // strictly earlier frames only
+        mx = fmaxf(mx, st[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { st[e] = expf(st[e] - mx); sum += st[e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float pd = expf(dg - mx);
+    const float inv = 1.0f / (sum + pd);
+    const float pdn = pd * inv;  // weight of the query's own (current) frame, held by every lane with r == i
+    const float* vcp = cache + off0 + 2 * d + (size_t)(4 * g) * tok_stride + r;
+    const float* vp = cur + off0 + 2 * d + (size_t)(4 * g) * tok_stride + r;
+    const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + r;
+    float pself[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pself[e] = __shfl(pdn, 4 * g + e);  // lane index 4g+e has r = 4g+e
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[e] * inv, vcp[(size_t)e * tok_stride + dt * 16], o, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = fmaf(pself[e], vp[(size_t)e * tok_stride + dt * 16], o[e]);
+            const size_t oi = obase + (size_t)(4 * g + e) * S * d + dt * 16;
+            if (!out16) out[oi] = v;
+            else if (plane) { uint16_t hi, lo; split_f16(v, hi, lo); out16[oi] = hi; out16[plane + oi] = lo; }
+            else out16[oi] = f32_to_bf16(v);
+        }
+    }
+}
+
+// generic geometry (any T <= 64, Dh in {8,16,32,64}): one thread per (b, s, head, frame)
+template <int DH>
+__global__ void attn_temporal_prefix_generic_kernel(const float* __restrict__ cur, const float* __restrict__ cache,
+                                                    float* __restrict__ out, long n, int T, int S, int d, int H,
+                                                    float scale, const float* __restrict__ nw,
+                                                    const float* __restrict__ nb) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int i = (int)(idx % T);
+    long rest = idx / T;
+    const int head = (int)(rest % H);
+    rest /= H;
+    const long s = rest % S, b = rest / S;
+    const long tok_stride = (long)S * 3 * d;
+    const size_t off0 = ((size_t)(b * T) * S + s) * 3 * d + head * DH;
+    auto load_norm = [&](const float* p, float* v) {
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) { v[c] = p[c]; m += v[c]; }
+        if (nw) {
+            m /= DH;
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) { float t = v[c] - m; var += t * t; }
+            const float rs = 1.0f / sqrtf(var / DH + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < DH; ++c) v[c] = (v[c] - m) * rs * nw[c] + nb[c];
+        }
+    };
+    float q[DH], kk[DH], o[DH];
+    load_norm(cur + off0 + (size_t)i * tok_stride, q);
+#pragma unroll
+    for (int c = 0; c < DH; ++c) { q[c] *= scale; o[c] = 0.f; }
+    float sc[64];
+    float mx = -INFINITY;
+    for (int j = 0; j <= i; ++j) {
+        const float* src = (j < i ? cache : cur) + off0 + (size_t)j * tok_stride + d;
+        load_norm(src, kk);
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) a = fmaf(q[c], kk[c], a);
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+    for (int j = 0; j <= i; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j <= i; ++j) {
+        const float* vsrc = (j < i ? cache : cur) + off0 + (size_t)j * tok_stride + 2 * d;
+        const float p = sc[j] * inv;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) o[c] = fmaf(p, vsrc[c], o[c]);
+    }
+    float* op = out + ((size_t)(b * T + i) * S + s) * d + head * DH;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) op[c] = o[c];
+}
+
+// out16/plane as in launch_attn_temporal_f32_mfma; the generic fallback writes f32 `out` only
+// (returns GENIE_E_UNSUPPORTED if a 16-bit output is requested for a geometry without an MFMA instantiation).
+int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
+                                int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
+                                uint16_t* out16, size_t plane) {
+    const long n_bs = (long)B * S, waves = n_bs * H;
+    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 28.0, st);
+    if (T == 16 && (Dh == 32 || Dh == 64)) {
+        const unsigned blocks = (unsigned)((waves + 3) / 4);
+        if (Dh == 64)
+            attn_temporal_prefix_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, scale, nw, nb,
+                                                                             out16, plane);
+        else
+            attn_temporal_prefix_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, scale, nw, nb,
+                                                                             out16, plane);
+        GENIE_LAUNCH_CHECK("attn_temporal_prefix_mfma");
+        return GENIE_OK;
+    }
+    if (out16) return GENIE_E_UNSUPPORTED;
+    GENIE_CHECK_SHAPE(T <= 64, "prefix attention: T=%d > 64", T);
+    const long n = waves * T;
+    const unsigned blocks = (unsigned)((n + 127) / 128);
+    switch (Dh) {
+        case 8: attn_temporal_prefix_generic_kernel<8><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
+        case 16: attn_temporal_prefix_generic_kernel<16><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
+        case 32: attn_temporal_prefix_generic_kernel<32><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
+        case 64: attn_temporal_prefix_generic_kernel<64><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
+        default: set_error("prefix attention: head_dim %d unsupported", Dh); return GENIE_E_SHAPE;
+    }
+    GENIE_LAUNCH_CHECK("attn_temporal_prefix_generic");
+    return GENIE_OK;
+}
+
 }  // namespace genie

@@ -167,6 +167,21 @@ int genie_readout_logits(const genie_cfg* cfg, const genie_weights* w, const flo
 int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int t0, int t1,
                          int layout, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- teacher-forced prefix reuse (evaluate.py:107-116 recomputes frames < t in every timeline) -----------------
+ * Temporal attention is causal and every other op is per-frame, so in the evaluator's timeline t the activations of
+ * the ground-truth frames < t equal those of ONE forward over the ground-truth clip ("clean pass"), and frame t
+ * itself only needs their temporal keys/values.  genie_clean_pass runs that forward and stores every layer's
+ * temporal qkv (L, B, T, S, 3d) f32 in `cache`; genie_masked_frames_logits then evaluates "frame t in timeline t"
+ * for ALL t at once: `frames` (B,T,S) holds, at frame t, the current tokens of timeline t's frame t (all-mask at
+ * MaskGIT step 0); frame i attends cached keys j < i and its own key.  logits: token-major (B,T,S,V).
+ * Same per-row arithmetic as the full forwards: (1 + steps*T/(T-1)... ) ~ 3 passes instead of 15*steps. */
+size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B);
+int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, float* cache,
+                     size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* w, const int64_t* frames, int B,
+                               const float* cache, size_t cache_bytes, float* logits, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* Factored cross-entropy + accuracy partial sums from token-major or BCTHW logits of frames [t0,t1)
  * (st_mask_git.py:231-253; eval_utils.py:44-77).
  *   targets (B,T,S) int64 (full clip; frames [t0,t1) are read)

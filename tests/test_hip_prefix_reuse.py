@@ -1,0 +1,67 @@
+"""Teacher-forced prefix reuse (genie_clean_pass + genie_masked_frames_logits): same outputs as the reference's
+15 x maskgit_steps full forwards -- ids bit-exact, CE within 1e-4 of the reference goldens.  Needs a GPU: -m gpu."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def make_ev(golden, name, precision, steps=2):
+    z, cfg, sd = golden(name)
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+    H = W = math.isqrt(cfg.S)
+    args = SimpleNamespace(maskgit_steps=steps, temperature=0, latent_h=H, latent_w=W)
+    return z, cfg, pkg("evaluate").GenieEvaluator(args, None, "cuda", model=m)
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_qknorm", "tiny_mup", "tiny_qknorm_mup"])
+def test_reuse_matches_reference_tiny(golden, name, precision):
+    z, cfg, ev = make_ev(golden, name, precision)
+    samples, fl = ev.predict_zframe_logits_reuse(dev(z["ids"]), noise=dev(z["ev_noise"]))
+    assert np.array_equal(samples.cpu().numpy(), z["ev_samples"])
+    assert np.abs(fl.cpu().numpy() - z["ev_logits"]).max() < 1e-4
+    sums = ev.evaluate_metric_sums_reuse(dev(z["ids"]), noise=dev(z["ev_noise"])).tolist()
+    assert abs(sums[0] / sums[1] - float(z["ev_loss"])) < 1e-4
+    assert abs(sums[2] / sums[3] - float(z["ev_acc"])) < 1e-7
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+@pytest.mark.parametrize("name", ["shape_dh32", "shape_dh64"])
+def test_reuse_matches_reference_real_geometry(golden, name, precision):
+    z, cfg, ev = make_ev(golden, name, precision)
+    ids = dev(z["ids"])
+    sums = ev.evaluate_metric_sums_reuse(ids, noise=dev(z["ev_noise"])).tolist()
+    assert abs(sums[0] / sums[1] - float(z["ev_loss"])) < 1e-4
+    assert abs(sums[2] / sums[3] - float(z["ev_acc"])) < 1e-7
+    samples, _ = ev.predict_zframe_logits_reuse(ids, noise=dev(z["ev_noise"]), return_logits=False)
+    assert np.array_equal(samples.cpu().numpy(), z["ev_samples"])
+
+
+@pytest.mark.parametrize("steps", [1, 3, 8])
+def test_reuse_equals_full_forward_path(golden, steps):
+    """Against this library's own full-forward evaluator on a batch of clips, several step counts, qk-norm geometry."""
+    z, cfg, ev = make_ev(golden, "shape_dh64_qknorm", "exact", steps)
+    ids = dev(pkg("synthetic").make_clips(3, cfg, seed=11))
+    noise = torch.rand(cfg.T - 1, max(steps - 1, 1), 3, cfg.S, device="cuda")
+    s_full, fl_full = ev.predict_zframe_logits(ids, noise=noise)
+    s_reuse, fl_reuse = ev.predict_zframe_logits_reuse(ids, noise=noise)
+    assert (fl_full - fl_reuse).abs().max().item() < 2e-5
+    mism = (s_full != s_reuse).float().mean().item()
+    assert mism < 2e-3  # identical up to top-2 logit gaps below the f32 accumulation-order noise (random clips)
+
+
+def test_reuse_bf16_close(golden):
+    z, cfg, ev = make_ev(golden, "shape_dh64", "bf16")
+    sums = ev.evaluate_metric_sums_reuse(dev(z["ids"]), noise=dev(z["ev_noise"])).tolist()
+    assert abs(sums[0] / sums[1] - float(z["ev_loss"])) < 5e-2
