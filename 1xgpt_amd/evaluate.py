@@ -188,7 +188,7 @@ class GenieEvaluator:
 
 @torch.no_grad()
 def evaluate_clips(evaluator: GenieEvaluator, clips: torch.LongTensor, batch_size=16, noise_seed=None,
-                   distributed=False):
+                   distributed=False, reuse=True):
     """Metric loop over ``clips`` (N, T*H*W) with the reference's AvgMetric weighting (eval_utils.py:16-25).
 
     With ``distributed=True`` every rank passes ITS shard of the clips; the six sums are all-reduced (SUM)
@@ -206,7 +206,8 @@ def evaluate_clips(evaluator: GenieEvaluator, clips: torch.LongTensor, batch_siz
             g = torch.Generator(device="cpu").manual_seed(noise_seed + i)
             noise = torch.rand(m.config.T - 1, evaluator.args.maskgit_steps - 1, batch.shape[0], m.config.S,
                                generator=g).to(dev)
-        total += evaluator.evaluate_metric_sums(batch, noise=noise)
+        fn = evaluator.evaluate_metric_sums_reuse if reuse else evaluator.evaluate_metric_sums
+        total += fn(batch, noise=noise)
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     if distributed:
