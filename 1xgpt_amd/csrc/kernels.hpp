@@ -54,6 +54,9 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
                                   const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
                                   size_t plane = 0);
+int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
+                              const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
+                              size_t plane = 0);
 int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
                                 int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
                                 uint16_t* out16 = nullptr, size_t plane = 0);

@@ -1,0 +1,254 @@
+// Spatial attention on the f16 matrix cores with split operands (the attention counterpart of gemm16<2>):
+// every matmul operand x is carried as hi + lo/2048 (two f16), each product as hi.hi + (hi.lo + lo.hi)/2048
+// accumulated in f32 -> f32-class scores and outputs at 3 MFMAs of v_mfma_f32_32x32x16_f16 per algorithmic
+// MFMA, ~5x less matrix-pipe time than the f32-MFMA kernel (32x32x2 f32 at 64 cycles per K=2).
+//
+// One workgroup per (sequence of S = 256 tokens, head), 8 waves x 32 queries.
+//   LDS:  K  as [key][Dh] f16 hi/lo, rows XOR-swizzled like the GEMM tiles (A operand of S^T = K Q^T)
+//         V^T as [d][key] f16 hi/lo, pitch 520 B (B operand of O = P V needs key-contiguous columns)
+//   S^T = K Q^T "swapped" so a lane holds 128 scores of ITS query (softmax = in-lane + one cross-half shuffle);
+//   the normalised probabilities are split in registers and fed as the A operand of P V: slot s of MFMA m
+//   of key tile kt is key kt*32 + 4h + (s&3) + 8*(s>>2) + 16*m, and V^T is read in exactly that order.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_h(float a, _Float16& hi, _Float16& lo) {
+    _Float16 h = (_Float16)a;
+    float hf = (float)h;
+    if (fabsf(hf) < 6.103515625e-05f) { h = (_Float16)0.0f; hf = 0.0f; }
+    hi = h;
+    lo = (_Float16)((a - hf) * 2048.0f);
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 int d, float scale, const float* __restrict__ nw,
+                                                                 const float* __restrict__ nb,
+                                                                 uint16_t* __restrict__ out16, size_t plane) {
+    constexpr int S = 256, NKT = 8;
+    constexpr int ROWB = DH * 2, SPR = ROWB / 16, RPB = 256 / ROWB;  // K rows: bytes, 16-B slots, rows per 256 B
+    constexpr int K_PLANE = S * ROWB;                                 // bytes
+    constexpr int VT_PITCH = 520, VT_PLANE = DH * VT_PITCH;           // bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sKh = smem;
+    unsigned char* sKl = smem + K_PLANE;
+    unsigned char* sVh = smem + 2 * K_PLANE;
+    unsigned char* sVl = sVh + VT_PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long row0 = (long)blockIdx.x * S;
+    const int head = blockIdx.y;
+    const float* base = qkv + (size_t)row0 * 3 * d + head * DH;
+
+    // ---- stage K: two adjacent lanes per key row, DH/2 features each (qk-norm statistics span both)
+    {
+        const int rr = tid >> 1, half = tid & 1;
+        const float* kp = base + (size_t)rr * 3 * d + d + half * (DH / 2);
+        float kx[DH / 2];
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            float4 t = *reinterpret_cast<const float4*>(kp + 4 * c);
+            kx[4 * c] = t.x; kx[4 * c + 1] = t.y; kx[4 * c + 2] = t.z; kx[4 * c + 3] = t.w;
+        }
+        if (nw) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) s += kx[c];
+            s += __shfl_xor(s, 1);
+            const float mu = s / DH;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) { float t = kx[c] - mu; v += t * t; }
+            v += __shfl_xor(v, 1);
+            const float rs = 1.0f / sqrtf(v / DH + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) {
+                const int cc = half * (DH / 2) + c;
+                kx[c] = (kx[c] - mu) * rs * nw[cc] + nb[cc];
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < DH / 16; ++sl) {  // 8 features = one 16-byte slot
+            f16x8 vh, vl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { _Float16 a, b; split_h(kx[sl * 8 + j], a, b); vh[j] = a; vl[j] = b; }
+            const int slot = half * (DH / 16) + sl;
+            const int off = rr * ROWB + ((slot ^ ((rr / RPB) % SPR)) << 4);
+            *reinterpret_cast<f16x8*>(sKh + off) = vh;
+            *reinterpret_cast<f16x8*>(sKl + off) = vl;
+        }
+    }
+    // ---- stage V^T: task = (key pair, 8-feature chunk); consecutive lanes write consecutive 4-byte words
+    for (int task = tid; task < (S / 2) * (DH / 8); task += 512) {
+        const int kp2 = task % (S / 2), dc = task / (S / 2);
+        const float* v0 = base + (size_t)(2 * kp2) * 3 * d + 2 * d + dc * 8;
+        const float* v1 = v0 + (size_t)3 * d;
+        float a[8], b[8];
+        *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(v0);
+        *reinterpret_cast<float4*>(a + 4) = *reinterpret_cast<const float4*>(v0 + 4);
+        *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(v1);
+        *reinterpret_cast<float4*>(b + 4) = *reinterpret_cast<const float4*>(v1 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 ah, al, bh, bl;
+            split_h(a[j], ah, al);
+            split_h(b[j], bh, bl);
+            const int off = (dc * 8 + j) * VT_PITCH + kp2 * 4;
+            uint32_t wh = (uint32_t)__builtin_bit_cast(uint16_t, ah) | ((uint32_t)__builtin_bit_cast(uint16_t, bh) << 16);
+            uint32_t wl = (uint32_t)__builtin_bit_cast(uint16_t, al) | ((uint32_t)__builtin_bit_cast(uint16_t, bl) << 16);
+            *reinterpret_cast<uint32_t*>(sVh + off) = wh;
+            *reinterpret_cast<uint32_t*>(sVl + off) = wl;
+        }
+    }
+    __syncthreads();
+
+    const int qb = wid;  // 8 waves x 32 queries = 256
+    // ---- Q fragments: lane (r,h) holds Q[r][16kk + 8h + j], split, scale folded in before the split
+    f16x8 qh[DH / 16], ql[DH / 16];
+    {
+        float qf[DH / 2];
+        const float* qp = base + (size_t)(qb * 32 + r) * 3 * d + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < DH / 16; ++kk) {
+            float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * kk);
+            float4 t1 = *reinterpret_cast<const float4*>(qp + 16 * kk + 4);
+            qf[8 * kk] = t0.x; qf[8 * kk + 1] = t0.y; qf[8 * kk + 2] = t0.z; qf[8 * kk + 3] = t0.w;
+            qf[8 * kk + 4] = t1.x; qf[8 * kk + 5] = t1.y; qf[8 * kk + 6] = t1.z; qf[8 * kk + 7] = t1.w;
+        }
+        if (nw) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) s += qf[c];
+            s += __shfl_xor(s, 32);
+            const float mu = s / DH;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) { float t = qf[c] - mu; v += t * t; }
+            v += __shfl_xor(v, 32);
+            const float rs = 1.0f / sqrtf(v / DH + 1e-5f);
+#pragma unroll
+            for (int kk = 0; kk < DH / 16; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int cc = 16 * kk + 8 * h + j;
+                    qf[8 * kk + j] = (qf[8 * kk + j] - mu) * rs * nw[cc] + nb[cc];
+                }
+        }
+#pragma unroll
+        for (int kk = 0; kk < DH / 16; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 a, b;
+                split_h(qf[8 * kk + j] * scale, a, b);  // q *= scale (attention.py:48)
+                qh[kk][j] = a; ql[kk][j] = b;
+            }
+    }
+    // ---- S^T tiles: sc[kt][e] = score(key kt*32 + (e&3) + 8(e>>2) + 4h, query r)
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 a0, c0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a0[e] = 0.f; c0[e] = 0.f; }
+        const int rowk = kt * 32 + r;
+#pragma unroll
+        for (int kk = 0; kk < DH / 16; ++kk) {
+            const int off = rowk * ROWB + (((2 * kk + h) ^ ((rowk / RPB) % SPR)) << 4);
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(sKh + off);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(sKl + off);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kk], a0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kk], c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kk], c0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[kt][e] = a0[e] + c0[e] * (1.0f / 2048.0f);
+    }
+    // ---- softmax over the 256 keys of query r (128 here, 128 in lane r^32)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[kt][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sc[kt][e] = expf(sc[kt][e] - mx); sum += sc[kt][e]; }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    // ---- O = P V
+    f32x16 oa[DH / 32], oc[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oa[dt][e] = 0.f; oc[dt][e] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f16x8 ph, pl;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                _Float16 a, b;
+                split_h(sc[kt][8 * m + s8] * inv, a, b);
+                ph[s8] = a; pl[s8] = b;
+            }
+            const int key0 = kt * 32 + 4 * h + 16 * m;  // slots 0..3 -> key0 + 0..3, slots 4..7 -> key0 + 8..11
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt) {
+                const int off = (dt * 32 + r) * VT_PITCH + key0 * 2;
+                f16x8 vh, vl;
+                const f16x4 h0 = *reinterpret_cast<const f16x4*>(sVh + off);
+                const f16x4 h1 = *reinterpret_cast<const f16x4*>(sVh + off + 16);
+                const f16x4 l0 = *reinterpret_cast<const f16x4*>(sVl + off);
+                const f16x4 l1 = *reinterpret_cast<const f16x4*>(sVl + off + 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vh[j] = h0[j]; vh[4 + j] = h1[j]; vl[j] = l0[j]; vl[4 + j] = l1[j]; }
+                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, oa[dt], 0, 0, 0);
+                oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[dt], 0, 0, 0);
+                oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[dt], 0, 0, 0);
+            }
+        }
+    // ---- store: row = query (e&3) + 8(e>>2) + 4h, col = feature r
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const size_t oi = (size_t)(row0 + q) * d + head * DH + dt * 32 + r;
+            const float v = oa[dt][e] + oc[dt][e] * (1.0f / 2048.0f);
+            if (!out16) out[oi] = v;
+            else if (plane) { uint16_t hi, lo; split_f16(v, hi, lo); out16[oi] = hi; out16[plane + oi] = lo; }
+            else out16[oi] = f32_to_bf16(v);
+        }
+}
+
+// Same contract as launch_attn_spatial_f32_mfma (f32 qkv in; f32 / split-f16 / bf16 out); S = 256 only.
+int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
+                              const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
+    if (S != 256 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
+    const size_t lds = (size_t)2 * 256 * Dh * 2 + (size_t)2 * Dh * 520;
+    dim3 grid((unsigned)n_seq, H);
+    ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * Dh * H * (double)n_seq, (double)n_seq * S * H * Dh * 16.0, st);
+    if (Dh == 64) {
+        (void)hipFuncSetAttribute((const void*)attn_spatial_split_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attn_spatial_split_kernel<64><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane);
+    } else {
+        (void)hipFuncSetAttribute((const void*)attn_spatial_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attn_spatial_split_kernel<32><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane);
+    }
+    GENIE_LAUNCH_CHECK("attn_spatial_split");
+    return GENIE_OK;
+}
+
+}  // namespace genie

@@ -454,8 +454,8 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     }
     GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.spatial.qkv_w16, d, 0, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv, nullptr,
                                0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
-    int rc = launch_attn_spatial_f32_mfma(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
-                                          nbs, st, xn16, 0);
+    int rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
+                                       nbs, st, xn16, 0);
     if (rc == GENIE_E_UNSUPPORTED) {
         GENIE_TRY(launch_attn_generic(qkv, w.logits, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
                                       c.attn_scale, 0, nws, nbs, st));
@@ -553,8 +553,8 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     }
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.spatial.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
-    int rc = launch_attn_spatial_f32_mfma(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
-                                          nbs, st, as, pd);
+    int rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
+                                       nbs, st, as, pd);
     if (rc == GENIE_E_UNSUPPORTED) {  // generic kernel writes f32 into x-sized scratch (logits region), then split
         float* tmp = w.logits;
         GENIE_TRY(launch_attn_generic(qkv, tmp, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
