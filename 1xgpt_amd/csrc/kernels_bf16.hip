@@ -9,6 +9,8 @@
 // a tile is lane-linear (that is what global_load_lds writes), so bank conflicts of the 16-byte fragment
 // reads are removed by an XOR swizzle applied on the SOURCE address (which 16-byte slot of its row a lane
 // fetches) and mirrored on the fragment read:  phys_slot = slot ^ ((row / rows_per_256B) % slots_per_row).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
 //   * XCD-aware block order: the 8 m-tiles of a group go to the 8 XCDs and each XCD walks the n-tiles of ITS
 //     m-tile, so the big operand (A) is fetched into one L2 only; W (<= 2 MB) is resident in every L2.
 // ------------------------------------------------------------------------------------------------
-template <int NPL, int BK>
-__global__ __launch_bounds__(512, 1) void gemm16_v2_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
+template <int NPL, int BK, int NWN>
+__global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
                                                            const uint16_t* __restrict__ W, long ldw, long planeW,
                                                            const float* __restrict__ bias, float* __restrict__ Cf,
                                                            uint16_t* __restrict__ C16, long plane16, long ldc, int M,
@@ -201,15 +203,18 @@ __global__ __launch_bounds__(512, 1) void gemm16_v2_kernel(const uint16_t* __res
     constexpr int ROWB = BK * 2, SPR = ROWB / 16, RPB = 256 / ROWB;
     constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB;
     constexpr int STAGE_B = NPL * (A_TILE + W_TILE);       // 48 KB
+    constexpr int NW = 4 * NWN;                             // waves per block: 4 (M) x NWN (N)
+    constexpr int NJ = BN / NWN / 32;                       // 32-wide MFMA tiles per wave along N
+    constexpr int WN_COLS = BN / NWN;                       // columns per wave
     constexpr int NCH = STAGE_B / 1024;                     // 1 KB chunks per stage (48)
-    constexpr int CPW = NCH / 8;                            // per wave (6)
+    constexpr int CPW = NCH / NW;                           // per wave (6 or 3)
     constexpr int CHUNK_ROWS = 1024 / ROWB;
-    static_assert(STAGE_B == 48 * 1024 && CPW * 8 == NCH, "stage geometry");
+    static_assert(STAGE_B == 48 * 1024 && CPW * NW == NCH, "stage geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / NWN, wn = wid % NWN;
     const int r = lane & 31, h = lane >> 5;
 
     // XCD-aware tile order (see header)
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_v2_kernel(const uint16_t* __res
     int ldsoff[CPW];
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
-        const int c = wid + 8 * i;
+        const int c = wid + NW * i;
         int off = c * 1024;
         const bool isA = off < NPL * A_TILE;
         if (!isA) off -= NPL * A_TILE;
@@ -261,19 +266,21 @@ __global__ __launch_bounds__(512, 1) void gemm16_v2_kernel(const uint16_t* __res
                                              16, 0, 0);
     };
 
-    f32x16 acc[2][2], corr[NPL == 2 ? 2 : 1][NPL == 2 ? 2 : 1];
+    f32x16 acc[2][NJ], corr[NPL == 2 ? 2 : 1][NPL == 2 ? NJ : 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 acc[i][j][e] = 0.f;
                 if constexpr (NPL == 2) corr[i][j][e] = 0.f;
             }
-    int rowA[2], rowB[2];
+    int rowA[2], rowB[NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { rowA[i] = wm * 64 + i * 32 + r; rowB[i] = wn * 64 + i * 32 + r; }
+    for (int i = 0; i < 2; ++i) rowA[i] = wm * 64 + i * 32 + r;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rowB[j] = wn * WN_COLS + j * 32 + r;
     auto frag_off = [&](int row_local, int kk) {
         const int slot = 2 * kk + h;
         return row_local * ROWB + ((slot ^ ((row_local / RPB) % SPR)) << 4);
@@ -293,34 +300,44 @@ __global__ __launch_bounds__(512, 1) void gemm16_v2_kernel(const uint16_t* __res
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             if constexpr (NPL == 1) {
-                bf16x8 a[2], b[2];
+                bf16x8 a[2], b[NJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[i] = *reinterpret_cast<const bf16x8*>(sa + frag_off(rowA[i], kk));
-                    b[i] = *reinterpret_cast<const bf16x8*>(sw + frag_off(rowB[i], kk));
-                }
+                for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + frag_off(rowA[i], kk));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sw + frag_off(rowB[j], kk));
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             } else {
-                f16x8 ah[2], al[2], bh[2], bl[2];
+                f16x8 ah[2], al[2], bh[NJ], bl[NJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     ah[i] = *reinterpret_cast<const f16x8*>(sa + frag_off(rowA[i], kk));
                     al[i] = *reinterpret_cast<const f16x8*>(sa + A_TILE + frag_off(rowA[i], kk));
-                    bh[i] = *reinterpret_cast<const f16x8*>(sw + frag_off(rowB[i], kk));
-                    bl[i] = *reinterpret_cast<const f16x8*>(sw + W_TILE + frag_off(rowB[i], kk));
                 }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8*>(sw + frag_off(rowB[j], kk));
+                    bl[j] = *reinterpret_cast<const f16x8*>(sw + W_TILE + frag_off(rowB[j], kk));
+                }
+                // three sweeps over the tiles so that no accumulator is touched by two consecutive MFMAs
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
                         corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], corr[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
                         corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], corr[i][j], 0, 0, 0);
-                    }
             }
         }
     }
@@ -331,28 +348,30 @@ __global__ __launch_bounds__(512, 1) void gemm16_v2_kernel(const uint16_t* __res
     // whole rows: 16 lanes x float4 = one 256-byte row segment per quarter-wave for the residual read, the f32
     // store and the 16-bit operand store.
     __syncthreads();  // every wave is done with the stage buffers (and has drained its loads)
-    float* ct = reinterpret_cast<float*>(smem) + wid * (64 * 64);
+    float* ct = reinterpret_cast<float*>(smem) + wid * (64 * WN_COLS);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][j][e];
                 if constexpr (NPL == 2) v += corr[i][j][e] * SPLIT_INV;
-                ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = v;
+                ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * WN_COLS + j * 32 + r] = v;
             }
     const bool do_gelu = flags & G16_GELU, do_acc = flags & G16_ACCUM;
     const bool out16 = flags & G16_OUT16, outf = flags & G16_OUTF32;
-    const int c4 = (lane & 15) << 2;
-    const int col = n0 + wn * 64 + c4;
+    constexpr int LPR = WN_COLS / 4;  // lanes per row (float4 each)
+    constexpr int RPI = 64 / LPR;     // rows per wave-instruction
+    const int c4 = (lane % LPR) << 2;
+    const int col = n0 + wn * WN_COLS + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias && col < N) bv = *reinterpret_cast<const float4*>(bias + col);
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int rl = it * 4 + (lane >> 4);
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const int rl = it * RPI + lane / LPR;
         const int row = m0 + wm * 64 + rl;
-        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+        float4 v = *reinterpret_cast<const float4*>(ct + rl * WN_COLS + c4);
         if (row >= M || col >= N) continue;
         v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
         if (do_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
@@ -399,11 +418,18 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
                            mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) +
                                  (flags & G16_OUT16 ? 2 * NPL : 0)),
                        st);
-        (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds2);
-        gemm16_v2_kernel<NPL, BK><<<dim3(mt2 * nt2, batch), 512, lds2, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf,
-                                                                              C16, plane16, ldc, M, N, K, flags,
-                                                                              alpha, strideA, strideC);
+        static const int nwn = [] { const char* e = getenv("GENIE_GEMM16_NWN"); return e ? atoi(e) : (NPL == 2 ? 4 : 2); }();
+        if (nwn == 4) {
+            (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK, 4>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            gemm16_v2_kernel<NPL, BK, 4><<<dim3(mt2 * nt2, batch), 1024, lds2, st>>>(
+                A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK, 2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            gemm16_v2_kernel<NPL, BK, 2><<<dim3(mt2 * nt2, batch), 512, lds2, st>>>(
+                A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC);
+        }
         GENIE_LAUNCH_CHECK("gemm16_v2");
         return GENIE_OK;
     }

@@ -63,6 +63,53 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
+    OutT* yr = y + (size_t)row * C;
+    if ((C & 3) == 0) {  // float4 path: 16 B per lane per access, 8 B / 2x8 B packed 16-bit stores
+        float4 v[8];     // C <= 2048
+        const int n4 = C >> 2;
+        int n = 0;
+        float s = 0.f;
+        for (int c = lane; c < n4; c += 64) {
+            v[n] = *reinterpret_cast<const float4*>(xr + 4 * c);
+            s += (v[n].x + v[n].y) + (v[n].z + v[n].w);
+            ++n;
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+        for (int k = 0; k < n; ++k) {
+            const float a0 = v[k].x - mean, a1 = v[k].y - mean, a2 = v[k].z - mean, a3 = v[k].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        n = 0;
+        for (int c = lane; c < n4; c += 64) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + 4 * c);
+            const float4 bb = *reinterpret_cast<const float4*>(b + 4 * c);
+            float4 o;
+            o.x = (v[n].x - mean) * rstd * gg.x + bb.x;
+            o.y = (v[n].y - mean) * rstd * gg.y + bb.y;
+            o.z = (v[n].z - mean) * rstd * gg.z + bb.z;
+            o.w = (v[n].w - mean) * rstd * gg.w + bb.w;
+            if constexpr (SPLIT) {
+                uint16_t h0, l0, h1, l1, h2, l2, h3, l3;
+                split_f16(o.x, h0, l0); split_f16(o.y, h1, l1); split_f16(o.z, h2, l2); split_f16(o.w, h3, l3);
+                uint2 ph, pl;
+                ph.x = (uint32_t)h0 | ((uint32_t)h1 << 16); ph.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                pl.x = (uint32_t)l0 | ((uint32_t)l1 << 16); pl.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
+                *reinterpret_cast<uint2*>(yr + 4 * c) = ph;
+                *reinterpret_cast<uint2*>(yr + plane + 4 * c) = pl;
+            } else if constexpr (sizeof(OutT) == 2) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+                *reinterpret_cast<uint2*>(yr + 4 * c) = pk;
+            } else {
+                *reinterpret_cast<float4*>(yr + 4 * c) = o;
+            }
+            ++n;
+        }
+        return;
+    }
     float v[32];  // C <= 2048
     int n = 0;
     float s = 0.f;
@@ -71,7 +118,6 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     float q = 0.f;
     for (int k = 0; k < n; ++k) { float t = v[k] - mean; q += t * t; }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-    OutT* yr = y + (size_t)row * C;
     n = 0;
     for (int c = lane; c < C; c += 64) {
         float o = (v[n] - mean) * rstd * g[c] + b[c];
@@ -954,6 +1000,32 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// NV (2 or 4) contiguous outputs of one row: f32, bf16 (plane == 0) or split-f16 planes
+template <int NV>
+__device__ __forceinline__ void store_row_chunk(float* out, uint16_t* out16, size_t plane, size_t oi, const float* v) {
+    if (!out16) {
+        if constexpr (NV == 4) *reinterpret_cast<float4*>(out + oi) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<float2*>(out + oi) = make_float2(v[0], v[1]);
+    } else if (plane) {
+        uint16_t hi[NV], lo[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) split_f16(v[c], hi[c], lo[c]);
+        if constexpr (NV == 4) {
+            *reinterpret_cast<uint2*>(out16 + oi) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+            *reinterpret_cast<uint2*>(out16 + plane + oi) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+        } else {
+            *reinterpret_cast<uint32_t*>(out16 + oi) = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+            *reinterpret_cast<uint32_t*>(out16 + plane + oi) = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+        }
+    } else {
+        if constexpr (NV == 4)
+            *reinterpret_cast<uint2*>(out16 + oi) = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                                                               (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+        else
+            *reinterpret_cast<uint32_t*>(out16 + oi) = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    }
+}
+
 template <int DH>
 __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float* __restrict__ qkv,
                                                                      float* __restrict__ out, long n_bs, int S,
@@ -1018,23 +1090,37 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    // O = P V
-    const float* vp = base + 2 * d + (size_t)(4 * g) * tok_stride + r;
-    const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + r;
+    // O = P V.  Feature permutation: MFMA column r of "d-tile" c is feature NV*r + c, so a lane fetches NV
+    // CONTIGUOUS features of V[4g+e] (16 lanes = one 4*DH-byte row segment) and later stores NV contiguous outputs.
+    constexpr int NV = DH / 16;
+    const float* vp = base + 2 * d + (size_t)(4 * g) * tok_stride + NV * r;
+    float vv[4][NV];
 #pragma unroll
-    for (int dt = 0; dt < DH / 16; ++dt) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[e] * inv, vp[(size_t)e * tok_stride + dt * 16], o, 0, 0, 0);
-        // C/D map of the 16x16 MFMA: col = lane&15 (feature), row = 4*(lane>>4) + e (query frame)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const size_t oi = obase + (size_t)(4 * g + e) * S * d + dt * 16;
-            if (!out16) out[oi] = o[e];
-            else if (plane) { uint16_t hi, lo; split_f16(o[e], hi, lo); out16[oi] = hi; out16[plane + oi] = lo; }
-            else out16[oi] = f32_to_bf16(o[e]);
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (NV == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(vp + (size_t)e * tok_stride);
+            vv[e][0] = t.x; vv[e][1] = t.y; vv[e][2] = t.z; vv[e][3] = t.w;
+        } else {
+            const float2 t = *reinterpret_cast<const float2*>(vp + (size_t)e * tok_stride);
+            vv[e][0] = t.x; vv[e][1] = t.y;
         }
+    }
+    f32x4 o[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[e] * inv, vv[e][c], o[c], 0, 0, 0);
+    }
+    // C/D map: col = lane&15 (-> features NV*r..NV*r+NV-1 over c), row = 4*(lane>>4) + e (query frame)
+    const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + NV * r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t oi = obase + (size_t)(4 * g + e) * S * d;
+        float ov[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) ov[c] = o[c][e];
+        store_row_chunk<NV>(out, out16, plane, oi, ov);
     }
 }
 
@@ -1184,26 +1270,41 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     const float pd = expf(dg - mx);
     const float inv = 1.0f / (sum + pd);
     const float pdn = pd * inv;  // weight of the query's own (current) frame, held by every lane with r == i
-    const float* vcp = cache + off0 + 2 * d + (size_t)(4 * g) * tok_stride + r;
-    const float* vp = cur + off0 + 2 * d + (size_t)(4 * g) * tok_stride + r;
-    const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + r;
+    constexpr int NV = DH / 16;  // feature permutation as in attn_temporal_f32_mfma_kernel
+    const float* vcp = cache + off0 + 2 * d + (size_t)(4 * g) * tok_stride + NV * r;
+    const float* vp = cur + off0 + 2 * d + (size_t)(4 * g) * tok_stride + NV * r;
+    float vc[4][NV], vs[4][NV];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (NV == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(vcp + (size_t)e * tok_stride);
+            const float4 u = *reinterpret_cast<const float4*>(vp + (size_t)e * tok_stride);
+            vc[e][0] = t.x; vc[e][1] = t.y; vc[e][2] = t.z; vc[e][3] = t.w;
+            vs[e][0] = u.x; vs[e][1] = u.y; vs[e][2] = u.z; vs[e][3] = u.w;
+        } else {
+            const float2 t = *reinterpret_cast<const float2*>(vcp + (size_t)e * tok_stride);
+            const float2 u = *reinterpret_cast<const float2*>(vp + (size_t)e * tok_stride);
+            vc[e][0] = t.x; vc[e][1] = t.y; vs[e][0] = u.x; vs[e][1] = u.y;
+        }
+    }
     float pself[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) pself[e] = __shfl(pdn, 4 * g + e);  // lane index 4g+e has r = 4g+e
+    f32x4 o[NV];
 #pragma unroll
-    for (int dt = 0; dt < DH / 16; ++dt) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NV; ++c) {
+        o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[e] * inv, vcp[(size_t)e * tok_stride + dt * 16], o, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) o[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[e] * inv, vc[e][c], o[c], 0, 0, 0);
+    }
+    const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + NV * r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = fmaf(pself[e], vp[(size_t)e * tok_stride + dt * 16], o[e]);
-            const size_t oi = obase + (size_t)(4 * g + e) * S * d + dt * 16;
-            if (!out16) out[oi] = v;
-            else if (plane) { uint16_t hi, lo; split_f16(v, hi, lo); out16[oi] = hi; out16[plane + oi] = lo; }
-            else out16[oi] = f32_to_bf16(v);
-        }
+    for (int e = 0; e < 4; ++e) {
+        const size_t oi = obase + (size_t)(4 * g + e) * S * d;
+        float ov[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) ov[c] = fmaf(pself[e], vs[e][c], o[c][e]);
+        store_row_chunk<NV>(out, out16, plane, oi, ov);
     }
 }
 
