@@ -63,6 +63,9 @@ static Workspace carve(const genie_cfg& c, int B, void* base) {
     w.total = off;
     w.tqkv = nullptr;
     w.tcache = nullptr;
+    w.fcache = nullptr;
+    w.frame_t = -1;
+    w.frame_T = 0;
     return w;
 }
 
@@ -106,10 +109,19 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
     const int d = c.d_model, M = B * c.T * c.S;
     float* qkv = (temporal && w.tqkv) ? w.tqkv : (float*)w.big;
     float* ao = (float*)w.xn;  // u may alias w.xn: it is dead once qkv is computed
-    GENIE_TRY(launch_gemm_f32(u, d, 0, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, qkv, 3 * d, 0, M, 3 * d, d, 1,
-                              0, 1.0f, st));
     const float* nw = c.qk_norm ? aw.norm_w : nullptr;
     const float* nb = c.qk_norm ? aw.norm_b : nullptr;
+    if (temporal && w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
+        float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
+        GENIE_TRY(launch_gemm_f32(u, d, (long)c.S * d, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, slot, 3 * d,
+                                  (long)w.frame_T * c.S * 3 * d, c.S, 3 * d, d, B, 0, 1.0f, st));
+        GENIE_TRY(launch_attn_temporal_single(w.fcache, ao, B, w.frame_T, c.S, w.frame_t, d, c.num_heads, c.head_dim,
+                                              c.attn_scale, nw, nb, st));
+        return launch_gemm_f32(ao, d, 0, aw.proj_w, d, 0, c.proj_bias ? aw.proj_b : nullptr, x, d, 0, M, d, d, 1,
+                               GEMM_ACCUM, 1.0f, st);
+    }
+    GENIE_TRY(launch_gemm_f32(u, d, 0, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, qkv, 3 * d, 0, M, 3 * d, d, 1,
+                              0, 1.0f, st));
     if (!temporal) {
         int rc = launch_attn_spatial_f32_mfma(qkv, ao, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale,
                                               nw, nb, st);
@@ -390,6 +402,33 @@ int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* wt, co
     hipStream_t st = as_stream(stream);
     GENIE_TRY(prefix_forward(*cfg, *wt, frames, B, const_cast<float*>(cache), false, w, st));
     return readout(*cfg, *wt, w.x, w, B, 0, cfg->T, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
+}
+
+int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frame_ids, int B, int t, float* cache,
+                     size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(wt && wt->layers_host && frame_ids && cache, "frame_pass: NULL pointer");
+    GENIE_CHECK_ARG(t >= 0 && t < cfg->T, "frame_pass: frame %d out of range", t);
+    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "frame_pass: cache too small");
+    GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
+    genie_cfg c1 = *cfg;
+    c1.T = 1;  // every buffer of this pass is a dense (B, 1, S, *) tensor
+    Workspace w = carve(c1, B, workspace);
+    hipStream_t st = as_stream(stream);
+    genie_weights w1 = *wt;
+    w1.pos_embed = wt->pos_embed + (size_t)t * cfg->S * cfg->d_model;  // pos_embed_TSC[0, t]
+    GENIE_TRY(launch_embed(c1, w1, frame_ids, B, w.x, st));
+    if (c1.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c1, w.x, w, B, st));
+    if (c1.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c1, w.x, w, B, st));
+    const size_t per_layer = (size_t)B * cfg->T * cfg->S * 3 * cfg->d_model;
+    for (int i = 0; i < c1.num_layers; ++i) {
+        w.fcache = cache + i * per_layer;
+        w.frame_t = t;
+        w.frame_T = cfg->T;
+        GENIE_TRY(st_block(c1, wt->layers_host[i], w.x, w, B, st));
+    }
+    if (!logits) return GENIE_OK;
+    return readout(c1, *wt, w.x, w, B, 0, 1, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
 }
 
 int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, const int64_t* targets,

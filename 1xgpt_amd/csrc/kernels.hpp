@@ -21,6 +21,12 @@ struct Workspace {
     // teacher-forced prefix reuse (set per layer by the prefix entry points, NULL otherwise):
     float* tqkv;         // where the temporal qkv GEMM writes (clean pass: this layer's slice of the cache)
     const float* tcache; // non-NULL: temporal attention takes keys j < i from this cached qkv (masked-frames pass)
+    // single-frame decode (generate with a temporal KV cache): the block runs on ONE frame (cfg.T == 1, dense
+    // (B,S,*) buffers); its temporal qkv is written into slot `frame_t` of this layer's cache slice and the
+    // attention reads slots 0..frame_t.
+    float* fcache;
+    int frame_t;   // -1 = off
+    int frame_T;   // frames per clip in the cache layout
 };
 
 // Brackets one launch with HIP events when profiling of `cls` is enabled (see genie_profile_* in the ABI).
@@ -57,6 +63,9 @@ int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, in
 int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
                               const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
                               size_t plane = 0);
+int launch_attn_temporal_single(const float* cache, float* out, int B, int T, int S, int t, int d, int H, int Dh,
+                                float scale, const float* nw, const float* nb, hipStream_t st,
+                                uint16_t* out16 = nullptr, size_t plane = 0);
 int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
                                 int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
                                 uint16_t* out16 = nullptr, size_t plane = 0);

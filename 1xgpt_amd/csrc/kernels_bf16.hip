@@ -148,39 +148,72 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
                         corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], corr[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
                         corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], corr[i][j], 0, 0, 0);
-                    }
             }
         }
         __syncthreads();  // drains this wave's global_load_lds (vmcnt) and orders the buffer swap
     }
 
-    const bool do_gelu = flags & G16_GELU, do_acc = flags & G16_ACCUM;
-    const bool out16 = flags & G16_OUT16, outf = flags & G16_OUTF32;
+    // epilogue through LDS (see gemm16_v2_kernel): 4 waves x 16 KB = the 64 KB ring
+    float* ct = reinterpret_cast<float*>(smem) + wid * (64 * 64);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + r;
-            if (col >= N) continue;
-            const float bcol = bias ? bias[col] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= M) continue;
                 float v = acc[i][j][e];
                 if constexpr (NPL == 2) v += corr[i][j][e] * SPLIT_INV;
-                v = v * alpha + bcol;
+                ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = v;
+            }
+    const bool do_gelu = flags & G16_GELU, do_acc = flags & G16_ACCUM;
+    const bool out16 = flags & G16_OUT16, outf = flags & G16_OUTF32;
+    const bool vec = ((N | (int)ldc) & 3) == 0;
+    const int c4 = (lane & 15) << 2;
+    const int col = n0 + wn * 64 + c4;
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + rl;
+        if (row >= M) continue;
+        float vv[4];
+        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+        if (vec && col + 3 < N) {
+            float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(vv[0] * alpha + bv.x, vv[1] * alpha + bv.y, vv[2] * alpha + bv.z, vv[3] * alpha + bv.w);
+            if (do_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            const size_t idx = (size_t)row * ldc + col;
+            if (do_acc) {
+                const float4 o = *reinterpret_cast<const float4*>(Cf + idx);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
+            if (out16) {
+                store16<NPL>(C16, (size_t)plane16, idx, v.x); store16<NPL>(C16, (size_t)plane16, idx + 1, v.y);
+                store16<NPL>(C16, (size_t)plane16, idx + 2, v.z); store16<NPL>(C16, (size_t)plane16, idx + 3, v.w);
+            }
+        } else {
+            for (int c = 0; c < 4; ++c) {
+                if (col + c >= N) break;
+                float v = vv[c] * alpha + (bias ? bias[col + c] : 0.f);
                 if (do_gelu) v = gelu_erf(v);
-                const size_t idx = (size_t)row * ldc + col;
+                const size_t idx = (size_t)row * ldc + col + c;
                 if (do_acc) v += Cf[idx];
                 if (outf) Cf[idx] = v;
                 if (out16) store16<NPL>(C16, (size_t)plane16, idx, v);
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,7 +443,8 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
     GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
     if (M <= 0 || N <= 0) return GENIE_OK;
     const double mn = (double)M * N * batch;
-    if (M >= 256 && N % 4 == 0 && ldc % 4 == 0) {
+    static const int force_v1 = [] { const char* e = getenv("GENIE_GEMM16_V1"); return e ? atoi(e) : 0; }();
+    if (!force_v1 && M >= 256 && N % 4 == 0 && ldc % 4 == 0) {
         const int mt2 = (M + 255) / 256, nt2 = (N + 127) / 128;
         const size_t lds2 = 3 * 48 * 1024;
         ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
@@ -492,6 +526,14 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
                                0, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
     // temporal (no pre-norm): operand = bf16 shadow of x
     float* tq = w.tqkv ? w.tqkv : qkv;
+    if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
+        float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
+        GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, slot,
+                                   nullptr, 0, 3 * d, c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.S * d,
+                                   (long)w.frame_T * c.S * 3 * d));
+        rc = launch_attn_temporal_single(w.fcache, nullptr, B, w.frame_T, c.S, w.frame_t, d, c.num_heads, c.head_dim,
+                                         c.attn_scale, nwt, nbt, st, xn16, 0);
+    } else {
     GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     if (w.tcache) {
@@ -510,6 +552,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
                                           c.head_dim, c.attn_scale, 1, nwt, nbt, st));
             rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
         }
+    }
     }
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.temporal.proj_w16, d, 0, c.proj_bias ? lw.temporal.proj_b : nullptr, x,
@@ -592,6 +635,14 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
                                xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
     // ---- temporal
     float* tq = w.tqkv ? w.tqkv : qkv;
+    if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
+        float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
+        GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr,
+                                   slot, nullptr, 0, 3 * d, c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.S * d,
+                                   (long)w.frame_T * c.S * 3 * d));
+        rc = launch_attn_temporal_single(w.fcache, nullptr, B, w.frame_T, c.S, w.frame_t, d, c.num_heads, c.head_dim,
+                                         c.attn_scale, nwt, nbt, st, as, pd);
+    } else {
     GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     if (w.tcache) {
@@ -611,6 +662,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
                                           c.head_dim, c.attn_scale, 1, nwt, nbt, st));
             rc = launch_split_f16(tmp, as, pd, pd, st);
         }
+    }
     }
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.temporal.proj_w16, d, pw_proj, c.proj_bias ? lw.temporal.proj_b : nullptr,

@@ -1399,4 +1399,73 @@ int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out
     return GENIE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Temporal attention of ONE query frame t against the cached qkv of frames 0..t (the frame's own qkv has just been
+// written into slot t): the decode step of the temporal KV cache used by generate().  One wavefront per
+// (b, s, head), lane = feature; T <= 64 scores live in registers of lane 0..t after wave reductions.
+// out: dense (B, S, d) f32 / bf16 / split-f16.
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* __restrict__ cache,
+                                                                   float* __restrict__ out, long n_items, int T, int S,
+                                                                   int t, int d, int H, float scale,
+                                                                   const float* __restrict__ nw,
+                                                                   const float* __restrict__ nb,
+                                                                   uint16_t* __restrict__ out16, size_t plane) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int head = (int)(item % H);
+    const long bs = item / H;
+    const long b = bs / S, s = bs - b * S;
+    const bool act = lane < DH;
+    const size_t tok_stride = (size_t)S * 3 * d;
+    const float* base = cache + ((size_t)(b * T) * S + s) * 3 * d + head * DH + (act ? lane : 0);
+    auto norm = [&](float v) {  // qk-norm over the DH active lanes
+        if (!nw) return v;
+        const float mu = wave_sum(act ? v : 0.f) / DH;
+        const float c = act ? v - mu : 0.f;
+        const float var = wave_sum(c * c) / DH;
+        return c * (1.0f / sqrtf(var + 1e-5f)) * nw[act ? lane : 0] + nb[act ? lane : 0];
+    };
+    float q = norm(base[(size_t)t * tok_stride]) * scale;
+    if (!act) q = 0.f;
+    float sc[64];
+    float mx = -INFINITY;
+    for (int j = 0; j <= t; ++j) {
+        const float kj = norm(base[(size_t)j * tok_stride + d]);
+        const float a = wave_sum(act ? q * kj : 0.f);
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+    for (int j = 0; j <= t; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+    const float inv = 1.0f / sum;
+    float o = 0.f;
+    for (int j = 0; j <= t; ++j) o = fmaf(sc[j] * inv, base[(size_t)j * tok_stride + 2 * d], o);
+    if (!act) return;
+    const size_t oi = (size_t)bs * d + head * DH + lane;
+    if (!out16) out[oi] = o;
+    else if (plane) { uint16_t hi, lo; split_f16(o, hi, lo); out16[oi] = hi; out16[plane + oi] = lo; }
+    else out16[oi] = f32_to_bf16(o);
+}
+
+int launch_attn_temporal_single(const float* cache, float* out, int B, int T, int S, int t, int d, int H, int Dh,
+                                float scale, const float* nw, const float* nb, hipStream_t st, uint16_t* out16,
+                                size_t plane) {
+    GENIE_CHECK_SHAPE(T <= 64 && t >= 0 && t < T, "temporal_single: bad frame %d of %d", t, T);
+    const long n = (long)B * S * H;
+    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * (t + 1) * Dh * (double)n, (double)n * Dh * 4.0 * (2 * t + 4), st);
+    const unsigned blocks = (unsigned)((n + 3) / 4);
+    switch (Dh) {
+        case 8: attn_temporal_single_kernel<8><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
+        case 16: attn_temporal_single_kernel<16><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
+        case 32: attn_temporal_single_kernel<32><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
+        case 64: attn_temporal_single_kernel<64><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
+        default: set_error("temporal_single: head_dim %d unsupported", Dh); return GENIE_E_SHAPE;
+    }
+    GENIE_LAUNCH_CHECK("attn_temporal_single");
+    return GENIE_OK;
+}
+
 }  // namespace genie

@@ -21,13 +21,21 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("GENIE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kwargs["device_id"] = torch.device("cuda", local_rank)
+            dev_index = local_device_index(local_rank)
+            torch.cuda.set_device(dev_index)
+            kwargs["device_id"] = torch.device("cuda", dev_index)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
+
+
+def local_device_index(local_rank: int) -> int:
+    """GPU of this rank: LOCAL_RANK, unless GENIE_FORCE_DEVICE pins every rank to one device (single-GPU smoke runs
+    of the multi-process path with the gloo backend)."""
+    forced = os.environ.get("GENIE_FORCE_DEVICE")
+    return int(forced) if forced is not None else local_rank
 
 
 def shard_range(n_items: int, rank: int, world: int):

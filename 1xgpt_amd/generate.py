@@ -42,6 +42,69 @@ def generate_frames(model, example_THW: torch.LongTensor, num_prompt_frames=8, m
     return torch.cat([outputs, example_THW[:, num_prompt_frames:]], dim=1)
 
 
+@torch.no_grad()
+def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_frames=8, maskgit_steps=2, temperature=0.0,
+                           teacher_force_time=False, noise=None, unmask_mode="random"):
+    """``generate_frames`` with a temporal KV cache (genie_frame_pass): every pass runs ONE frame through the stack
+    against the cached temporal keys/values of the earlier frames instead of the full 16-frame forward --
+    P + (T-P)*(steps+1) single-frame passes (= 2 full-pass equivalents at P=8, steps=2) instead of (T-P)*steps full
+    forwards (16).  Same outputs (per-row arithmetic is unchanged)."""
+    import math
+    from . import _lib
+    lib = _lib.load()
+    cfg, w = model._weights()[:2]
+    ex = example_THW.to(torch.int64).contiguous()
+    B, T = ex.shape[0], ex.shape[1]
+    S, V = model.config.S, model.config.factored_vocab_size * model.config.num_factored_vocabs
+    P = num_prompt_frames
+    assert P <= T and P >= 1
+    dev = ex.device
+    ids = ex.view(B, T, S)
+    ws = model._workspace(B)
+    nbytes = lib.genie_prefix_cache_bytes(cfg, B)
+    cache = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def frame_pass(tokens_BS, t, logits=None):
+        _lib.check(lib.genie_frame_pass(cfg, w, tokens_BS.data_ptr(), B, t, cache.data_ptr(), nbytes,
+                                        0 if logits is None else logits.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                   "genie_frame_pass")
+
+    for t in range(P):
+        frame_pass(ids[:, t].contiguous(), t)
+    logits = torch.empty(B, S, V, dtype=torch.float32, device=dev)
+    samples = torch.empty(B, S, dtype=torch.int64, device=dev)
+    conf = torch.empty(B, S, dtype=torch.float32, device=dev)
+    gen = []
+    for k, t in enumerate(range(P, T)):
+        cur = torch.full((B, S), model.mask_token_id, dtype=torch.int64, device=dev)
+        unmasked = torch.zeros(B, S, dtype=torch.uint8, device=dev)
+        for step in range(maskgit_steps):
+            frame_pass(cur, t, logits)
+            uni = torch.rand(model.config.num_factored_vocabs, B, S, device=dev) if temperature > 1e-8 else None
+            _lib.check(lib.genie_sample(cfg, logits.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, B, float(temperature),
+                                        0 if uni is None else uni.data_ptr(), samples.data_ptr(), conf.data_ptr(), st),
+                       "genie_sample")
+            last = step == maskgit_steps - 1
+            keys, n = None, 0
+            if not last:
+                n = math.ceil(math.cos((step + 1) / maskgit_steps * math.pi / 2) * S)
+                if unmask_mode == "greedy":
+                    keys = conf
+                elif noise is None:
+                    keys = torch.rand(B, S, device=dev)
+                else:
+                    keys = noise[k][step].to(dev).reshape(B, S).float().contiguous()
+            _lib.check(lib.genie_mask_step(0 if keys is None else keys.data_ptr(), n, int(last), model.mask_token_id,
+                                           unmasked.data_ptr(), samples.data_ptr(), cur.data_ptr(), S, B, S, st),
+                       "genie_mask_step")
+        gen.append(cur.view(B, model.h, model.w))
+        if t + 1 < T:  # commit frame t (its final tokens, or the ground truth when teacher-forcing in time)
+            frame_pass(ids[:, t].contiguous() if teacher_force_time else cur, t)
+    outputs = torch.cat([ex[:, :P], torch.stack(gen, dim=1)], dim=1)
+    return torch.cat([outputs, ex[:, P:]], dim=1)
+
+
 def write_outputs(outputs_THW: torch.LongTensor, output_dir, dataset_metadata: dict, args: dict):
     """video.bin (token_dtype of the source dataset) + metadata.json with the reference's extra keys
     (generate.py:105-116).  outputs for ONE example: (1, n, H, W) or (n, H, W)."""

@@ -90,8 +90,9 @@ def main():
     dist_mod = importlib.import_module("1xgpt_amd.distributed")
     rank, world, local_rank = dist_mod.init_distributed()
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = dist_mod.local_device_index(local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     cfgmod = importlib.import_module("1xgpt_amd.config")
     synth = importlib.import_module("1xgpt_amd.synthetic")

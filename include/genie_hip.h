@@ -182,6 +182,15 @@ int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* w, con
                                const float* cache, size_t cache_bytes, float* logits, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Temporal KV cache for autoregressive generation (generate.py:81-95 re-runs the full 16-frame forward for every
+ * MaskGIT step of every new frame): run ONE frame (frame_ids (B,S), frame index t) through the stack; each layer writes
+ * the frame's temporal qkv into slot t of `cache` (same layout as genie_clean_pass) and attends slots 0..t.  Calling
+ * it for t = 0..P-1 on the prompt frames fills the cache; for a new frame call it once per MaskGIT step on the current
+ * (partially masked) tokens to get `logits` (B,S,V) token-major (NULL = not wanted), and once more on the final tokens
+ * to commit them.  Same per-row arithmetic as the full forward restricted to frame t. */
+int genie_frame_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* frame_ids, int B, int t, float* cache,
+                     size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Factored cross-entropy + accuracy partial sums from token-major or BCTHW logits of frames [t0,t1)
  * (st_mask_git.py:231-253; eval_utils.py:44-77).
  *   targets (B,T,S) int64 (full clip; frames [t0,t1) are read)
