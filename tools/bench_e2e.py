@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: end-to-end MAGVIT2 encode -> GENIE sample -> MAGVIT2 decode on 256x256 RGB frames, everything
+resident in HBM (the reference round-trips tokens and frames through numpy / PIL, eval_utils.py:39-41).
+Synthetic frames and synthetic weights (no checkpoints offline)."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+
+def timed(fn, reps=2):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return out, (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clips", type=int, default=8)
+    ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--model", default="c138")
+    ap.add_argument("--steps", type=int, default=2)
+    a = ap.parse_args()
+    cfgmod = importlib.import_module("1xgpt_amd.config")
+    synth = importlib.import_module("1xgpt_amd.synthetic")
+    mv = importlib.import_module("1xgpt_amd.magvit2")
+    G = importlib.import_module("1xgpt_amd.generate")
+    STMaskGIT = importlib.import_module("1xgpt_amd.st_mask_git").STMaskGIT
+    cfg = cfgmod.c138() if a.model == "c138" else cfgmod.c35()
+    m = STMaskGIT(cfg, precision=a.precision).load_numpy_state_dict(synth.make_state_dict(cfg, seed=0)).to("cuda")
+    vq = mv.VQModel(mv.VQConfig())
+    vq.load_state_dict({k: torch.from_numpy(v) for k, v in mv.make_vq_state_dict(vq, seed=1).items()})
+    vq = vq.to(device="cuda", dtype=torch.bfloat16).eval()
+    B = a.clips
+    g = torch.Generator(device="cuda").manual_seed(0)
+    frames = torch.randint(0, 256, (B * 16, 3, 256, 256), dtype=torch.uint8, device="cuda", generator=g)
+
+    def encode():
+        return torch.cat([vq.encode_tokens(frames[i:i + 16]) for i in range(0, B * 16, 16)])
+
+    tokens, t_enc = timed(encode)
+    clips = tokens.view(B, 16, 16, 16)
+    noise = torch.rand(8, max(a.steps - 1, 1), B, cfg.S, device="cuda")
+    out, t_gen = timed(lambda: G.generate_frames_cached(m, clips, 8, a.steps, 0.0, False, noise=noise))
+    gen = out[:, 8:16].reshape(B * 8, 16, 16)
+
+    def decode():
+        return torch.cat([vq.decode_tokens(gen[i:i + 16]) for i in range(0, B * 8, 16)])
+
+    rgb, t_dec = timed(decode)
+    assert rgb.shape == (B * 8, 3, 256, 256) and rgb.dtype == torch.uint8 and rgb.is_cuda
+    total = t_enc + t_gen + t_dec
+    res = {"workload": f"encode {B}x16 frames -> sample 8 frames/clip ({a.steps} MaskGIT steps, KV cache, {a.precision}) -> "
+                       f"decode {B}x8 frames; {a.model}; MAGVIT2 convs via MIOpen bf16, bit/byte ends in HIP",
+           "clips": B, "encode_frames_per_sec": B * 16 / t_enc, "generate_frames_per_sec": B * 8 / t_gen,
+           "decode_frames_per_sec": B * 8 / t_dec, "end_to_end_generated_frames_per_sec": B * 8 / total,
+           "seconds": {"encode": t_enc, "generate": t_gen, "decode": t_dec}}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
