@@ -89,6 +89,16 @@ SIGNATURES = {
     "genie_bits_from_tokens": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_rescale_u8_bf16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_rescale_u8_f32": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_pack_conv_weight": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "genie_conv3x3_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, c_ptr]),
+    "genie_conv1x1_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "genie_conv_direct_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         c_ptr]),
+    "genie_group_norm_swish_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_float, C.c_int, c_ptr]),
+    "genie_bits_from_tokens_nhwc_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_int, C.c_int, c_ptr]),
+    "genie_rescale_u8_nhwc_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_tokens_from_bits": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
 }
 

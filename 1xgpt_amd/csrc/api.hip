@@ -586,4 +586,39 @@ int genie_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits
     return launch_tokens_from_bits(h, ids, n, hw, bits, as_stream(stream));
 }
 
+int genie_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int taps, void* stream) {
+    GENIE_CHECK_ARG(w && out && Cout >= 1 && Cin >= 1 && taps >= 1, "pack_conv_weight: bad argument");
+    return launch_pack_conv_weight(w, out, Cout, Cin, taps, as_stream(stream));
+}
+int genie_conv3x3_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, const uint16_t* residual, uint16_t* y,
+                       const uint16_t* zero_page, int n, int H, int W, int Cin, int Cout, int depth_to_space, void* stream) {
+    GENIE_CHECK_ARG(x && w_packed && y && zero_page && n >= 0 && H >= 1 && W >= 1, "conv3x3: bad argument");
+    return launch_conv3x3_igemm(x, w_packed, bias, residual, y, zero_page, n, H, W, Cin, Cout, depth_to_space,
+                                as_stream(stream));
+}
+int genie_conv1x1_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, uint16_t* y, int n_pix, int Cin,
+                       int Cout, void* stream) {
+    GENIE_CHECK_ARG(x && w_packed && y && n_pix >= 0, "conv1x1: bad argument");
+    return launch_gemm_bf16_out16(x, w_packed, bias, y, n_pix, Cout, Cin, as_stream(stream));
+}
+int genie_conv_direct_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, void* y, int n, int H, int W,
+                           int Cin, int Cout, int out_mode, void* stream) {
+    GENIE_CHECK_ARG(x && w_packed && y && n >= 0 && (out_mode == 0 || out_mode == 1), "conv_direct: bad argument");
+    return launch_conv_direct(x, w_packed, bias, y, n, H, W, Cin, Cout, out_mode, as_stream(stream));
+}
+int genie_group_norm_swish_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats_ws, int n,
+                                int HW, int C, int groups, float eps, int apply_swish, void* stream) {
+    GENIE_CHECK_ARG(x && gamma && beta && y && stats_ws && n >= 0, "group_norm_swish: bad argument");
+    if (n == 0) return GENIE_OK;
+    return launch_gn_swish(x, gamma, beta, y, stats_ws, n, HW, C, groups, eps, apply_swish, as_stream(stream));
+}
+int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_pix, int bits, int cpad, void* stream) {
+    GENIE_CHECK_ARG(ids && z && n_pix >= 0 && bits >= 1 && bits <= 62 && cpad >= bits, "bits_nhwc: bad argument");
+    return launch_bits_nhwc(ids, z, (long)n_pix, bits, cpad, as_stream(stream));
+}
+int genie_rescale_u8_nhwc_bf16(const uint16_t* x, uint8_t* out, int n, int HW, int cpad, int cout, void* stream) {
+    GENIE_CHECK_ARG(x && out && n >= 0 && HW >= 1 && cout >= 1 && cpad >= cout, "rescale_u8_nhwc: bad argument");
+    return launch_rescale_nhwc_u8(x, out, n, HW, cpad, cout, as_stream(stream));
+}
+
 }  // extern "C"

@@ -84,6 +84,17 @@ int launch_check_masked(const int64_t* prompt, int B, int T, int S, int out_t, i
 int launch_bits(const int64_t* ids, float* z, int n, int hw, int bits, hipStream_t st);
 int launch_rescale_u8(const void* x, int is_bf16, uint8_t* out, size_t n, hipStream_t st);
 int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, hipStream_t st);
+int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bias, const uint16_t* residual, uint16_t* Y,
+                         const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st);
+int launch_gn_swish(const uint16_t* X, const float* gamma, const float* beta, uint16_t* Y, float* stats, int n_img, int HW,
+                    int C, int groups, float eps, int apply_swish, hipStream_t st);
+int launch_conv_direct(const uint16_t* X, const uint16_t* Wt, const float* bias, void* Y, int n_img, int H, int Wd, int Cin,
+                       int Cout, int out_mode, hipStream_t st);
+int launch_bits_nhwc(const int64_t* ids, uint16_t* z, long n_pix, int bits, int cpad, hipStream_t st);
+int launch_rescale_nhwc_u8(const uint16_t* x, uint8_t* out, long n_img, int HW, int cpad, int cout, hipStream_t st);
+int launch_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int taps, hipStream_t st);
+int launch_gemm_bf16_out16(const uint16_t* A16, const uint16_t* W16, const float* bias, uint16_t* C16, int M, int N, int K,
+                           hipStream_t st);
 int launch_pack_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t st);
 
 }  // namespace genie

@@ -714,4 +714,10 @@ int launch_linear_lowp(int precision, const uint16_t* x16, const uint16_t* W16, 
     return GENIE_E_UNSUPPORTED;
 }
 
+// bf16 x bf16 -> bf16 Linear (1x1 convolution on NHWC activations)
+int launch_gemm_bf16_out16(const uint16_t* A16, const uint16_t* W16, const float* bias, uint16_t* C16, int M, int N, int K,
+                           hipStream_t st) {
+    return launch_gemm16<1>(A16, K, 0, W16, K, 0, bias, nullptr, C16, 0, N, M, N, K, G16_OUT16, 1.0f, st);
+}
+
 }  // namespace genie

@@ -1,0 +1,400 @@
+// MAGVIT2 decoder convolutions for gfx950: activations NHWC bf16, f32 accumulate.
+//
+//   conv3x3_igemm_kernel   3x3 / pad 1 / stride 1 as an implicit GEMM on v_mfma_f32_32x32x16_bf16:
+//                          rows = output pixels (n*H*W), cols = C_out, K = 9*C_in ordered tap-major, so one
+//                          64-wide K stage never straddles a tap (C_in % 64 == 0).  Same machinery as gemm16_v2:
+//                          256x128 tile, 8 waves, 3-stage global_load_lds ring, counted vmcnt, XOR-swizzled LDS
+//                          image (swizzle on the source address).  The A operand is gathered on the fly: lane ->
+//                          (pixel, tap) -> neighbour pixel's channel slice; out-of-image taps read a zero page.
+//                          Epilogue: + bias, + residual (ResBlock skip), bf16 NHWC store, optionally through the DCR
+//                          depth-to-space permutation of the Upsampler (improved_model.py:185-237).
+//   gn_stats / gn_swish    GroupNorm(32, eps 1e-6) statistics (f32 sums via atomics) and the fused normalise + affine +
+//                          x*sigmoid(x) pass that writes the next conv's bf16 operand (improved_model.py:24-51).
+//   conv_direct_kernel     small direct convolution for the two edge layers (C_in = 18 -> 512 and 128 -> 3).
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { CONV_D2S = 1 };
+
+__global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                                              const float* __restrict__ bias,
+                                                              const uint16_t* __restrict__ residual,
+                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ zero,
+                                                              int n_img, int H, int Wd, int Cin, int Cout, int flags) {
+    constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
+    constexpr int ROWB = 128, SPR = 8, RPB = 2;
+    constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB, STAGE_B = A_TILE + W_TILE;  // 48 KB
+    constexpr int CPW = 6;  // 1 KB chunks per wave per stage: 4 of A (32 chunks / 8 waves), 2 of W
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const long M = (long)n_img * H * Wd;
+    const int K = 9 * Cin;
+    const int mt = (int)((M + BM - 1) / BM), nt = (Cout + BN - 1) / BN;
+    int bid = blockIdx.x, m_tile, n_tile;
+    const int full = (mt / 8) * 8 * nt;
+    if (bid < full) {
+        const int grp = bid / (8 * nt), rem = bid - grp * 8 * nt;
+        m_tile = grp * 8 + (rem & 7);
+        n_tile = rem >> 3;
+    } else {
+        const int rem = bid - full;
+        m_tile = (mt / 8) * 8 + rem / nt;
+        n_tile = rem % nt;
+    }
+    const long m0 = (long)m_tile * BM;
+    const int n0 = n_tile * BN;
+
+    // ---- staging descriptors.  A chunks c = wid + 8*i (i < 4): rows c*8 .. c*8+7; W chunks: wid + 8*j (j < 2)
+    int a_y[4], a_x[4], a_slot[4];
+    long a_pix[4];  // pixel index of the lane's row (clamped), -1 if the row is past M
+    const int c_row = lane >> 3, c_phys = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row_local = (wid + 8 * i) * 8 + c_row;
+        a_slot[i] = c_phys ^ ((row_local / RPB) % SPR);
+        long p = m0 + row_local;
+        if (p >= M) { a_pix[i] = -1; a_y[i] = 0; a_x[i] = 0; continue; }
+        a_pix[i] = p;
+        const long in_img = p % ((long)H * Wd);
+        a_y[i] = (int)(in_img / Wd);
+        a_x[i] = (int)(in_img % Wd);
+    }
+    const uint16_t* w_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row_local = (wid + 8 * j) * 8 + c_row;
+        const int slot = c_phys ^ ((row_local / RPB) % SPR);
+        int rw = n0 + row_local;
+        rw = rw < Cout ? rw : Cout - 1;
+        w_src[j] = Wt + (size_t)rw * K + slot * 8;
+    }
+    auto stage = [&](int st, int k0) {
+        const int tap = k0 / Cin, kc = k0 - tap * Cin;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        unsigned char* base = smem + st * STAGE_B;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+            const bool ok = a_pix[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+            const uint16_t* src = ok ? X + (size_t)(a_pix[i] + (long)dy * Wd + dx) * Cin + kc + a_slot[i] * 8 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + (wid + 8 * i) * 1024), 16, 0,
+                                             0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(w_src[j] + k0),
+                (__attribute__((address_space(3))) void*)(base + A_TILE + (wid + 8 * j) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int rowA[2], rowB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { rowA[i] = wm * 64 + i * 32 + r; rowB[i] = wn * 64 + i * 32 + r; }
+    auto frag_off = [&](int row_local, int kk) {
+        const int slot = 2 * kk + h;
+        return row_local * ROWB + ((slot ^ ((row_local / RPB) % SPR)) << 4);
+    };
+    const int nk = K / BK;
+    stage(0, 0);
+    if (nk > 1) stage(1, BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage((kt + 2) % NST, (kt + 2) * BK);
+        const unsigned char* sa = smem + (kt % NST) * STAGE_B;
+        const unsigned char* sw = sa + A_TILE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(sa + frag_off(rowA[i], kk));
+                b[i] = *reinterpret_cast<const bf16x8*>(sw + frag_off(rowB[i], kk));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue through LDS: rows = pixels, 4 consecutive output channels per lane
+    __syncthreads();
+    float* ct = reinterpret_cast<float*>(smem) + wid * (64 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
+    const int c4 = (lane & 15) << 2;
+    const int col = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && col < Cout) bv = *reinterpret_cast<const float4*>(bias + col);
+    const bool d2s = flags & CONV_D2S;
+    const int Cq = Cout >> 2;  // channels after depth-to-space
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const long p = m0 + wm * 64 + rl;
+        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+        if (p >= M || col >= Cout) continue;
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        size_t oidx;
+        if (!d2s) {
+            oidx = (size_t)p * Cout + col;
+        } else {  // DCR: conv channel (i*2 + j)*Cq + c -> pixel (2y+i, 2x+j), channel c
+            const int grp = col / Cq, c = col - grp * Cq;
+            const long img = p / ((long)H * Wd);
+            const long in_img = p - img * (long)H * Wd;
+            const int y = (int)(in_img / Wd), x = (int)(in_img % Wd);
+            oidx = (((size_t)img * (2 * H) + (2 * y + (grp >> 1))) * (2 * Wd) + (2 * x + (grp & 1))) * Cq + c;
+        }
+        if (residual) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(residual + oidx);
+            v.x += bf16_to_f32((uint16_t)(rr.x & 0xFFFF)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
+            v.z += bf16_to_f32((uint16_t)(rr.y & 0xFFFF)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
+        }
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2*>(Y + oidx) = pk;
+    }
+}
+
+int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bias, const uint16_t* residual, uint16_t* Y,
+                         const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st) {
+    GENIE_CHECK_SHAPE(Cin % 64 == 0 && Cout % 4 == 0, "conv3x3_igemm: C_in %% 64 and C_out %% 4 required (got %d, %d)", Cin,
+                      Cout);
+    GENIE_CHECK_SHAPE(!d2s || (Cout % 16 == 0), "conv3x3_igemm: depth-to-space needs C_out %% 16 == 0");
+    const long M = (long)n_img * H * Wd;
+    if (M <= 0) return GENIE_OK;
+    const int mt = (int)((M + 255) / 256), nt = (Cout + 127) / 128;
+    const size_t lds = 3 * 48 * 1024;
+    ProfScope prof(GENIE_KC_OTHER, 2.0 * M * Cout * 9.0 * Cin, 2.0 * (M * (double)Cin + M * (double)Cout + 9.0 * Cin * Cout),
+                   st);
+    (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    conv3x3_igemm_kernel<<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout,
+                                                    d2s ? CONV_D2S : 0);
+    GENIE_LAUNCH_CHECK("conv3x3_igemm");
+    return GENIE_OK;
+}
+
+// ---- GroupNorm(32) statistics: block = 256 threads over a slab of pixels of one image; thread t owns channel pair
+// columns so that its group is fixed; per-(image, group) f32 sum / sum-of-squares via one atomicAdd pair per block.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X, float* __restrict__ stats, int HW, int C,
+                                                       int groups, int pix_per_block) {
+    extern __shared__ float red[];  // [groups][2]
+    const int img = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, HW);
+    const int cpg = C / groups;
+    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    const int c8 = C >> 3;                  // 16-byte chunks per pixel; 256 % c8 == 0 (checked by the launcher)
+    const int chunk = threadIdx.x % c8;     // fixed channel slice of this thread -> fixed group(s)
+    const int prow = threadIdx.x / c8, pstep = blockDim.x / c8;
+    const uint16_t* base = X + ((size_t)img * HW) * C + chunk * 8;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // first / second half of the chunk (cpg == 4: two groups)
+    for (int p = p0 + prow; p < p1; p += pstep) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)p * C);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float a = bf16_to_f32((uint16_t)(w[k] & 0xFFFF)), b = bf16_to_f32((uint16_t)(w[k] >> 16));
+            s0 += a + b; q0 += a * a + b * b;
+            const float c = bf16_to_f32((uint16_t)(w[2 + k] & 0xFFFF)), d = bf16_to_f32((uint16_t)(w[2 + k] >> 16));
+            s1 += c + d; q1 += c * c + d * d;
+        }
+    }
+    const int g0 = (chunk * 8) / cpg, g1 = (chunk * 8 + 4) / cpg;
+    if (g0 == g1) { atomicAdd(&red[g0 * 2], s0 + s1); atomicAdd(&red[g0 * 2 + 1], q0 + q1); }
+    else { atomicAdd(&red[g0 * 2], s0); atomicAdd(&red[g0 * 2 + 1], q0); atomicAdd(&red[g1 * 2], s1); atomicAdd(&red[g1 * 2 + 1], q1); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) atomicAdd(&stats[(size_t)img * groups * 2 + i], red[i]);
+}
+
+// (sum, sumsq) -> (mean, rstd) in place, one thread per (image, group)
+__global__ void gn_finalize_kernel(float* __restrict__ stats, int n, float cnt, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mean = stats[2 * i] / cnt;
+    const float var = fmaxf(stats[2 * i + 1] / cnt - mean * mean, 0.f);
+    stats[2 * i] = mean;
+    stats[2 * i + 1] = 1.0f / sqrtf(var + eps);
+}
+
+// y = swish(gn(x)) as bf16 NHWC (apply_swish = 0: GroupNorm only); stats hold (mean, rstd)
+__global__ void gn_swish_kernel(const uint16_t* __restrict__ X, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, uint16_t* __restrict__ Y,
+                                long n_chunks, int HW, int C, int groups, int apply_swish) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_chunks) return;
+    const int c8 = C >> 3, cpg = C / groups;
+    const int chunk = (int)(idx % c8);
+    const long pix = idx / c8;
+    const int img = (int)(pix / HW);
+    const uint4 v = *reinterpret_cast<const uint4*>(X + idx * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int c0 = chunk * 8;
+    const float* st0 = stats + ((size_t)img * groups + c0 / cpg) * 2;
+    const float* st1 = stats + ((size_t)img * groups + (c0 + 4) / cpg) * 2;
+    const float m0 = st0[0], r0 = st0[1], m1 = st1[0], r1 = st1[1];
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c0), gb = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    const float4 ba = *reinterpret_cast<const float4*>(beta + c0), bb = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    const float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    const float be[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float r2[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int j = 2 * k + hh;
+            const float x = bf16_to_f32((uint16_t)(hh ? (w[k] >> 16) : (w[k] & 0xFFFF)));
+            float y = (x - (j < 4 ? m0 : m1)) * (j < 4 ? r0 : r1) * gg[j] + be[j];
+            if (apply_swish) y = y / (1.0f + __expf(-y));
+            r2[hh] = y;
+        }
+        o[k] = (uint32_t)f32_to_bf16(r2[0]) | ((uint32_t)f32_to_bf16(r2[1]) << 16);
+    }
+    *reinterpret_cast<uint4*>(Y + idx * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+int launch_gn_swish(const uint16_t* X, const float* gamma, const float* beta, uint16_t* Y, float* stats, int n_img, int HW,
+                    int C, int groups, float eps, int apply_swish, hipStream_t st) {
+    GENIE_CHECK_SHAPE(C % groups == 0 && (C / groups) % 4 == 0 && C % 8 == 0 && groups <= 64 && 256 % (C / 8) == 0,
+                      "group_norm: C=%d groups=%d unsupported", C, groups);
+    if (hipMemsetAsync(stats, 0, (size_t)n_img * groups * 2 * sizeof(float), st) != hipSuccess) {
+        set_error("group_norm: memset failed");
+        return GENIE_E_LAUNCH;
+    }
+    const int ppb = HW >= 16384 ? 512 : (HW >= 1024 ? 128 : (HW >= 64 ? 64 : HW));
+    dim3 grid((HW + ppb - 1) / ppb, n_img);
+    gn_stats_kernel<<<grid, 256, groups * 2 * sizeof(float), st>>>(X, stats, HW, C, groups, ppb);
+    GENIE_LAUNCH_CHECK("gn_stats");
+    gn_finalize_kernel<<<(n_img * groups + 255) / 256, 256, 0, st>>>(stats, n_img * groups, (float)HW * (C / groups), eps);
+    GENIE_LAUNCH_CHECK("gn_finalize");
+    const long n_chunks = (long)n_img * HW * (C / 8);
+    gn_swish_kernel<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>(X, stats, gamma, beta, Y, n_chunks, HW, C, groups,
+                                                                        apply_swish);
+    GENIE_LAUNCH_CHECK("gn_swish");
+    return GENIE_OK;
+}
+
+// ---- direct 3x3 / pad 1 convolution for the edge layers: X NHWC bf16, Wt (Cout, 3, 3, Cin) bf16, f32 accumulate.
+// out_mode 0: Y NHWC bf16;  1: NCHW f32 (decoder conv_out feeding the u8 rescale)
+__global__ void conv_direct_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                   const float* __restrict__ bias, void* __restrict__ Yv, int n_img, int H, int Wd, int Cin,
+                                   int Cout, int out_mode) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_img * H * Wd * Cout;
+    if (idx >= total) return;
+    int co;
+    long p;
+    if (out_mode == 0) { co = (int)(idx % Cout); p = idx / Cout; }            // channel fastest
+    else { p = idx % ((long)n_img * H * Wd); co = (int)(idx / ((long)n_img * H * Wd)); }  // pixel fastest
+    const long img = p / ((long)H * Wd);
+    const long in_img = p - img * (long)H * Wd;
+    const int y = (int)(in_img / Wd), x = (int)(in_img % Wd);
+    float acc = bias ? bias[co] : 0.f;
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= Wd) continue;
+        const uint16_t* xp = X + (((size_t)img * H + yy) * Wd + xx) * Cin;
+        const uint16_t* wp = Wt + ((size_t)co * 9 + t) * Cin;
+        for (int c = 0; c < Cin; ++c) acc = fmaf(bf16_to_f32(xp[c]), bf16_to_f32(wp[c]), acc);
+    }
+    if (out_mode == 0) reinterpret_cast<uint16_t*>(Yv)[(size_t)p * Cout + co] = f32_to_bf16(acc);
+    else reinterpret_cast<float*>(Yv)[((size_t)img * Cout + co) * H * Wd + in_img] = acc;
+}
+
+int launch_conv_direct(const uint16_t* X, const uint16_t* Wt, const float* bias, void* Y, int n_img, int H, int Wd, int Cin,
+                       int Cout, int out_mode, hipStream_t st) {
+    const long total = (long)n_img * H * Wd * Cout;
+    if (total <= 0) return GENIE_OK;
+    ProfScope prof(GENIE_KC_OTHER, 2.0 * total * 9.0 * Cin, 2.0 * total, st);
+    conv_direct_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(X, Wt, bias, Y, n_img, H, Wd, Cin, Cout, out_mode);
+    GENIE_LAUNCH_CHECK("conv_direct");
+    return GENIE_OK;
+}
+
+// tokens (n, hw) int64 -> +-1 bit planes as NHWC bf16 (n, hw, bits): the decoder's input operand (a18 + layout)
+__global__ void bits_nhwc_kernel(const int64_t* __restrict__ ids, uint16_t* __restrict__ z, long n_pix, int bits, int cpad) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix * cpad) return;
+    const long p = idx / cpad;
+    const int c = (int)(idx - p * cpad);
+    // +1.0 / -1.0 in bf16; channels >= bits are zero padding (so that C_in %% 64 == 0 for the implicit GEMM)
+    z[idx] = c >= bits ? (uint16_t)0 : (((ids[p] >> c) & 1) ? (uint16_t)0x3F80 : (uint16_t)0xBF80);
+}
+int launch_bits_nhwc(const int64_t* ids, uint16_t* z, long n_pix, int bits, int cpad, hipStream_t st) {
+    if (n_pix <= 0) return GENIE_OK;
+    bits_nhwc_kernel<<<(unsigned)((n_pix * cpad + 255) / 256), 256, 0, st>>>(ids, z, n_pix, bits, cpad);
+    GENIE_LAUNCH_CHECK("bits_nhwc");
+    return GENIE_OK;
+}
+
+// (C_out, C_in, 3, 3) f32 -> (C_out, 3, 3, C_in) bf16 (tap-major K for the implicit GEMM); 1x1: (C_out, C_in) cast
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int taps) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)Cout * Cin * taps;
+    if (idx >= total) return;
+    const int c = (int)(idx % Cin);
+    const int t = (int)((idx / Cin) % taps);
+    const int co = (int)(idx / ((long)Cin * taps));
+    out[idx] = f32_to_bf16(w[((size_t)co * Cin + c) * taps + t]);
+}
+int launch_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int taps, hipStream_t st) {
+    const long total = (long)Cout * Cin * taps;
+    if (total <= 0) return GENIE_OK;
+    pack_conv_weight_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(w, out, Cout, Cin, taps);
+    GENIE_LAUNCH_CHECK("pack_conv_weight");
+    return GENIE_OK;
+}
+
+// decoder tail: conv_out result as NHWC bf16 with cpad channels -> (n, c_out, H*W) uint8 through the reference's
+// bf16 rescale (visualize.py:84-92): u8 = trunc(clamp(bf16(bf16(x + 1) * 127.5), 0, 255))
+__global__ void rescale_nhwc_to_nchw_u8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ out, long n_pix_total,
+                                               int HW, int cpad, int cout) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix_total * cout) return;
+    const int c = (int)(idx / n_pix_total % cout);
+    (void)c;
+    const long p = idx % n_pix_total;
+    const int ch = (int)(idx / n_pix_total);
+    const long img = p / HW, in_img = p - img * HW;
+    float v = bf16_to_f32(x[(size_t)p * cpad + ch]);
+    v = bf16_to_f32(f32_to_bf16(v + 1.0f));
+    v = bf16_to_f32(f32_to_bf16(v * 127.5f));
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    out[((size_t)img * cout + ch) * HW + in_img] = (uint8_t)v;
+}
+int launch_rescale_nhwc_u8(const uint16_t* x, uint8_t* out, long n_img, int HW, int cpad, int cout, hipStream_t st) {
+    const long total = n_img * HW * cout;
+    if (total <= 0) return GENIE_OK;
+    rescale_nhwc_to_nchw_u8_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, out, n_img * HW, HW, cpad, cout);
+    GENIE_LAUNCH_CHECK("rescale_nhwc_u8");
+    return GENIE_OK;
+}
+
+}  // namespace genie

@@ -251,6 +251,143 @@ class VQModel(nn.Module):
         return tokens_from_bits(self.encoder(x))
 
 
+class HipDecoder:
+    """The MAGVIT2 ``Decoder`` (improved_model.py:124-182) on hand-written gfx950 kernels: NHWC bf16 activations,
+    3x3 convolutions as implicit GEMMs on the bf16 matrix cores (``genie_conv3x3_bf16``: gathered A operand, fused
+    bias / ResBlock skip / depth-to-space epilogue), fused GroupNorm+swish (``genie_group_norm_swish_bf16``), 1x1
+    shortcuts as GEMMs, direct kernels for the two edge layers, tokens in and uint8 frames out without leaving HBM.
+    Built from a ``Decoder`` module's parameters (weights are re-packed tap-major bf16 once).
+    Requires every ResBlock width to be a multiple of 64 (true for the shipped config: 128/256/512)."""
+
+    def __init__(self, decoder: "Decoder", codebook_dim: int = 18):
+        self.lib = _lib.load()
+        dev = next(decoder.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): move the decoder to cuda")
+        self.dev, self.bits = dev, codebook_dim
+        self.zero = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+        self._keep = []
+        st = _stream()
+
+        def pack(conv, pad_in=None, pad_out=None):
+            w = conv.weight.detach().float()
+            bsrc = conv.bias
+            if pad_in is not None and w.shape[1] < pad_in:   # zero input channels: C_in %% 64 == 0 for the implicit GEMM
+                w = torch.cat([w, w.new_zeros(w.shape[0], pad_in - w.shape[1], *w.shape[2:])], 1)
+            if pad_out is not None and w.shape[0] < pad_out:  # zero output channels: C_out %% 4 == 0
+                w = torch.cat([w, w.new_zeros(pad_out - w.shape[0], *w.shape[1:])], 0)
+                if bsrc is not None:
+                    bsrc = torch.cat([bsrc.detach().float(), bsrc.new_zeros(pad_out - bsrc.shape[0]).float()])
+            w = w.contiguous()
+            co, ci, kh, kw = w.shape
+            out = torch.empty(co, kh * kw, ci, dtype=torch.bfloat16, device=dev)
+            _lib.check(self.lib.genie_pack_conv_weight(w.data_ptr(), out.data_ptr(), co, ci, kh * kw, st), "pack_conv")
+            b = None if bsrc is None else bsrc.detach().float().contiguous()
+            self._keep += [w, out, b]
+            return out, b, ci, co
+
+        def f32(p):
+            t = p.detach().float().contiguous()
+            self._keep.append(t)
+            return t
+
+        def block(rb):
+            d = {"n1": (f32(rb.norm1.weight), f32(rb.norm1.bias)), "n2": (f32(rb.norm2.weight), f32(rb.norm2.bias)),
+                 "c1": pack(rb.conv1), "c2": pack(rb.conv2), "cin": rb.in_filters, "cout": rb.out_filters}
+            if rb.in_filters != rb.out_filters:
+                d["nin"] = pack(rb.nin_shortcut)
+            return d
+
+        self.cin_pad = 64
+        self.conv_in = pack(decoder.conv_in, pad_in=self.cin_pad)
+        self.mid = [block(b) for b in decoder.mid_block]
+        self.levels = []
+        for i_level in reversed(range(decoder.num_blocks)):
+            up = decoder.up[i_level]
+            self.levels.append({"blocks": [block(b) for b in up.block],
+                                "up": pack(up.upsample.conv1) if i_level > 0 else None})
+        self.norm_out = (f32(decoder.norm_out.weight), f32(decoder.norm_out.bias))
+        self.c_out = decoder.conv_out.weight.shape[0]
+        self.conv_out = pack(decoder.conv_out, pad_out=(self.c_out + 3) // 4 * 4)
+        torch.cuda.synchronize()
+
+    # -- primitive wrappers (x: (n, H, W, C) bf16 contiguous)
+    def _gn(self, x, gb, swish=True):
+        n, H, W, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(n * 32 * 2, dtype=torch.float32, device=self.dev)
+        _lib.check(self.lib.genie_group_norm_swish_bf16(x.data_ptr(), gb[0].data_ptr(), gb[1].data_ptr(), y.data_ptr(),
+                                                        stats.data_ptr(), n, H * W, C, 32, 1e-6, int(swish), _stream()),
+                   "genie_group_norm_swish_bf16")
+        return y
+
+    def _conv3(self, x, wp, residual=None, d2s=False):
+        w, b, ci, co = wp
+        n, H, W, C = x.shape
+        assert C == ci
+        y = torch.empty((n, 2 * H, 2 * W, co // 4) if d2s else (n, H, W, co), dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_conv3x3_bf16(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
+                                               0 if residual is None else residual.data_ptr(), y.data_ptr(),
+                                               self.zero.data_ptr(), n, H, W, ci, co, int(d2s), _stream()),
+                   "genie_conv3x3_bf16")
+        return y
+
+    def _conv1(self, x, wp):
+        w, b, ci, co = wp
+        n, H, W, C = x.shape
+        y = torch.empty(n, H, W, co, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_conv1x1_bf16(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
+                                               n * H * W, ci, co, _stream()), "genie_conv1x1_bf16")
+        return y
+
+    def _direct(self, x, wp, out_mode):
+        w, b, ci, co = wp
+        n, H, W, C = x.shape
+        y = torch.empty((n, H, W, co), dtype=torch.bfloat16, device=self.dev) if out_mode == 0 else \
+            torch.empty((n, co, H, W), dtype=torch.float32, device=self.dev)
+        _lib.check(self.lib.genie_conv_direct_bf16(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
+                                                   y.data_ptr(), n, H, W, ci, co, out_mode, _stream()),
+                   "genie_conv_direct_bf16")
+        return y
+
+    def _res(self, x, blk):
+        t = self._conv3(self._gn(x, blk["n1"]), blk["c1"])
+        t = self._gn(t, blk["n2"])
+        res = x if "nin" not in blk else self._conv1(x, blk["nin"])
+        return self._conv3(t, blk["c2"], residual=res)
+
+    @torch.no_grad()
+    def decode_bits_nhwc(self, z_nhwc: torch.Tensor) -> torch.Tensor:
+        """(n, h, w, 64) bf16 (+-1 bits, zero padded) -> decoder output NHWC bf16 (n, H, W, 4) (channel 3 is padding)."""
+        x = self._conv3(z_nhwc, self.conv_in)
+        for blk in self.mid:
+            x = self._res(x, blk)
+        for lvl in self.levels:
+            for blk in lvl["blocks"]:
+                x = self._res(x, blk)
+            if lvl["up"] is not None:
+                x = self._conv3(x, lvl["up"], d2s=True)
+        x = self._gn(x, self.norm_out)
+        return self._conv3(x, self.conv_out)
+
+    @torch.no_grad()
+    def decode_tokens(self, ids_nhw: torch.LongTensor, return_float=False):
+        """(n, h, w) token ids -> (n, 3, H, W) uint8 (truncating rescale, visualize.py:84-92)."""
+        ids = ids_nhw.to(self.dev).to(torch.int64).contiguous()
+        n, h, w = ids.shape
+        z = torch.empty(n, h, w, self.cin_pad, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_bits_from_tokens_nhwc_bf16(ids.data_ptr(), z.data_ptr(), n * h * w, self.bits,
+                                                             self.cin_pad, _stream()), "genie_bits_from_tokens_nhwc_bf16")
+        y = self.decode_bits_nhwc(z)  # (n, H, W, cpad) bf16
+        H, W, cpad = y.shape[1], y.shape[2], y.shape[3]
+        if return_float:
+            return y[..., :self.c_out].permute(0, 3, 1, 2).float().contiguous()
+        out = torch.empty(n, self.c_out, H, W, dtype=torch.uint8, device=self.dev)
+        _lib.check(self.lib.genie_rescale_u8_nhwc_bf16(y.data_ptr(), out.data_ptr(), n, H * W, cpad, self.c_out, _stream()),
+                   "genie_rescale_u8_nhwc_bf16")
+        return out
+
+
 def load_tokenizer_ckpt(model: VQModel, path: str):
     """Lightning checkpoint -> encoder.* / decoder.* (lfqgan.py:85-119; EMA == raw weights at inference)."""
     sd = torch.load(path, map_location="cpu")["state_dict"]
@@ -264,11 +401,14 @@ def load_tokenizer_ckpt(model: VQModel, path: str):
 
 
 def decode_latents_wrapper(batch_size=16, tokenizer_ckpt="data/magvit2.ckpt", max_images=None, model: VQModel = None,
-                           device="cuda", dtype=torch.bfloat16):
-    """visualize.py:95-122, device-resident: returns ``decode_latents(tokens (b,h,w)) -> uint8 (b,3,H,W)`` tensor."""
+                           device="cuda", dtype=torch.bfloat16, backend="hip"):
+    """visualize.py:95-122, device-resident: returns ``decode_latents(tokens (b,h,w)) -> uint8 (b,3,H,W)`` tensor.
+    backend "hip": the hand-written conv stack (HipDecoder; needs ResBlock widths %% 64 == 0); "miopen": torch convs."""
     if model is None:
         model = load_tokenizer_ckpt(VQModel(VQConfig()), tokenizer_ckpt)
     model = model.to(device=device, dtype=dtype).eval()
+    widths_ok = all(c % 64 == 0 for c in [model.config.base_channels * m for m in model.config.ch_mult])
+    hip_dec = HipDecoder(model.decoder, model.codebook_dim) if backend == "hip" and widths_ok else None
 
     @torch.no_grad()
     def decode_latents(video_data):
@@ -277,7 +417,8 @@ def decode_latents_wrapper(batch_size=16, tokenizer_ckpt="data/magvit2.ckpt", ma
         video_data = video_data.to(device)
         outs = []
         for s in range(0, video_data.shape[0], batch_size):
-            outs.append(model.decode_tokens(video_data[s:s + batch_size]))
+            chunk = video_data[s:s + batch_size]
+            outs.append(hip_dec.decode_tokens(chunk) if hip_dec is not None else model.decode_tokens(chunk))
             if max_images and len(outs) * batch_size >= max_images:
                 break
         return torch.cat(outs)

@@ -261,6 +261,30 @@ int genie_rescale_u8_f32(const float* x, uint8_t* out, size_t n, void* stream);
  * the dataset convention).  ids (n, hw) int64. */
 int genie_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, void* stream);
 
+/* ---- MAGVIT2 decoder convolutions (improved_model.py:12-51, 124-237), activations NHWC bf16, f32 accumulate ------
+ * genie_pack_conv_weight: (C_out, C_in, kh*kw) f32 torch layout -> (C_out, kh*kw, C_in) bf16 (tap-major K).
+ * genie_conv3x3_bf16: 3x3 / pad 1 / stride 1 implicit GEMM on the bf16 matrix cores; C_in %% 64 == 0, C_out %% 4 == 0;
+ *   residual (same shape as the output) is added before the bf16 store (ResBlock skip); depth_to_space != 0 writes
+ *   the Upsampler's DCR-permuted (n, 2H, 2W, C_out/4) image; zero_page: >= 16 zero bytes for out-of-image taps.
+ * genie_conv1x1_bf16: the 1x1 nin_shortcut (a plain Linear over pixels).
+ * genie_conv_direct_bf16: direct 3x3 conv for the edge layers (C_in = 18 -> 512, 128 -> 3); out_mode 0 = NHWC bf16,
+ *   1 = NCHW f32.
+ * genie_group_norm_swish_bf16: GroupNorm(groups, eps) [+ x*sigmoid(x)] of an NHWC bf16 image; stats_ws: n*groups*2 f32.
+ * genie_bits_from_tokens_nhwc_bf16: tokens (n_pix) -> (n_pix, cpad) bf16: channel c < bits = +-1 for bit c (a18 in
+ *   operand layout), channels >= bits zero (cpad %% 64 == 0 lets conv_in run on the implicit GEMM).
+ * genie_rescale_u8_nhwc_bf16: decoder tail: (n, HW, cpad) bf16 -> (n, cout, HW) uint8 with the reference's bf16 rescale. */
+int genie_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int taps, void* stream);
+int genie_conv3x3_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, const uint16_t* residual, uint16_t* y,
+                       const uint16_t* zero_page, int n, int H, int W, int Cin, int Cout, int depth_to_space, void* stream);
+int genie_conv1x1_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, uint16_t* y, int n_pix, int Cin,
+                       int Cout, void* stream);
+int genie_conv_direct_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, void* y, int n, int H, int W,
+                           int Cin, int Cout, int out_mode, void* stream);
+int genie_group_norm_swish_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats_ws, int n,
+                                int HW, int C, int groups, float eps, int apply_swish, void* stream);
+int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_pix, int bits, int cpad, void* stream);
+int genie_rescale_u8_nhwc_bf16(const uint16_t* x, uint8_t* out, int n, int HW, int cpad, int cout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -401,6 +401,21 @@ def magvit_fixture():
     out["enc_frames"], out["enc_h"] = frames, hcode.numpy()
     out["enc_min_abs_h"] = np.float64(hcode.abs().min().item())
     np.savez_compressed(os.path.join(OUT, "magvit_small.npz"), **out)
+    # mid-size decoder (ResBlock widths 256/128: the geometry class of the shipped config) for the hand-written conv path
+    mid = dict(base_channels=128, ch_mult=(1, 2), num_res_blocks=1)
+    rcfg2 = RefVQ(**mid)
+    mine2 = mv.VQModel(mv.VQConfig(**mid))
+    sd2 = mv.make_vq_state_dict(mine2, seed=2)
+    dec2 = RefDec(rcfg2)
+    dec2.load_state_dict({k[len("decoder."):]: torch.from_numpy(v) for k, v in sd2.items() if k.startswith("decoder.")})
+    dec2.eval()
+    tok2 = g.integers(0, 262144, size=(3, 8, 8)).astype(np.int64)
+    z2 = lfq.get_codebook_entry(torch.from_numpy(tok2.reshape(3, 64)), bhwc=(3, 8, 8, 18)).flip(1).float()
+    y2 = dec2(z2)
+    o2 = {"cfg": np.array(repr(mid)), "weight_seed": 2, "dec_tokens": tok2, "dec_out_f32": y2.numpy(),
+          "dec_u8_f32": ref_vis.rescale_magvit_output(y2).numpy()}
+    np.savez_compressed(os.path.join(OUT, "magvit_mid.npz"), **o2)
+    print("magvit_mid: dec out range", float(y2.min()), float(y2.max()), y2.shape)
     print("magvit_small: dec out range", float(y32.min()), float(y32.max()), "enc |h| min", out["enc_min_abs_h"])
 
 
