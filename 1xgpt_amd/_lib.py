@@ -92,6 +92,10 @@ SIGNATURES = {
     "genie_pack_conv_weight": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_conv3x3_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, c_ptr]),
+    "genie_conv3x3_s2_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        c_ptr]),
+    "genie_frames_to_nhwc_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "genie_tokens_from_code_nhwc_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_int, C.c_int, c_ptr]),
     "genie_conv1x1_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_conv_direct_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          c_ptr]),

@@ -596,6 +596,19 @@ int genie_conv3x3_bf16(const uint16_t* x, const uint16_t* w_packed, const float*
     return launch_conv3x3_igemm(x, w_packed, bias, residual, y, zero_page, n, H, W, Cin, Cout, depth_to_space,
                                 as_stream(stream));
 }
+int genie_conv3x3_s2_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, uint16_t* y,
+                          const uint16_t* zero_page, int n, int H, int W, int Cin, int Cout, void* stream) {
+    GENIE_CHECK_ARG(x && w_packed && y && zero_page && n >= 0 && H >= 1 && W >= 1, "conv3x3_s2: bad argument");
+    return launch_conv3x3_igemm(x, w_packed, bias, nullptr, y, zero_page, n, H, W, Cin, Cout, 0, as_stream(stream), 2);
+}
+int genie_frames_to_nhwc_bf16(const uint8_t* frames, uint16_t* x, int n, int HW, int cin, int cpad, void* stream) {
+    GENIE_CHECK_ARG(frames && x && n >= 0 && HW >= 1 && cin >= 1 && cpad >= cin, "frames_to_nhwc: bad argument");
+    return launch_frames_to_nhwc(frames, x, n, HW, cin, cpad, as_stream(stream));
+}
+int genie_tokens_from_code_nhwc_bf16(const uint16_t* h, int64_t* ids, int64_t n_pix, int bits, int cpad, void* stream) {
+    GENIE_CHECK_ARG(h && ids && n_pix >= 0 && bits >= 1 && bits <= 62 && cpad >= bits, "tokens_from_code: bad argument");
+    return launch_tokens_from_nhwc(h, ids, (long)n_pix, bits, cpad, as_stream(stream));
+}
 int genie_conv1x1_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, uint16_t* y, int n_pix, int Cin,
                        int Cout, void* stream) {
     GENIE_CHECK_ARG(x && w_packed && y && n_pix >= 0, "conv1x1: bad argument");

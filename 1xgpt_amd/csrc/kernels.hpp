@@ -85,7 +85,10 @@ int launch_bits(const int64_t* ids, float* z, int n, int hw, int bits, hipStream
 int launch_rescale_u8(const void* x, int is_bf16, uint8_t* out, size_t n, hipStream_t st);
 int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, hipStream_t st);
 int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bias, const uint16_t* residual, uint16_t* Y,
-                         const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st);
+                         const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st,
+                         int stride = 1);
+int launch_frames_to_nhwc(const uint8_t* f, uint16_t* x, long n_img, int HW, int cin, int cpad, hipStream_t st);
+int launch_tokens_from_nhwc(const uint16_t* h, int64_t* ids, long n_pix, int bits, int cpad, hipStream_t st);
 int launch_gn_swish(const uint16_t* X, const float* gamma, const float* beta, uint16_t* Y, float* stats, int n_img, int HW,
                     int C, int groups, float eps, int apply_swish, hipStream_t st);
 int launch_conv_direct(const uint16_t* X, const uint16_t* Wt, const float* bias, void* Y, int n_img, int H, int Wd, int Cin,

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
                                                               const float* __restrict__ bias,
                                                               const uint16_t* __restrict__ residual,
                                                               uint16_t* __restrict__ Y, const uint16_t* __restrict__ zero,
-                                                              int n_img, int H, int Wd, int Cin, int Cout, int flags) {
+                                                              int n_img, int H, int Wd, int Cin, int Cout, int flags,
+                                                              int stride) {
     constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
     constexpr int ROWB = 128, SPR = 8, RPB = 2;
     constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB, STAGE_B = A_TILE + W_TILE;  // 48 KB
@@ -37,6 +38,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 31, h = lane >> 5;
+    // H, Wd: OUTPUT height/width; the input image is (H*stride, Wd*stride) (stride 2 = the encoder's downsample conv)
+    const int Hin = H * stride, Win = Wd * stride;
     const long M = (long)n_img * H * Wd;
     const int K = 9 * Cin;
     const int mt = (int)((M + BM - 1) / BM), nt = (Cout + BN - 1) / BN;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
 
     // ---- staging descriptors.  A chunks c = wid + 8*i (i < 4): rows c*8 .. c*8+7; W chunks: wid + 8*j (j < 2)
     int a_y[4], a_x[4], a_slot[4];
-    long a_pix[4];  // pixel index of the lane's row (clamped), -1 if the row is past M
+    long a_pix[4];  // INPUT pixel index under the centre tap of the lane's output pixel, -1 if the row is past M
     const int c_row = lane >> 3, c_phys = lane & 7;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -64,10 +67,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
         a_slot[i] = c_phys ^ ((row_local / RPB) % SPR);
         long p = m0 + row_local;
         if (p >= M) { a_pix[i] = -1; a_y[i] = 0; a_x[i] = 0; continue; }
-        a_pix[i] = p;
-        const long in_img = p % ((long)H * Wd);
-        a_y[i] = (int)(in_img / Wd);
-        a_x[i] = (int)(in_img % Wd);
+        const long img = p / ((long)H * Wd);
+        const long in_img = p - img * (long)H * Wd;
+        a_y[i] = (int)(in_img / Wd) * stride;   // input coordinates of the centre tap
+        a_x[i] = (int)(in_img % Wd) * stride;
+        a_pix[i] = (img * Hin + a_y[i]) * Win + a_x[i];
     }
     const uint16_t* w_src[2];
 #pragma unroll
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-            const bool ok = a_pix[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
-            const uint16_t* src = ok ? X + (size_t)(a_pix[i] + (long)dy * Wd + dx) * Cin + kc + a_slot[i] * 8 : zero;
+            const bool ok = a_pix[i] >= 0 && yy >= 0 && yy < Hin && xx >= 0 && xx < Win;
+            const uint16_t* src = ok ? X + (size_t)(a_pix[i] + (long)dy * Win + dx) * Cin + kc + a_slot[i] * 8 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + (wid + 8 * i) * 1024), 16, 0,
                                              0);
@@ -182,7 +186,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
 }
 
 int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bias, const uint16_t* residual, uint16_t* Y,
-                         const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st) {
+                         const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st,
+                         int stride) {
+    GENIE_CHECK_SHAPE(stride == 1 || (stride == 2 && !d2s), "conv3x3_igemm: stride %d unsupported", stride);
     GENIE_CHECK_SHAPE(Cin % 64 == 0 && Cout % 4 == 0, "conv3x3_igemm: C_in %% 64 and C_out %% 4 required (got %d, %d)", Cin,
                       Cout);
     GENIE_CHECK_SHAPE(!d2s || (Cout % 16 == 0), "conv3x3_igemm: depth-to-space needs C_out %% 16 == 0");
@@ -194,7 +200,7 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
                    st);
     (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv3x3_igemm_kernel<<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout,
-                                                    d2s ? CONV_D2S : 0);
+                                                    d2s ? CONV_D2S : 0, stride);
     GENIE_LAUNCH_CHECK("conv3x3_igemm");
     return GENIE_OK;
 }
@@ -394,6 +400,39 @@ int launch_rescale_nhwc_u8(const uint16_t* x, uint8_t* out, long n_img, int HW, 
     if (total <= 0) return GENIE_OK;
     rescale_nhwc_to_nchw_u8_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, out, n_img * HW, HW, cpad, cout);
     GENIE_LAUNCH_CHECK("rescale_nhwc_u8");
+    return GENIE_OK;
+}
+
+// encoder head: (n, c_in, H*W) uint8 frames -> (n, H*W, cpad) bf16 with x/127.5 - 1 (channels >= c_in zero)
+__global__ void frames_to_nhwc_kernel(const uint8_t* __restrict__ f, uint16_t* __restrict__ x, long n_pix_total, int HW, int cin,
+                                      int cpad) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix_total * cpad) return;
+    const long p = idx / cpad;
+    const int c = (int)(idx - p * cpad);
+    if (c >= cin) { x[idx] = 0; return; }
+    const long img = p / HW, in_img = p - img * HW;
+    x[idx] = f32_to_bf16((float)f[((size_t)img * cin + c) * HW + in_img] / 127.5f - 1.0f);
+}
+int launch_frames_to_nhwc(const uint8_t* f, uint16_t* x, long n_img, int HW, int cin, int cpad, hipStream_t st) {
+    const long total = n_img * HW * cpad;
+    if (total <= 0) return GENIE_OK;
+    frames_to_nhwc_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(f, x, n_img * HW, HW, cin, cpad);
+    GENIE_LAUNCH_CHECK("frames_to_nhwc");
+    return GENIE_OK;
+}
+// encoder tail: code (n_pix, cpad) bf16 -> dataset-convention ids: bit c = [h_c > 0]
+__global__ void tokens_from_nhwc_kernel(const uint16_t* __restrict__ h, int64_t* __restrict__ ids, long n_pix, int bits, int cpad) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pix) return;
+    int64_t id = 0;
+    for (int c = 0; c < bits; ++c) id |= (int64_t)(bf16_to_f32(h[(size_t)p * cpad + c]) > 0.0f) << c;
+    ids[p] = id;
+}
+int launch_tokens_from_nhwc(const uint16_t* h, int64_t* ids, long n_pix, int bits, int cpad, hipStream_t st) {
+    if (n_pix <= 0) return GENIE_OK;
+    tokens_from_nhwc_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, st>>>(h, ids, n_pix, bits, cpad);
+    GENIE_LAUNCH_CHECK("tokens_from_nhwc");
     return GENIE_OK;
 }
 

@@ -5,12 +5,15 @@ Counterpart of the reference's magvit2/ package restricted to what the hot path 
 ``decode_latents_wrapper`` of visualize.py:95-122.  State-dict keys equal the reference's ``encoder.*`` /
 ``decoder.*`` keys, so a Lightning ``magvit2.ckpt`` loads with ``load_tokenizer_ckpt``.
 
-Round-1 slice: the conv stack runs on PyTorch-ROCm convolutions (MIOpen) -- GroupNorm(32, eps 1e-6), x*sigmoid(x),
-3x3/1x1 convs, DCR depth-to-space -- while the integer/byte ends of the pipeline are HIP kernels behind the C ABI:
-``genie_bits_from_tokens`` (tokens -> +-1 planes), ``genie_rescale_u8_*`` (the truncating u8 rescale with the
-reference's bf16 roundings) and ``genie_tokens_from_bits``.  Tokens and frames never leave HBM (the reference
-round-trips through numpy and PIL, eval_utils.py:39-41).  Hand-written implicit-GEMM MFMA convs are the next step
-(SURVEY.md section 8f rank 2).
+Two executions of the same parameters:
+  * ``HipDecoder`` / ``HipEncoder`` -- the product path: hand-written gfx950 kernels behind the C ABI (NHWC bf16,
+    implicit-GEMM 3x3 convolutions on the bf16 matrix cores with a gathered A operand and fused bias / ResBlock skip /
+    depth-to-space epilogue, fused GroupNorm+swish, bit/byte ends ``genie_bits_from_tokens*``,
+    ``genie_rescale_u8_*``, ``genie_tokens_from_*``).  Tokens and frames never leave HBM (the reference round-trips
+    through numpy and PIL, eval_utils.py:39-41).
+  * the ``nn.Module`` classes below -- parameter holders with the reference's state-dict keys whose ``forward`` is the
+    plain torch (MIOpen) formulation; used to load checkpoints, as the measured library baseline, and for widths the
+    implicit GEMM does not cover (ResBlock widths must be multiples of 64).
 """
 import json
 import math
@@ -267,37 +270,7 @@ class HipDecoder:
         self.dev, self.bits = dev, codebook_dim
         self.zero = torch.zeros(64, dtype=torch.bfloat16, device=dev)
         self._keep = []
-        st = _stream()
-
-        def pack(conv, pad_in=None, pad_out=None):
-            w = conv.weight.detach().float()
-            bsrc = conv.bias
-            if pad_in is not None and w.shape[1] < pad_in:   # zero input channels: C_in %% 64 == 0 for the implicit GEMM
-                w = torch.cat([w, w.new_zeros(w.shape[0], pad_in - w.shape[1], *w.shape[2:])], 1)
-            if pad_out is not None and w.shape[0] < pad_out:  # zero output channels: C_out %% 4 == 0
-                w = torch.cat([w, w.new_zeros(pad_out - w.shape[0], *w.shape[1:])], 0)
-                if bsrc is not None:
-                    bsrc = torch.cat([bsrc.detach().float(), bsrc.new_zeros(pad_out - bsrc.shape[0]).float()])
-            w = w.contiguous()
-            co, ci, kh, kw = w.shape
-            out = torch.empty(co, kh * kw, ci, dtype=torch.bfloat16, device=dev)
-            _lib.check(self.lib.genie_pack_conv_weight(w.data_ptr(), out.data_ptr(), co, ci, kh * kw, st), "pack_conv")
-            b = None if bsrc is None else bsrc.detach().float().contiguous()
-            self._keep += [w, out, b]
-            return out, b, ci, co
-
-        def f32(p):
-            t = p.detach().float().contiguous()
-            self._keep.append(t)
-            return t
-
-        def block(rb):
-            d = {"n1": (f32(rb.norm1.weight), f32(rb.norm1.bias)), "n2": (f32(rb.norm2.weight), f32(rb.norm2.bias)),
-                 "c1": pack(rb.conv1), "c2": pack(rb.conv2), "cin": rb.in_filters, "cout": rb.out_filters}
-            if rb.in_filters != rb.out_filters:
-                d["nin"] = pack(rb.nin_shortcut)
-            return d
-
+        pack, f32, block = self._pack, self._f32, self._block
         self.cin_pad = 64
         self.conv_in = pack(decoder.conv_in, pad_in=self.cin_pad)
         self.mid = [block(b) for b in decoder.mid_block]
@@ -310,6 +283,37 @@ class HipDecoder:
         self.c_out = decoder.conv_out.weight.shape[0]
         self.conv_out = pack(decoder.conv_out, pad_out=(self.c_out + 3) // 4 * 4)
         torch.cuda.synchronize()
+
+    # -- weight packing (tap-major bf16 once per model)
+    def _pack(self, conv, pad_in=None, pad_out=None):
+        w = conv.weight.detach().float()
+        bsrc = conv.bias
+        if pad_in is not None and w.shape[1] < pad_in:   # zero input channels: C_in % 64 == 0 for the implicit GEMM
+            w = torch.cat([w, w.new_zeros(w.shape[0], pad_in - w.shape[1], *w.shape[2:])], 1)
+        if pad_out is not None and w.shape[0] < pad_out:  # zero output channels: C_out % 4 == 0
+            w = torch.cat([w, w.new_zeros(pad_out - w.shape[0], *w.shape[1:])], 0)
+            if bsrc is not None:
+                bsrc = torch.cat([bsrc.detach().float(), bsrc.new_zeros(pad_out - bsrc.shape[0]).float()])
+        w = w.contiguous()
+        co, ci, kh, kw = w.shape
+        out = torch.empty(co, kh * kw, ci, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_pack_conv_weight(w.data_ptr(), out.data_ptr(), co, ci, kh * kw, _stream()), "pack_conv")
+        b = None if bsrc is None else bsrc.detach().float().contiguous()
+        self._keep += [w, out, b]
+        return out, b, ci, co
+
+    def _f32(self, p):
+        t = p.detach().float().contiguous()
+        self._keep.append(t)
+        return t
+
+    def _block(self, rb):
+        d = {"n1": (self._f32(rb.norm1.weight), self._f32(rb.norm1.bias)),
+             "n2": (self._f32(rb.norm2.weight), self._f32(rb.norm2.bias)),
+             "c1": self._pack(rb.conv1), "c2": self._pack(rb.conv2), "cin": rb.in_filters, "cout": rb.out_filters}
+        if rb.in_filters != rb.out_filters:
+            d["nin"] = self._pack(rb.nin_shortcut)
+        return d
 
     # -- primitive wrappers (x: (n, H, W, C) bf16 contiguous)
     def _gn(self, x, gb, swish=True):
@@ -386,6 +390,65 @@ class HipDecoder:
         _lib.check(self.lib.genie_rescale_u8_nhwc_bf16(y.data_ptr(), out.data_ptr(), n, H * W, cpad, self.c_out, _stream()),
                    "genie_rescale_u8_nhwc_bf16")
         return out
+
+
+class HipEncoder(HipDecoder):
+    """The MAGVIT2 ``Encoder`` (improved_model.py:54-121) on the same hand-written kernels: uint8 frames in, token ids
+    (dataset bit convention) out.  conv_in 3->128 runs on the implicit GEMM with the input zero-padded
+    to 64 channels; the stride-2 downsample convs use the strided A-gather (``genie_conv3x3_s2_bf16``); the 1x1
+    conv_out 512->18 is a GEMM padded to 20 outputs whose sign bits are packed by ``genie_tokens_from_code_nhwc_bf16``."""
+
+    def __init__(self, encoder: "Encoder", codebook_dim: int = 18):  # noqa: super().__init__ builds decoder tables
+        self.lib = _lib.load()
+        dev = next(encoder.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): move the encoder to cuda")
+        self.dev, self.bits = dev, codebook_dim
+        self.zero = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+        self._keep = []
+        self.cin = encoder.conv_in.weight.shape[1]
+        self.cin_pad = 64
+        self.conv_in = self._pack(encoder.conv_in, pad_in=self.cin_pad)
+        self.levels = []
+        for i_level in range(encoder.num_blocks):
+            dn = encoder.down[i_level]
+            self.levels.append({"blocks": [self._block(b) for b in dn.block],
+                                "down": self._pack(dn.downsample) if i_level < encoder.num_blocks - 1 else None})
+        self.mid = [self._block(b) for b in encoder.mid_block]
+        self.norm_out = (self._f32(encoder.norm_out.weight), self._f32(encoder.norm_out.bias))
+        self.code_pad = (codebook_dim + 3) // 4 * 4
+        self.conv_out = self._pack(encoder.conv_out, pad_out=self.code_pad)
+        torch.cuda.synchronize()
+
+    @torch.no_grad()
+    def encode_tokens(self, frames_u8: torch.Tensor) -> torch.LongTensor:
+        """(n, 3, H, W) uint8 -> (n, H/16, W/16) int64 token ids."""
+        f = frames_u8.to(self.dev).contiguous()
+        n, c, H, W = f.shape
+        x = torch.empty(n, H, W, self.cin_pad, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_frames_to_nhwc_bf16(f.data_ptr(), x.data_ptr(), n, H * W, c, self.cin_pad, _stream()),
+                   "genie_frames_to_nhwc_bf16")
+        x = self._conv3(x, self.conv_in)
+        for lvl in self.levels:
+            for blk in lvl["blocks"]:
+                x = self._res(x, blk)
+            if lvl["down"] is not None:
+                w, b, ci, co = lvl["down"]
+                nn_, h_, w_, _ = x.shape
+                y = torch.empty(nn_, h_ // 2, w_ // 2, co, dtype=torch.bfloat16, device=self.dev)
+                _lib.check(self.lib.genie_conv3x3_s2_bf16(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
+                                                          y.data_ptr(), self.zero.data_ptr(), nn_, h_ // 2, w_ // 2, ci, co,
+                                                          _stream()), "genie_conv3x3_s2_bf16")
+                x = y
+        for blk in self.mid:
+            x = self._res(x, blk)
+        x = self._gn(x, self.norm_out)
+        code = self._conv1(x, self.conv_out)  # (n, h, w, code_pad) bf16
+        nn_, h_, w_, _ = code.shape
+        ids = torch.empty(nn_, h_, w_, dtype=torch.int64, device=self.dev)
+        _lib.check(self.lib.genie_tokens_from_code_nhwc_bf16(code.data_ptr(), ids.data_ptr(), nn_ * h_ * w_, self.bits,
+                                                             self.code_pad, _stream()), "genie_tokens_from_code_nhwc_bf16")
+        return ids
 
 
 def load_tokenizer_ckpt(model: VQModel, path: str):

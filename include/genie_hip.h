@@ -276,6 +276,13 @@ int genie_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits
 int genie_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int taps, void* stream);
 int genie_conv3x3_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, const uint16_t* residual, uint16_t* y,
                        const uint16_t* zero_page, int n, int H, int W, int Cin, int Cout, int depth_to_space, void* stream);
+/* The encoder's downsample: 3x3 / pad 1 / stride 2 (improved_model.py:90); H, W are the OUTPUT size, input is (2H, 2W). */
+int genie_conv3x3_s2_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, uint16_t* y,
+                          const uint16_t* zero_page, int n, int H, int W, int Cin, int Cout, void* stream);
+/* Encoder ends: uint8 frames (n, cin, HW) -> (n, HW, cpad) bf16 in [-1,1] (x/127.5 - 1; channels >= cin zero), and the
+ * encoder code (n_pix, cpad) bf16 -> dataset-convention token ids, bit c = [h_c > 0]. */
+int genie_frames_to_nhwc_bf16(const uint8_t* frames, uint16_t* x, int n, int HW, int cin, int cpad, void* stream);
+int genie_tokens_from_code_nhwc_bf16(const uint16_t* h, int64_t* ids, int64_t n_pix, int bits, int cpad, void* stream);
 int genie_conv1x1_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, uint16_t* y, int n_pix, int Cin,
                        int Cout, void* stream);
 int genie_conv_direct_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, void* y, int n, int H, int W,

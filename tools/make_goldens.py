@@ -412,8 +412,13 @@ def magvit_fixture():
     tok2 = g.integers(0, 262144, size=(3, 8, 8)).astype(np.int64)
     z2 = lfq.get_codebook_entry(torch.from_numpy(tok2.reshape(3, 64)), bhwc=(3, 8, 8, 18)).flip(1).float()
     y2 = dec2(z2)
+    enc2 = RefEnc(rcfg2)
+    enc2.load_state_dict({k[len("encoder."):]: torch.from_numpy(v) for k, v in sd2.items() if k.startswith("encoder.")})
+    enc2.eval()
+    frames2 = g.integers(0, 256, size=(3, 3, 32, 32)).astype(np.uint8)
+    h2 = enc2(torch.from_numpy(frames2).float() / 127.5 - 1.0)
     o2 = {"cfg": np.array(repr(mid)), "weight_seed": 2, "dec_tokens": tok2, "dec_out_f32": y2.numpy(),
-          "dec_u8_f32": ref_vis.rescale_magvit_output(y2).numpy()}
+          "dec_u8_f32": ref_vis.rescale_magvit_output(y2).numpy(), "enc_frames": frames2, "enc_h": h2.numpy()}
     np.savez_compressed(os.path.join(OUT, "magvit_mid.npz"), **o2)
     print("magvit_mid: dec out range", float(y2.min()), float(y2.max()), y2.shape)
     print("magvit_small: dec out range", float(y32.min()), float(y32.max()), "enc |h| min", out["enc_min_abs_h"])
