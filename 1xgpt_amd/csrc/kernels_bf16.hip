@@ -320,6 +320,14 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     };
 
     const int nk = K / BK;
+    constexpr int KK = BK / 16;
+    // one piece of a stage's loads (CPW pieces in total) -- issued between MFMA groups so that the VMEM issue cost
+    // (~100 cycles per global_load_lds) overlaps matrix-pipe time instead of sitting in front of it
+    auto stage_piece = [&](int st, int k0, int i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(smem + st * STAGE_B + ldsoff[i]), 16, 0,
+                                         0);
+    };
     stage(0, 0);
     if (nk > 1) stage(1, BK);
     for (int kt = 0; kt < nk; ++kt) {
@@ -327,50 +335,89 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's share of stage kt is visible; stage kt-1's buffer is free
-        if (kt + 2 < nk) stage((kt + 2) % NST, (kt + 2) * BK);
+        const bool more = kt + 2 < nk;
+        const int nst = (kt + 2) % NST, nk0 = (kt + 2) * BK;
         const unsigned char* sa = smem + (kt % NST) * STAGE_B;
         const unsigned char* sw = sa + NPL * A_TILE;
+        if constexpr (NPL == 1) {
+            bf16x8 a[2][2], b[2][NJ];  // [kk parity]: fragments of step kk+1 are fetched while step kk multiplies
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            if constexpr (NPL == 1) {
-                bf16x8 a[2], b[NJ];
+            for (int i = 0; i < 2; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(sa + frag_off(rowA[i], 0));
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + frag_off(rowA[i], kk));
+            for (int j = 0; j < NJ; ++j) b[0][j] = *reinterpret_cast<const bf16x8*>(sw + frag_off(rowB[j], 0));
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sw + frag_off(rowB[j], kk));
+            for (int kk = 0; kk < KK; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < KK) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        a[nxt][i] = *reinterpret_cast<const bf16x8*>(sa + frag_off(rowA[i], kk + 1));
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        b[nxt][j] = *reinterpret_cast<const bf16x8*>(sw + frag_off(rowB[j], kk + 1));
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            } else {
-                f16x8 ah[2], al[2], bh[NJ], bl[NJ];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                if (more) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    ah[i] = *reinterpret_cast<const f16x8*>(sa + frag_off(rowA[i], kk));
-                    al[i] = *reinterpret_cast<const f16x8*>(sa + A_TILE + frag_off(rowA[i], kk));
+                    for (int i = kk * CPW / KK; i < (kk + 1) * CPW / KK; ++i) stage_piece(nst, nk0, i);
                 }
+            }
+        } else {
+            f16x8 ah[2][2], al[2][2], bh[2][NJ], bl[2][NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    bh[j] = *reinterpret_cast<const f16x8*>(sw + frag_off(rowB[j], kk));
-                    bl[j] = *reinterpret_cast<const f16x8*>(sw + W_TILE + frag_off(rowB[j], kk));
+            for (int i = 0; i < 2; ++i) {
+                ah[0][i] = *reinterpret_cast<const f16x8*>(sa + frag_off(rowA[i], 0));
+                al[0][i] = *reinterpret_cast<const f16x8*>(sa + A_TILE + frag_off(rowA[i], 0));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[0][j] = *reinterpret_cast<const f16x8*>(sw + frag_off(rowB[j], 0));
+                bl[0][j] = *reinterpret_cast<const f16x8*>(sw + W_TILE + frag_off(rowB[j], 0));
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < KK) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        ah[nxt][i] = *reinterpret_cast<const f16x8*>(sa + frag_off(rowA[i], kk + 1));
+                        al[nxt][i] = *reinterpret_cast<const f16x8*>(sa + A_TILE + frag_off(rowA[i], kk + 1));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        bh[nxt][j] = *reinterpret_cast<const f16x8*>(sw + frag_off(rowB[j], kk + 1));
+                        bl[nxt][j] = *reinterpret_cast<const f16x8*>(sw + W_TILE + frag_off(rowB[j], kk + 1));
+                    }
                 }
                 // three sweeps over the tiles so that no accumulator is touched by two consecutive MFMAs
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+                if (more) {
+#pragma unroll
+                    for (int i = (2 * kk) * CPW / (2 * KK); i < (2 * kk + 1) * CPW / (2 * KK); ++i) stage_piece(nst, nk0, i);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], corr[i][j], 0, 0, 0);
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur][j], corr[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], corr[i][j], 0, 0, 0);
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur][j], corr[i][j], 0, 0, 0);
+                if (more) {
+#pragma unroll
+                    for (int i = (2 * kk + 1) * CPW / (2 * KK); i < (2 * kk + 2) * CPW / (2 * KK); ++i)
+                        stage_piece(nst, nk0, i);
+                }
             }
         }
     }
