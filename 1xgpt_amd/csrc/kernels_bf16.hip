@@ -491,7 +491,11 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
     if (M <= 0 || N <= 0) return GENIE_OK;
     const double mn = (double)M * N * batch;
     static const int force_v1 = [] { const char* e = getenv("GENIE_GEMM16_V1"); return e ? atoi(e) : 0; }();
-    if (!force_v1 && M >= 256 && N % 4 == 0 && ldc % 4 == 0) {
+    // small problems (batch-1 generate: M = 4096 or 256 rows): 256x128 tiles would leave most of the 256 CUs idle, the
+    // 128x128 kernel below makes 2x the workgroups (and runs two of them per CU)
+    const long tiles_v2 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
+    const bool small = tiles_v2 < 160;
+    if (!force_v1 && !small && M >= 256 && N % 4 == 0 && ldc % 4 == 0) {
         const int mt2 = (M + 255) / 256, nt2 = (N + 127) / 128;
         const size_t lds2 = 3 * 48 * 1024;
         ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
