@@ -100,4 +100,31 @@ int launch_gemm_bf16_out16(const uint16_t* A16, const uint16_t* W16, const float
                            hipStream_t st);
 int launch_pack_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t st);
 
+// ---- training step (kernels_train.hip) ----
+// C[b1][b2][M,N] = alpha * A.B (+bias) (+R); ta/tb: operand stored k-major; nsplit > 1: slabs C + s*sCsplit
+int launch_gemm_f32_gen(bool ta, bool tb, const float* A, long lda, long sA1, long sA2, const float* W, long ldw, long sW1,
+                        long sW2, const float* bias, const float* R, float* C, long ldc, long sC1, long sC2, int M, int N,
+                        int K, int batch1, int batch2, int nsplit, long sCsplit, float alpha, hipStream_t st);
+int launch_slab_reduce(const float* part, int ns, size_t n, float* out, float beta, hipStream_t st);
+int launch_wgrad_f32(const float* dY, long ldy, const float* X, long ldx, float* dW, int Mtok, int N, int K, float alpha,
+                     float beta, float* slabs, size_t slab_floats, hipStream_t st);
+constexpr int COLSUM_SCRATCH_ROWS = 256;
+int launch_colsum(const float* Y, long ld, long rows, int N, float* out, float beta, float* part, hipStream_t st);
+size_t ln_bwd_scratch_floats(int C);
+int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dxout, float* dgamma, float* dbeta,
+                  long rows, int C, float eps, float beta, float* part, hipStream_t st);
+int launch_gelu_fwd(const float* z, float* h, size_t n, hipStream_t st);
+int launch_gelu_bwd(const float* z, float* g, size_t n, hipStream_t st);
+int launch_softmax_rows(float* P, long rows, int N, hipStream_t st);
+int launch_softmax_bwd_rows(const float* P, float* dP, long rows, int N, hipStream_t st);
+int launch_attn_temporal_bwd(const float* qkv, const float* dO, float* dqkv, int B, int T, int S, int d, int H, int Dh,
+                             float scale, hipStream_t st);
+int launch_ce_fwd_bwd(const genie_cfg& c, float* logits, const int64_t* ids, const int64_t* labels, int B, double* sums,
+                      hipStream_t st);
+int launch_embed_bwd(const genie_cfg& c, const float* dx, const int64_t* ids, int B, float* dpos, float* dmask,
+                     float* const* tables_host, float beta, hipStream_t st);
+int launch_sumsq(const float* x, size_t n, double* out, double* scratch, hipStream_t st);
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, float grad_mult, const double* sumsq, float max_norm, hipStream_t st);
+
 }  // namespace genie

@@ -1,0 +1,752 @@
+// Kernels of the training step: what autograd derives for STMaskGIT.forward
+// (genie/st_mask_git.py:231-279) plus the optimizer of train.py:426-441, 628-633.  f32 throughout ("exact"
+// precision): every contraction runs on v_mfma_f32_32x32x2_f32 through ONE general GEMM that reads either operand
+// in either orientation, so no activation or weight is ever physically transposed for a backward product:
+//     forward   Y  = X . W^T          A = X  [rows][k]      B = W  [cols][k]
+//     dgrad     dX = dY . W           A = dY [rows][k]      B = W  [k][cols]   (TB)
+//     wgrad     dW = dY^T . X         A = dY [k][rows] (TA) B = X  [k][cols]   (TB), split over the token axis
+// All reductions that feed a gradient (split-K partials, LayerNorm / bias column sums, embedding scatter) are
+// two-stage with a fixed summation order: a training step is bit-reproducible run to run.
+#include "kernels.hpp"
+
+namespace genie {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// C[b1][b2][M,N] = alpha * sum_k A(m,k) B(n,k) (+ bias[n]) (+ R[m,n])
+//   TA: A(m,k) = A[k*lda + m] else A[m*lda + k];   TB: B(n,k) = W[k*ldw + n] else W[n*ldw + k]
+//   blockIdx.y = b1, blockIdx.z = b2 * nsplit + split; split s contracts k in [s*K/nsplit, (s+1)*K/nsplit) and
+//   writes its own slab C + s*sCsplit (no bias / residual there; splitk_reduce adds the slabs in order).
+// 128x128x16 tile, 4 waves (2x2) x 64x64, double-buffered LDS.  Row-major operands use the k-permuted
+// ds_read_b128 fetch of gemm_f32_nt_kernel (kernels_exact.hip); k-major operands are staged as they lie
+// ([16][128] floats, coalesced float4) and fetched with one conflict-free ds_read_b32 per MFMA -- the f32 MFMA
+// issues every 64 cycles per SIMD, so four narrow LDS reads per four MFMAs stay hidden.
+// ------------------------------------------------------------------------------------------------
+constexpr int GG_BM = 128, GG_BK = 16, GG_LD = GG_BK + 4, GG_TLD = GG_BM + 4;
+constexpr int GG_TILE = GG_BM * GG_LD;  // 2560 floats >= 16 * 132
+
+template <bool TR>
+__device__ __forceinline__ void gg_stage_load(const float* __restrict__ G, long ld, int row0, int limit, int k0, int tid,
+                                              float4 (&regs)[2]) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if constexpr (!TR) {
+            const int row = row0 + (tid >> 2) + p * 64;
+            regs[p] = row < limit ? *reinterpret_cast<const float4*>(G + (size_t)row * ld + k0 + ((tid & 3) << 2)) : z4;
+        } else {
+            const int kr = (tid >> 5) + p * 8, c4 = (tid & 31) << 2;
+            regs[p] = (row0 + c4) < limit ? *reinterpret_cast<const float4*>(G + (size_t)(k0 + kr) * ld + row0 + c4) : z4;
+        }
+    }
+}
+template <bool TR>
+__device__ __forceinline__ void gg_stage_store(float* s, int tid, const float4 (&regs)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if constexpr (!TR)
+            *reinterpret_cast<float4*>(&s[((tid >> 2) + p * 64) * GG_LD + ((tid & 3) << 2)]) = regs[p];
+        else
+            *reinterpret_cast<float4*>(&s[((tid >> 5) + p * 8) * GG_TLD + ((tid & 31) << 2)]) = regs[p];
+    }
+}
+// the four k-values (8kk + 4h + j, j = 0..3) of operand row `row` that MFMA j consumes
+template <bool TR>
+__device__ __forceinline__ float4 gg_frag(const float* s, int row, int kk, int h) {
+    if constexpr (!TR) return *reinterpret_cast<const float4*>(&s[row * GG_LD + kk * 8 + 4 * h]);
+    const float* p = s + (kk * 8 + 4 * h) * GG_TLD + row;
+    return make_float4(p[0], p[GG_TLD], p[2 * GG_TLD], p[3 * GG_TLD]);
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_gen_kernel(const float* __restrict__ A, long lda, long sA1, long sA2,
+                                                           const float* __restrict__ W, long ldw, long sW1, long sW2,
+                                                           const float* __restrict__ bias, const float* R,
+                                                           float* C, long ldc, long sC1, long sC2, int M, int N, int K,
+                                                           float alpha, int nsplit, long sCsplit) {
+    __shared__ __attribute__((aligned(16))) float sA[2][GG_TILE];
+    __shared__ __attribute__((aligned(16))) float sB[2][GG_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tiles = (N + GG_BM - 1) / GG_BM;
+    const int m0 = (blockIdx.x / n_tiles) * GG_BM, n0 = (blockIdx.x % n_tiles) * GG_BM;
+    const int b2 = blockIdx.z / nsplit, sp = blockIdx.z - b2 * nsplit;
+    A += (size_t)blockIdx.y * sA1 + (size_t)b2 * sA2;
+    W += (size_t)blockIdx.y * sW1 + (size_t)b2 * sW2;
+    const size_t coff = (size_t)blockIdx.y * sC1 + (size_t)b2 * sC2 + (size_t)sp * sCsplit;
+    C += coff;
+    if (R) R += coff;
+    const int kc = K / nsplit, kbeg = sp * kc;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[2], rb[2];
+    const int nk = kc / GG_BK;
+    gg_stage_load<TA>(A, lda, m0, M, kbeg, tid, ra);
+    gg_stage_load<TB>(W, ldw, n0, N, kbeg, tid, rb);
+    gg_stage_store<TA>(sA[0], tid, ra);
+    gg_stage_store<TB>(sB[0], tid, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            gg_stage_load<TA>(A, lda, m0, M, kbeg + (kt + 1) * GG_BK, tid, ra);
+            gg_stage_load<TB>(W, ldw, n0, N, kbeg + (kt + 1) * GG_BK, tid, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GG_BK / 8; ++kk) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = gg_frag<TA>(sA[buf], wm * 64 + i * 32 + r, kk, h);
+                b[i] = gg_frag<TB>(sB[buf], wn * 64 + i * 32 + r, kk, h);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) {
+            gg_stage_store<TA>(sA[buf ^ 1], tid, ra);
+            gg_stage_store<TB>(sB[buf ^ 1], tid, rb);
+        }
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+            if (col >= N) continue;
+            const float bcol = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                const size_t idx = (size_t)row * ldc + col;
+                float v = acc[i][j][e] * alpha + bcol;
+                if (R) v += R[idx];
+                C[idx] = v;
+            }
+        }
+}
+
+int launch_gemm_f32_gen(bool ta, bool tb, const float* A, long lda, long sA1, long sA2, const float* W, long ldw, long sW1,
+                        long sW2, const float* bias, const float* R, float* C, long ldc, long sC1, long sC2, int M, int N,
+                        int K, int batch1, int batch2, int nsplit, long sCsplit, float alpha, hipStream_t st) {
+    GENIE_CHECK_SHAPE(K > 0 && nsplit > 0 && K % (GG_BK * nsplit) == 0,
+                      "gemm_gen: K=%d must be a positive multiple of %d", K, GG_BK * nsplit);
+    GENIE_CHECK_SHAPE(lda % 4 == 0 && ldw % 4 == 0, "gemm_gen: leading dims must be multiples of 4 floats");
+    GENIE_CHECK_SHAPE((!ta || M % 4 == 0) && (!tb || N % 4 == 0), "gemm_gen: k-major operands need row counts % 4 == 0");
+    if (M <= 0 || N <= 0 || batch1 <= 0 || batch2 <= 0) return GENIE_OK;
+    const int mt = (M + GG_BM - 1) / GG_BM, nt = (N + GG_BM - 1) / GG_BM;
+    dim3 grid(mt * nt, batch1, batch2 * nsplit);
+    const double mn = (double)M * N * batch1 * batch2;
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
+                   4.0 * (((double)M * K + (double)N * K) * batch1 * batch2 + mn * nsplit * (R ? 2 : 1)), st);
+#define GG_LAUNCH(TA_, TB_)                                                                                          \
+    gemm_f32_gen_kernel<TA_, TB_><<<grid, 256, 0, st>>>(A, lda, sA1, sA2, W, ldw, sW1, sW2, bias, R, C, ldc, sC1, sC2, \
+                                                        M, N, K, alpha, nsplit, sCsplit)
+    if (!ta && !tb) GG_LAUNCH(false, false);
+    else if (!ta && tb) GG_LAUNCH(false, true);
+    else if (ta && tb) GG_LAUNCH(true, true);
+    else GG_LAUNCH(true, false);
+#undef GG_LAUNCH
+    GENIE_LAUNCH_CHECK("gemm_f32_gen");
+    return GENIE_OK;
+}
+
+// out[i] = beta * out[i] + sum_{s < ns} part[s*n + i]   (fixed order)
+__global__ void slab_reduce_kernel(const float* __restrict__ part, int ns, size_t n, float* __restrict__ out, float beta) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < ns; ++k) s += part[(size_t)k * n + i];
+    out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
+}
+int launch_slab_reduce(const float* part, int ns, size_t n, float* out, float beta, hipStream_t st) {
+    if (!n) return GENIE_OK;
+    slab_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, ns, n, out, beta);
+    GENIE_LAUNCH_CHECK("slab_reduce");
+    return GENIE_OK;
+}
+
+// dW[N,K] (beta*dW +)= alpha * dY[M,N]^T . X[M,K], contraction over the M tokens split into slabs
+int launch_wgrad_f32(const float* dY, long ldy, const float* X, long ldx, float* dW, int Mtok, int N, int K, float alpha,
+                     float beta, float* slabs, size_t slab_floats, hipStream_t st) {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int ns = 1;
+    while (ns < 64 && tiles * ns < 512 && Mtok % (GG_BK * ns * 2) == 0 && (size_t)(ns * 2) * N * K <= slab_floats) ns *= 2;
+    if (ns == 1)
+        return launch_gemm_f32_gen(true, true, dY, ldy, 0, 0, X, ldx, 0, 0, nullptr, beta != 0.f ? dW : nullptr, dW, K, 0, 0,
+                                   N, K, Mtok, 1, 1, 1, 0, alpha, st);
+    GENIE_CHECK_ARG(beta == 0.f || beta == 1.f, "wgrad: beta must be 0 or 1");
+    GENIE_TRY(launch_gemm_f32_gen(true, true, dY, ldy, 0, 0, X, ldx, 0, 0, nullptr, nullptr, slabs, K, 0, 0, N, K, Mtok, 1,
+                                  1, ns, (long)N * K, alpha, st));
+    return launch_slab_reduce(slabs, ns, (size_t)N * K, dW, beta, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients): part[chunk][N] = sum over the chunk's rows, then slab_reduce
+// ------------------------------------------------------------------------------------------------
+__global__ void colsum_partial_kernel(const float* __restrict__ Y, long ld, long rows, int N, float* __restrict__ part) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += Y[(size_t)r * ld + c];
+    part[(size_t)blockIdx.y * N + c] = s;
+}
+constexpr int COLSUM_CHUNKS = 256;
+int launch_colsum(const float* Y, long ld, long rows, int N, float* out, float beta, float* part, hipStream_t st) {
+    if (rows <= 0 || N <= 0) return GENIE_OK;
+    colsum_partial_kernel<<<dim3((N + 255) / 256, COLSUM_CHUNKS), 256, 0, st>>>(Y, ld, rows, N, part);
+    GENIE_LAUNCH_CHECK("colsum");
+    return launch_slab_reduce(part, COLSUM_CHUNKS, (size_t)N, out, beta, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (nn.LayerNorm(C, eps), biased variance): one wave per row, statistics recomputed from x.
+//   dxout[row] += (gy - mean(gy) - xhat * mean(gy * xhat)) * rstd,  gy = dy * gamma
+//   part[block][0][C] = sum_rows dy * xhat, part[block][1][C] = sum_rows dy   (then slab_reduce -> dgamma, dbeta)
+// ------------------------------------------------------------------------------------------------
+constexpr int LNB_MAXI = 16;  // C <= 1024
+constexpr int LNB_BLOCKS = 512;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, float* __restrict__ dxout,
+                                                     float* __restrict__ part, long rows, int C, float eps) {
+    extern __shared__ float red[];  // [4][2][C]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float dg[LNB_MAXI], db[LNB_MAXI], gm[LNB_MAXI];
+#pragma unroll
+    for (int i = 0; i < LNB_MAXI; ++i) {
+        dg[i] = 0.f; db[i] = 0.f;
+        const int c = lane + 64 * i;
+        gm[i] = c < C ? gamma[c] : 0.f;
+    }
+    const float invC = 1.0f / (float)C;
+    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
+        const float* xr = x + (size_t)row * C;
+        const float* dr = dy + (size_t)row * C;
+        float xv[LNB_MAXI], dv[LNB_MAXI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXI; ++i) {
+            const int c = lane + 64 * i;
+            xv[i] = c < C ? xr[c] : 0.f;
+            dv[i] = c < C ? dr[c] : 0.f;
+            s += xv[i];
+        }
+        const float mean = wave_sum(s) * invC;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXI; ++i) {
+            const int c = lane + 64 * i;
+            const float xc = c < C ? xv[i] - mean : 0.f;
+            xv[i] = xc;
+            v += xc * xc;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) * invC + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXI; ++i) {
+            xv[i] *= rstd;  // xhat
+            const float gy = dv[i] * gm[i];
+            s1 += gy;
+            s2 += gy * xv[i];
+            dg[i] += dv[i] * xv[i];
+            db[i] += dv[i];
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+        float* o = dxout + (size_t)row * C;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXI; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) o[c] += (dv[i] * gm[i] - s1 - xv[i] * s2) * rstd;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LNB_MAXI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) { red[(wid * 2 + 0) * C + c] = dg[i]; red[(wid * 2 + 1) * C + c] = db[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int which = c / C, cc = c - which * C;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * C + cc];
+        part[(size_t)blockIdx.x * 2 * C + c] = s;  // [block][which][C]
+    }
+}
+// part slabs are [block][2][C]: dgamma = reduce of the first C, dbeta of the second C
+int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dxout, float* dgamma, float* dbeta,
+                  long rows, int C, float eps, float beta, float* part, hipStream_t st) {
+    GENIE_CHECK_SHAPE(C <= 64 * LNB_MAXI, "ln_bwd: C=%d > %d", C, 64 * LNB_MAXI);
+    if (rows <= 0) return GENIE_OK;
+    ProfScope prof(GENIE_KC_LAYERNORM, 12.0 * rows * C, 16.0 * rows * C, st);
+    ln_bwd_kernel<<<LNB_BLOCKS, 256, (size_t)8 * C * sizeof(float), st>>>(x, gamma, dy, dxout, part, rows, C, eps);
+    GENIE_LAUNCH_CHECK("ln_bwd");
+    // the two halves of each slab are contiguous ([2][C]), so one reduce of 2C columns serves both when dbeta follows
+    // dgamma in memory; they need not, so reduce separately through strided views
+    float* tmp = part + (size_t)LNB_BLOCKS * 2 * C;  // [2][C] reduced
+    GENIE_TRY(launch_slab_reduce(part, LNB_BLOCKS, (size_t)2 * C, tmp, 0.f, st));
+    GENIE_TRY(launch_slab_reduce(tmp, 1, (size_t)C, dgamma, beta, st));
+    return launch_slab_reduce(tmp + C, 1, (size_t)C, dbeta, beta, st);
+}
+size_t ln_bwd_scratch_floats(int C) { return (size_t)(LNB_BLOCKS + 1) * 2 * C; }
+
+// ------------------------------------------------------------------------------------------------
+// erf-GELU forward (saving the pre-activation) and backward: dz = dh * (Phi(z) + z * phi(z))
+// ------------------------------------------------------------------------------------------------
+__global__ void gelu_fwd_kernel(const float4* __restrict__ z, float4* __restrict__ h, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = z[i];
+    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+    h[i] = v;
+}
+__device__ __forceinline__ float gelu_grad(float z) {
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    const float pdf = expf(-0.5f * z * z) * 0.39894228040143267794f;
+    return cdf + z * pdf;
+}
+__global__ void gelu_bwd_kernel(const float4* __restrict__ z, float4* __restrict__ g, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 zz = z[i];
+    float4 v = g[i];
+    v.x *= gelu_grad(zz.x); v.y *= gelu_grad(zz.y); v.z *= gelu_grad(zz.z); v.w *= gelu_grad(zz.w);
+    g[i] = v;
+}
+int launch_gelu_fwd(const float* z, float* h, size_t n, hipStream_t st) {
+    GENIE_CHECK_SHAPE(n % 4 == 0, "gelu: n %% 4");
+    if (!n) return GENIE_OK;
+    gelu_fwd_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>((const float4*)z, (float4*)h, n / 4);
+    GENIE_LAUNCH_CHECK("gelu_fwd");
+    return GENIE_OK;
+}
+int launch_gelu_bwd(const float* z, float* g, size_t n, hipStream_t st) {
+    GENIE_CHECK_SHAPE(n % 4 == 0, "gelu: n %% 4");
+    if (!n) return GENIE_OK;
+    gelu_bwd_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>((const float4*)z, (float4*)g, n / 4);
+    GENIE_LAUNCH_CHECK("gelu_bwd");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row softmax (in place) and its backward dS = P * (dP - sum_j P dP) (in place on dP); one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ P, long rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = P + (size_t)row * N;
+    float m = -INFINITY;
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, p[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) { const float e = expf(p[j] - m); p[j] = e; s += e; }
+    const float inv = 1.0f / wave_sum(s);
+    for (int j = lane; j < N; j += 64) p[j] *= inv;
+}
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP,
+                                                               long rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = P + (size_t)row * N;
+    float* g = dP + (size_t)row * N;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += p[j] * g[j];
+    s = wave_sum(s);
+    for (int j = lane; j < N; j += 64) g[j] = p[j] * (g[j] - s);
+}
+int launch_softmax_rows(float* P, long rows, int N, hipStream_t st) {
+    if (rows <= 0) return GENIE_OK;
+    softmax_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(P, rows, N);
+    GENIE_LAUNCH_CHECK("softmax_rows");
+    return GENIE_OK;
+}
+int launch_softmax_bwd_rows(const float* P, float* dP, long rows, int N, hipStream_t st) {
+    if (rows <= 0) return GENIE_OK;
+    softmax_bwd_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(P, dP, rows, N);
+    GENIE_LAUNCH_CHECK("softmax_bwd_rows");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Temporal (causal, N = T <= 16 frames) attention backward on the frame-strided rows of (B,T,S,3d) -- the
+// "(B S) T C" view of st_transformer.py:77 without a transpose.  One thread per (sequence, head, frame i);
+// a block holds GPB (sequence, head) groups of 16 threads; q (pre-scaled), k, v, dO rows sit in LDS.
+//   p_ij = softmax_j(scale q_i.k_j), j <= i;  dp_ij = dO_i.v_j;  ds_ij = p_ij (dp_ij - sum_j p_ij dp_ij)
+//   dq_i = scale sum_j ds_ij k_j;  dk_j = scale sum_{i>=j} ds_ij q_i;  dv_j = sum_{i>=j} p_ij dO_i
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                               float* __restrict__ dqkv, int B, int T, int S, int d, int H,
+                                                               float scale) {
+    constexpr int GPB = 4, NMAX = 16, DHP = DH + 4;  // padded rows: threads of a group read different rows, same column
+    extern __shared__ float sm[];
+    const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
+    float* sq = sm + (size_t)g * (4 * NMAX * DHP + 2 * NMAX * NMAX);
+    float* sk = sq + NMAX * DHP;
+    float* sv = sk + NMAX * DHP;
+    float* sd = sv + NMAX * DHP;
+    float* sp = sd + NMAX * DHP;  // [i][j]
+    float* sds = sp + NMAX * NMAX;
+    const long grp = (long)blockIdx.x * GPB + g;  // (b, s, head)
+    const long n_grp = (long)B * S * H;
+    const bool active = grp < n_grp && i < T;
+    long row = 0;
+    int head = 0;
+    if (active) {
+        head = (int)(grp % H);
+        const long bs = grp / H;
+        const long b = bs / S, s = bs - b * S;
+        row = (b * T + i) * (long)S + s;
+        const float* base = qkv + (size_t)row * 3 * d + head * DH;
+        const float* dob = dO + (size_t)row * d + head * DH;
+#pragma unroll 4
+        for (int c = 0; c < DH; c += 4) {
+            float4 q4 = *reinterpret_cast<const float4*>(base + c);
+            q4.x *= scale; q4.y *= scale; q4.z *= scale; q4.w *= scale;
+            *reinterpret_cast<float4*>(sq + i * DHP + c) = q4;
+            *reinterpret_cast<float4*>(sk + i * DHP + c) = *reinterpret_cast<const float4*>(base + d + c);
+            *reinterpret_cast<float4*>(sv + i * DHP + c) = *reinterpret_cast<const float4*>(base + 2 * d + c);
+            *reinterpret_cast<float4*>(sd + i * DHP + c) = *reinterpret_cast<const float4*>(dob + c);
+        }
+    }
+    __syncthreads();
+    float acc[DH];
+    if (active) {
+        float p[NMAX], dp[NMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            float s = 0.f, t = 0.f;
+            if (j <= i) {
+#pragma unroll 8
+                for (int c = 0; c < DH; ++c) {
+                    s = fmaf(sq[i * DHP + c], sk[j * DHP + c], s);
+                    t = fmaf(sd[i * DHP + c], sv[j * DHP + c], t);
+                }
+                m = fmaxf(m, s);
+            }
+            p[j] = s; dp[j] = t;
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            p[j] = j <= i ? expf(p[j] - m) : 0.f;
+            l += p[j];
+        }
+        const float inv = 1.0f / l;
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) { p[j] *= inv; dsum += p[j] * dp[j]; }
+#pragma unroll
+        for (int c = 0; c < DH; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            const float ds = p[j] * (dp[j] - dsum);  // p[j] = 0 beyond the causal bound
+            sp[i * NMAX + j] = p[j];
+            sds[i * NMAX + j] = ds;
+            if (j <= i) {
+#pragma unroll 8
+                for (int c = 0; c < DH; ++c) acc[c] = fmaf(ds, sk[j * DHP + c], acc[c]);
+            }
+        }
+        float* o = dqkv + (size_t)row * 3 * d + head * DH;
+#pragma unroll 4
+        for (int c = 0; c < DH; c += 4)
+            *reinterpret_cast<float4*>(o + c) =
+                make_float4(acc[c] * scale, acc[c + 1] * scale, acc[c + 2] * scale, acc[c + 3] * scale);
+    }
+    __syncthreads();
+    if (active) {
+        const int j = i;
+        float* o = dqkv + (size_t)row * 3 * d + head * DH;
+        // dk_j: sq holds scale*q, so sum_i ds_ij * sq_i is already the scaled product
+#pragma unroll
+        for (int c = 0; c < DH; ++c) acc[c] = 0.f;
+        for (int ii = j; ii < T; ++ii) {
+            const float ds = sds[ii * NMAX + j];
+#pragma unroll 8
+            for (int c = 0; c < DH; ++c) acc[c] = fmaf(ds, sq[ii * DHP + c], acc[c]);
+        }
+#pragma unroll 4
+        for (int c = 0; c < DH; c += 4)
+            *reinterpret_cast<float4*>(o + d + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+#pragma unroll
+        for (int c = 0; c < DH; ++c) acc[c] = 0.f;
+        for (int ii = j; ii < T; ++ii) {
+            const float pp = sp[ii * NMAX + j];
+#pragma unroll 8
+            for (int c = 0; c < DH; ++c) acc[c] = fmaf(pp, sd[ii * DHP + c], acc[c]);
+        }
+#pragma unroll 4
+        for (int c = 0; c < DH; c += 4)
+            *reinterpret_cast<float4*>(o + 2 * d + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    }
+}
+int launch_attn_temporal_bwd(const float* qkv, const float* dO, float* dqkv, int B, int T, int S, int d, int H, int Dh,
+                             float scale, hipStream_t st) {
+    GENIE_CHECK_SHAPE(T <= 16, "temporal attention backward: T=%d > 16", T);
+    const long n_grp = (long)B * S * H;
+    if (n_grp <= 0) return GENIE_OK;
+    const unsigned blocks = (unsigned)((n_grp + 3) / 4);
+    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 10.0 * n_grp * T * T * Dh, 4.0 * n_grp * T * Dh * 7, st);
+#define TB_LAUNCH(DH_)                                                                                       \
+    {                                                                                                        \
+        const size_t lds = (size_t)4 * (4 * 16 * (DH_ + 4) + 2 * 16 * 16) * sizeof(float);                        \
+        (void)hipFuncSetAttribute((const void*)attn_temporal_bwd_kernel<DH_>,                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        attn_temporal_bwd_kernel<DH_><<<blocks, 64, lds, st>>>(qkv, dO, dqkv, B, T, S, d, H, scale);         \
+    }
+    if (Dh == 64) TB_LAUNCH(64)
+    else if (Dh == 32) TB_LAUNCH(32)
+    else if (Dh == 128) TB_LAUNCH(128)
+    else {
+        set_error("temporal attention backward: head_dim %d not in {32, 64, 128}", Dh);
+        return GENIE_E_UNSUPPORTED;
+    }
+#undef TB_LAUNCH
+    GENIE_LAUNCH_CHECK("attn_temporal_bwd");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// masked factored cross-entropy, forward and backward in one pass (st_mask_git.py:231-253, 276):
+//   counted(token) = frame >= 1 and input id == MASK;  n = number of counted tokens (count_masked_kernel)
+//   sums += [sum ce, sum all-factors-correct, (n is written by the count kernel)]
+//   logits row (V = nfac*vf) is REPLACED by d loss / d logits = counted ? (softmax_f - onehot_f) / n : 0
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void count_masked_kernel(const int64_t* __restrict__ ids, long B, int T, int S,
+                                                            int64_t mask_id, double* __restrict__ sums) {
+    __shared__ unsigned long long red[16];
+    unsigned long long c = 0;
+    const long n = B * T * (long)S;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const int t = (int)((i / S) % T);
+        c += (t >= 1 && ids[i] == mask_id) ? 1ull : 0ull;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int w = 0; w < 16; ++w) s += red[w];
+        sums[2] = (double)s;
+    }
+}
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(float* __restrict__ logits, const int64_t* __restrict__ ids,
+                                                         const int64_t* __restrict__ labels, long n_tok, int T, int S,
+                                                         int vf, int nfac, int64_t mask_id, double* __restrict__ sums) {
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long n = (long)blockIdx.x * 4 + wid;
+    double ce = 0, hit = 0;
+    if (n < n_tok) {
+        float* lp = logits + (size_t)n * vf * nfac;
+        const int t = (int)((n / S) % T);
+        const bool counted = t >= 1 && ids[n] == mask_id;
+        if (!counted) {
+            for (int k = lane; k < vf * nfac; k += 64) lp[k] = 0.f;
+        } else {
+            const float wgt = (float)(1.0 / sums[2]);
+            int64_t tgt = labels[n];
+            float loss = 0.f;
+            bool all_ok = true;
+            for (int f = 0; f < nfac; ++f) {
+                const int tf = (int)(tgt % vf);
+                tgt /= vf;
+                float* lf = lp + f * vf;
+                float mx = -INFINITY;
+                int mi = 0;
+                for (int k = lane; k < vf; k += 64) {
+                    const float v = lf[k];
+                    if (v > mx) { mx = v; mi = k; }
+                }
+                wave_argmax(mx, mi);
+                float se = 0.f;
+                for (int k = lane; k < vf; k += 64) se += expf(lf[k] - mx);
+                se = wave_sum(se);
+                loss += logf(se) + mx - lf[tf];
+                all_ok = all_ok && (mi == tf);
+                const float inv = 1.0f / se;
+                for (int k = lane; k < vf; k += 64) {
+                    const float p = expf(lf[k] - mx) * inv;
+                    lf[k] = (p - (k == tf ? 1.0f : 0.0f)) * wgt;
+                }
+            }
+            if (lane == 0) { ce = loss; hit = all_ok ? 1.0 : 0.0; }
+        }
+    }
+    if (lane == 0) { red[0][wid] = ce; red[1][wid] = hit; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+        for (int w = 0; w < 4; ++w) { a += red[0][w]; b += red[1][w]; }
+        if (a != 0.0 || b != 0.0) { atomicAdd(&sums[0], a); atomicAdd(&sums[1], b); }
+    }
+}
+int launch_ce_fwd_bwd(const genie_cfg& c, float* logits, const int64_t* ids, const int64_t* labels, int B, double* sums,
+                      hipStream_t st) {
+    const long n_tok = (long)B * c.T * c.S;
+    if (n_tok <= 0) return GENIE_OK;
+    count_masked_kernel<<<1, 1024, 0, st>>>(ids, B, c.T, c.S, (int64_t)c.image_vocab_size, sums);
+    GENIE_LAUNCH_CHECK("count_masked");
+    ce_fwd_bwd_kernel<<<(unsigned)((n_tok + 3) / 4), 256, 0, st>>>(logits, ids, labels, n_tok, c.T, c.S, c.factored_vocab,
+                                                                  c.num_factored, (int64_t)c.image_vocab_size, sums);
+    GENIE_LAUNCH_CHECK("ce_fwd_bwd");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding backward (factorization_utils.py:29-52, st_mask_git.py:257-261), scatter-free and ordered:
+//   dpos[t,s,:]  = sum_b dx[b,t,s,:]
+//   row v of table f (block f*vf + v): sum over tokens n (ascending) with factor_f(id_n) == v and id_n != MASK
+//   mask row (last block): sum over tokens with id_n == MASK
+// ------------------------------------------------------------------------------------------------
+struct EmbedTables { float* p[4]; };
+__global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int B, size_t per_clip,
+                                     float beta) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_clip) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[(size_t)b * per_clip + i];
+    dpos[i] = (beta != 0.f ? beta * dpos[i] : 0.f) + s;
+}
+__global__ __launch_bounds__(256) void embed_bwd_tables_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
+                                                               long n_tok, int d, int vf, int nfac, int64_t mask_id,
+                                                               EmbedTables tables, float* __restrict__ dmask,
+                                                               float beta) {
+    __shared__ int64_t sid[1024];
+    const int blk = blockIdx.x;
+    const bool is_mask_row = blk == nfac * vf;
+    const int f = is_mask_row ? 0 : blk / vf, v = is_mask_row ? 0 : blk - f * vf;
+    int64_t div = 1;
+    for (int k = 0; k < f; ++k) div *= vf;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // channels threadIdx.x + 256*k, d <= 1024
+    for (long base = 0; base < n_tok; base += 1024) {
+        const int cnt = (int)((n_tok - base) < 1024 ? (n_tok - base) : 1024);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) sid[i] = ids[base + i];
+        __syncthreads();
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t id = sid[i];
+            const bool m = is_mask_row ? (id == mask_id) : (id != mask_id && (int)((id / div) % vf) == v);
+            if (m) {
+                const float* r = dx + (size_t)(base + i) * d;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = threadIdx.x + 256 * k;
+                    if (c < d) acc[k] += r[c];
+                }
+            }
+        }
+    }
+    float* out = is_mask_row ? dmask : tables.p[f] + (size_t)v * d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < d) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + acc[k];
+    }
+}
+int launch_embed_bwd(const genie_cfg& c, const float* dx, const int64_t* ids, int B, float* dpos, float* dmask,
+                     float* const* tables_host, float beta, hipStream_t st) {
+    EmbedTables tables_dev;
+    for (int j = 0; j < 4; ++j) tables_dev.p[j] = j < c.num_factored ? tables_host[j] : nullptr;
+    GENIE_CHECK_SHAPE(c.d_model <= 1024, "embed backward: d_model > 1024");
+    const size_t per_clip = (size_t)c.T * c.S * c.d_model;
+    embed_bwd_pos_kernel<<<(unsigned)((per_clip + 255) / 256), 256, 0, st>>>(dx, dpos, B, per_clip, beta);
+    GENIE_LAUNCH_CHECK("embed_bwd_pos");
+    embed_bwd_tables_kernel<<<c.num_factored * c.factored_vocab + 1, 256, 0, st>>>(
+        dx, ids, (long)B * c.T * c.S, c.d_model, c.factored_vocab, c.num_factored, (int64_t)c.image_vocab_size, tables_dev,
+        dmask, beta);
+    GENIE_LAUNCH_CHECK("embed_bwd_tables");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer: sum of squares (two-stage, f64) and torch.optim.AdamW's update with clip_grad_norm_ folded in
+// ------------------------------------------------------------------------------------------------
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, size_t n, double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = x[i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        *out += s;
+    }
+}
+int launch_sumsq(const float* x, size_t n, double* out, double* scratch, hipStream_t st) {
+    if (!n) return GENIE_OK;
+    sumsq_partial_kernel<<<SUMSQ_BLOCKS, 256, 0, st>>>(x, n, scratch);
+    GENIE_LAUNCH_CHECK("sumsq");
+    sumsq_final_kernel<<<1, 64, 0, st>>>(scratch, SUMSQ_BLOCKS, out);
+    GENIE_LAUNCH_CHECK("sumsq_final");
+    return GENIE_OK;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float beta1, float beta2, float eps, float decay,
+                             float step_size, float inv_sqrt_bc2, float grad_mult, const double* __restrict__ sumsq,
+                             float max_norm) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float coef = grad_mult;
+    if (sumsq && max_norm > 0.f) {  // clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6))
+        const float tn = (float)sqrt(*sumsq) * grad_mult;
+        coef *= fminf(1.0f, max_norm / (tn + 1e-6f));
+    }
+    const float gi = g[i] * coef;
+    float pi = p[i] * decay;  // decoupled weight decay: p *= 1 - lr*wd
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, float grad_mult, const double* sumsq, float max_norm, hipStream_t st) {
+    if (!n) return GENIE_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    adamw_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p, g, m, v, n, lr, beta1, beta2, eps,
+                                                             (float)(1.0 - (double)lr * weight_decay), (float)(lr / bc1),
+                                                             (float)(1.0 / sqrt(bc2)), grad_mult, sumsq, max_norm);
+    GENIE_LAUNCH_CHECK("adamw");
+    return GENIE_OK;
+}
+
+}  // namespace genie

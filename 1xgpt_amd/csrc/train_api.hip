@@ -1,0 +1,295 @@
+// C ABI of the training step (include/genie_hip.h, "training" section): forward with saved activations, masked
+// factored CE, backward layer by layer (so the caller can overlap the gradient all-reduce of finished layers with
+// the backward of earlier ones), AdamW.  GENIE_PREC_EXACT only in this round: f32 storage, f32 MFMA contractions.
+//
+// HBM layout of the saved activations (floats; M = B*T*S tokens, token-major rows):
+//   per layer l at l*per_layer:  x0 (M,d) layer input | u1 (M,d) norm1(x0) | qkv_s (M,3d) | ao_s (M,d) spatial attention
+//   output before proj | x1 (M,d) | qkv_t (M,3d) | ao_t (M,d) | x2 (M,d) | u2 (M,d) norm2(x2) | z (M,hid) fc1 pre-activation
+//   | h (M,hid) gelu(z);  after the layers: xL (M,d) | logits (M,V) (replaced in place by d loss / d logits)
+// 21*d floats per token and layer: 5.6 GB per clip for the C138 shape -- sized for 288 GB, nothing is recomputed
+// except the spatial softmax (materialised per layer in the workspace, never saved).
+#include "kernels.hpp"
+
+namespace genie {
+
+struct TrainActs {
+    size_t per_layer, o_x0, o_u1, o_qkvs, o_aos, o_x1, o_qkvt, o_aot, o_x2, o_u2, o_z, o_h, o_xL, o_logits, total;
+};
+static TrainActs train_acts(const genie_cfg& c, int B) {
+    const size_t M = (size_t)B * c.T * c.S, d = c.d_model, hid = c.hidden;
+    const size_t V = (size_t)c.factored_vocab * c.num_factored;
+    TrainActs a;
+    size_t o = 0;
+    a.o_x0 = o; o += M * d;
+    a.o_u1 = o; o += M * d;
+    a.o_qkvs = o; o += M * 3 * d;
+    a.o_aos = o; o += M * d;
+    a.o_x1 = o; o += M * d;
+    a.o_qkvt = o; o += M * 3 * d;
+    a.o_aot = o; o += M * d;
+    a.o_x2 = o; o += M * d;
+    a.o_u2 = o; o += M * d;
+    a.o_z = o; o += M * hid;
+    a.o_h = o; o += M * hid;
+    a.per_layer = o;
+    a.o_xL = a.per_layer * c.num_layers;
+    a.o_logits = a.o_xL + M * d;
+    a.total = a.o_logits + M * V;
+    return a;
+}
+
+struct TrainWs {
+    float *dx, *d1, *g, *p, *dp, *slabs, *lnpart, *colpart;
+    double* dscratch;  // 1024 doubles (sumsq partials)
+    size_t slab_floats, total;
+};
+static TrainWs train_ws(const genie_cfg& c, int B, void* base) {
+    const size_t M = (size_t)B * c.T * c.S, d = c.d_model;
+    const size_t wide = (size_t)(3 * d > (size_t)c.hidden ? 3 * d : c.hidden);
+    const size_t V = (size_t)c.factored_vocab * c.num_factored;
+    const size_t scores = M * c.num_heads * c.S;
+    size_t maxw = (size_t)c.hidden * d;
+    if (3 * d * d > maxw) maxw = 3 * d * d;
+    if (V * d > maxw) maxw = V * d;
+    size_t maxn = wide > V ? wide : V;
+    TrainWs w;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t at = o; o += (floats * 4 + 255) / 256 * 256; return at; };
+    const size_t o_dx = take(M * d), o_d1 = take(M * d), o_g = take(M * wide), o_p = take(scores), o_dp = take(scores);
+    w.slab_floats = 64 * maxw;
+    const size_t o_sl = take(w.slab_floats), o_ln = take(ln_bwd_scratch_floats((int)d));
+    const size_t o_cp = take((size_t)COLSUM_SCRATCH_ROWS * maxn), o_ds = take(2 * 1024);
+    w.total = o;
+    char* b = (char*)base;
+    w.dx = (float*)(b + o_dx); w.d1 = (float*)(b + o_d1); w.g = (float*)(b + o_g); w.p = (float*)(b + o_p);
+    w.dp = (float*)(b + o_dp); w.slabs = (float*)(b + o_sl); w.lnpart = (float*)(b + o_ln);
+    w.colpart = (float*)(b + o_cp); w.dscratch = (double*)(b + o_ds);
+    return w;
+}
+
+static int train_check(const genie_cfg* c, int B) {
+    GENIE_CHECK_ARG(c != nullptr && B > 0, "training: cfg is NULL or B <= 0");
+    GENIE_TRY(genie_check_config(c));
+    if (c->precision != GENIE_PREC_EXACT) {
+        set_error("training step: only GENIE_PREC_EXACT is built (precision=%d)", c->precision);
+        return GENIE_E_UNSUPPORTED;
+    }
+    if (c->qk_norm) {
+        set_error("training step: qk_norm=true is not built yet (LayerNorm over head_dim in the attention backward)");
+        return GENIE_E_UNSUPPORTED;
+    }
+    GENIE_CHECK_SHAPE(c->S % 16 == 0 && c->head_dim % 16 == 0 && c->d_model % 16 == 0 && c->hidden % 16 == 0 && c->T <= 16,
+                      "training step: S, head_dim, d_model, hidden must be multiples of 16 and T <= 16");
+    return GENIE_OK;
+}
+
+// y = x . W^T + b (+ R) on the general GEMM
+static int lin(const float* x, long ldx, const float* W, const float* b, const float* R, float* y, long ldy, int M, int N,
+               int K, float alpha, hipStream_t st) {
+    return launch_gemm_f32_gen(false, false, x, ldx, 0, 0, W, K, 0, 0, b, R, y, ldy, 0, 0, M, N, K, 1, 1, 1, 0, alpha, st);
+}
+// dx = alpha * dy . W (+ R), W (N,K) row-major read k-major
+static int dgrad(const float* dy, const float* W, const float* R, float* dx, int M, int N, int K, float alpha,
+                 hipStream_t st) {
+    return launch_gemm_f32_gen(false, true, dy, N, 0, 0, W, K, 0, 0, nullptr, R, dx, K, 0, 0, M, K, N, 1, 1, 1, 0, alpha,
+                               st);
+}
+
+static int spatial_attn_fwd(const genie_cfg& c, const float* qkv, float* ao, int B, hipStream_t st) {
+    int rc = launch_attn_spatial_f32_mfma(qkv, ao, c.S, (long)B * c.T, c.d_model, c.num_heads, c.head_dim, c.attn_scale,
+                                          nullptr, nullptr, st);
+    if (rc == GENIE_E_UNSUPPORTED)
+        rc = launch_attn_generic(qkv, ao, c.S, (long)B * c.T, 1, c.S, 0, 1, c.d_model, c.num_heads, c.head_dim,
+                                 c.attn_scale, 0, nullptr, nullptr, st);
+    return rc;
+}
+static int temporal_attn_fwd(const genie_cfg& c, const float* qkv, float* ao, int B, hipStream_t st) {
+    int rc = launch_attn_temporal_f32_mfma(qkv, ao, B, c.T, c.S, c.d_model, c.num_heads, c.head_dim, c.attn_scale, nullptr,
+                                           nullptr, st);
+    if (rc == GENIE_E_UNSUPPORTED)
+        rc = launch_attn_generic(qkv, ao, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, c.d_model, c.num_heads,
+                                 c.head_dim, c.attn_scale, 1, nullptr, nullptr, st);
+    return rc;
+}
+
+// spatial attention backward through materialised scores: qkv (M,3d), dao (M,d) -> dqkv (M,3d)
+static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, const float* dao, float* dqkv, TrainWs& w, int B,
+                            hipStream_t st) {
+    const int S = c.S, d = c.d_model, H = c.num_heads, Dh = c.head_dim, BT = B * c.T;
+    const long q3 = (long)S * 3 * d, ss = (long)S * S, hss = (long)H * ss, sd = (long)S * d;
+    const float sc = c.attn_scale;
+    // P = softmax(scale Q K^T)
+    GENIE_TRY(launch_gemm_f32_gen(false, false, qkv, 3 * d, q3, Dh, qkv + d, 3 * d, q3, Dh, nullptr, nullptr, w.p, S, hss,
+                                  ss, S, S, Dh, BT, H, 1, 0, sc, st));
+    GENIE_TRY(launch_softmax_rows(w.p, (long)BT * H * S, S, st));
+    // dV = P^T dO
+    GENIE_TRY(launch_gemm_f32_gen(true, true, w.p, S, hss, ss, dao, d, sd, Dh, nullptr, nullptr, dqkv + 2 * d, 3 * d, q3,
+                                  Dh, S, Dh, S, BT, H, 1, 0, 1.0f, st));
+    // dP = dO V^T, dS = P (dP - rowsum(P dP))
+    GENIE_TRY(launch_gemm_f32_gen(false, false, dao, d, sd, Dh, qkv + 2 * d, 3 * d, q3, Dh, nullptr, nullptr, w.dp, S, hss,
+                                  ss, S, S, Dh, BT, H, 1, 0, 1.0f, st));
+    GENIE_TRY(launch_softmax_bwd_rows(w.p, w.dp, (long)BT * H * S, S, st));
+    // dQ = scale dS K,  dK = scale dS^T Q
+    GENIE_TRY(launch_gemm_f32_gen(false, true, w.dp, S, hss, ss, qkv + d, 3 * d, q3, Dh, nullptr, nullptr, dqkv, 3 * d, q3,
+                                  Dh, S, Dh, S, BT, H, 1, 0, sc, st));
+    GENIE_TRY(launch_gemm_f32_gen(true, true, w.dp, S, hss, ss, qkv, 3 * d, q3, Dh, nullptr, nullptr, dqkv + d, 3 * d, q3,
+                                  Dh, S, Dh, S, BT, H, 1, 0, sc, st));
+    return GENIE_OK;
+}
+
+}  // namespace genie
+
+using namespace genie;
+
+extern "C" {
+
+size_t genie_train_activation_bytes(const genie_cfg* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return train_acts(*cfg, B).total * sizeof(float);
+}
+size_t genie_train_workspace_bytes(const genie_cfg* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return train_ws(*cfg, B, nullptr).total;
+}
+
+int genie_train_forward(const genie_cfg* cfg, const genie_weights* wt, const int64_t* input_ids, const int64_t* labels,
+                        int B, float* acts, size_t acts_bytes, double* sums, void* stream) {
+    GENIE_TRY(train_check(cfg, B));
+    GENIE_CHECK_ARG(wt && input_ids && labels && acts && sums, "genie_train_forward: NULL argument");
+    const genie_cfg& c = *cfg;
+    const TrainActs a = train_acts(c, B);
+    GENIE_CHECK_ARG(acts_bytes >= a.total * sizeof(float), "genie_train_forward: activation buffer too small: %zu < %zu",
+                    acts_bytes, a.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    const int d = c.d_model, hid = c.hidden, M = B * c.T * c.S;
+    GENIE_TRY(launch_embed(c, *wt, input_ids, B, acts + a.o_x0, st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const genie_layer_weights& lw = wt->layers_host[l];
+        float* L = acts + a.per_layer * l;
+        float* xnext = (l + 1 < c.num_layers) ? acts + a.per_layer * (l + 1) + a.o_x0 : acts + a.o_xL;
+        GENIE_TRY(launch_layer_norm(L + a.o_x0, lw.norm1_w, lw.norm1_b, L + a.o_u1, M, d, 1e-5f, st));
+        GENIE_TRY(lin(L + a.o_u1, d, lw.spatial.qkv_w, c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, L + a.o_qkvs,
+                      3 * d, M, 3 * d, d, 1.0f, st));
+        GENIE_TRY(spatial_attn_fwd(c, L + a.o_qkvs, L + a.o_aos, B, st));
+        GENIE_TRY(lin(L + a.o_aos, d, lw.spatial.proj_w, c.proj_bias ? lw.spatial.proj_b : nullptr, L + a.o_x0,
+                      L + a.o_x1, d, M, d, d, 1.0f, st));
+        GENIE_TRY(lin(L + a.o_x1, d, lw.temporal.qkv_w, c.qkv_bias ? lw.temporal.qkv_b : nullptr, nullptr, L + a.o_qkvt,
+                      3 * d, M, 3 * d, d, 1.0f, st));
+        GENIE_TRY(temporal_attn_fwd(c, L + a.o_qkvt, L + a.o_aot, B, st));
+        GENIE_TRY(lin(L + a.o_aot, d, lw.temporal.proj_w, c.proj_bias ? lw.temporal.proj_b : nullptr, L + a.o_x1,
+                      L + a.o_x2, d, M, d, d, 1.0f, st));
+        GENIE_TRY(launch_layer_norm(L + a.o_x2, lw.norm2_w, lw.norm2_b, L + a.o_u2, M, d, 1e-5f, st));
+        GENIE_TRY(lin(L + a.o_u2, d, lw.fc1_w, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, L + a.o_z, hid, M, hid, d, 1.0f,
+                      st));
+        GENIE_TRY(launch_gelu_fwd(L + a.o_z, L + a.o_h, (size_t)M * hid, st));
+        GENIE_TRY(lin(L + a.o_h, hid, lw.fc2_w, c.mlp_bias ? lw.fc2_b : nullptr, L + a.o_x2, xnext, d, M, d, hid, 1.0f,
+                      st));
+    }
+    const int V = c.factored_vocab * c.num_factored;
+    GENIE_TRY(lin(acts + a.o_xL, d, wt->out_w, wt->out_b, nullptr, acts + a.o_logits, V, M, V, d, c.readout_mult, st));
+    if (hipMemsetAsync(sums, 0, 3 * sizeof(double), st) != hipSuccess) {
+        set_error("genie_train_forward: hipMemsetAsync failed");
+        return GENIE_E_LAUNCH;
+    }
+    return launch_ce_fwd_bwd(c, acts + a.o_logits, input_ids, labels, B, sums, st);
+}
+
+int genie_train_backward_head(const genie_cfg* cfg, const genie_weights* wt, const genie_weights* grads, int B,
+                              const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+    GENIE_TRY(train_check(cfg, B));
+    GENIE_CHECK_ARG(wt && grads && acts && workspace, "genie_train_backward_head: NULL argument");
+    const genie_cfg& c = *cfg;
+    const TrainActs a = train_acts(c, B);
+    TrainWs w = train_ws(c, B, workspace);
+    GENIE_CHECK_ARG(workspace_bytes >= w.total, "training workspace too small: %zu < %zu", workspace_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = c.d_model, M = B * c.T * c.S, V = c.factored_vocab * c.num_factored;
+    const float beta = accumulate ? 1.0f : 0.0f;
+    const float* dl = acts + a.o_logits;
+    GENIE_TRY(launch_wgrad_f32(dl, V, acts + a.o_xL, d, (float*)grads->out_w, M, V, d, c.readout_mult, beta, w.slabs,
+                               w.slab_floats, st));
+    GENIE_TRY(launch_colsum(dl, V, M, V, (float*)grads->out_b, beta, w.colpart, st));
+    return dgrad(dl, wt->out_w, nullptr, w.dx, M, V, d, c.readout_mult, st);
+}
+
+int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* wt, const genie_weights* grads, int layer, int B,
+                               const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+    GENIE_TRY(train_check(cfg, B));
+    GENIE_CHECK_ARG(wt && grads && acts && workspace, "genie_train_backward_layer: NULL argument");
+    GENIE_CHECK_ARG(layer >= 0 && layer < cfg->num_layers, "genie_train_backward_layer: layer %d out of range", layer);
+    const genie_cfg& c = *cfg;
+    const TrainActs a = train_acts(c, B);
+    TrainWs w = train_ws(c, B, workspace);
+    GENIE_CHECK_ARG(workspace_bytes >= w.total, "training workspace too small: %zu < %zu", workspace_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = c.d_model, hid = c.hidden, M = B * c.T * c.S;
+    const float beta = accumulate ? 1.0f : 0.0f;
+    const genie_layer_weights& lw = wt->layers_host[layer];
+    const genie_layer_weights& g = grads->layers_host[layer];
+    const float* L = acts + a.per_layer * layer;
+    float* dx = w.dx;
+
+    // ---- MLP: x3 = x2 + fc2(gelu(fc1(norm2(x2))))  (st_transformer.py:81, 16-25)
+    GENIE_TRY(launch_wgrad_f32(dx, d, L + a.o_h, hid, (float*)g.fc2_w, M, d, hid, 1.0f, beta, w.slabs, w.slab_floats, st));
+    if (c.mlp_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.fc2_b, beta, w.colpart, st));
+    GENIE_TRY(dgrad(dx, lw.fc2_w, nullptr, w.g, M, d, hid, 1.0f, st));          // dh
+    GENIE_TRY(launch_gelu_bwd(L + a.o_z, w.g, (size_t)M * hid, st));            // dz
+    GENIE_TRY(launch_wgrad_f32(w.g, hid, L + a.o_u2, d, (float*)g.fc1_w, M, hid, d, 1.0f, beta, w.slabs, w.slab_floats,
+                               st));
+    if (c.mlp_bias) GENIE_TRY(launch_colsum(w.g, hid, M, hid, (float*)g.fc1_b, beta, w.colpart, st));
+    GENIE_TRY(dgrad(w.g, lw.fc1_w, nullptr, w.d1, M, hid, d, 1.0f, st));        // d norm2 output
+    GENIE_TRY(launch_ln_bwd(L + a.o_x2, lw.norm2_w, w.d1, dx, (float*)g.norm2_w, (float*)g.norm2_b, M, d, 1e-5f, beta,
+                            w.lnpart, st));
+
+    // ---- temporal: x2 = x1 + proj(attn(qkv(x1))), no pre-norm  (st_transformer.py:77-78)
+    GENIE_TRY(launch_wgrad_f32(dx, d, L + a.o_aot, d, (float*)g.temporal.proj_w, M, d, d, 1.0f, beta, w.slabs,
+                               w.slab_floats, st));
+    if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.temporal.proj_b, beta, w.colpart, st));
+    GENIE_TRY(dgrad(dx, lw.temporal.proj_w, nullptr, w.d1, M, d, d, 1.0f, st));  // d attention output
+    GENIE_TRY(launch_attn_temporal_bwd(L + a.o_qkvt, w.d1, w.g, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, st));
+    GENIE_TRY(launch_wgrad_f32(w.g, 3 * d, L + a.o_x1, d, (float*)g.temporal.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs,
+                               w.slab_floats, st));
+    if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.temporal.qkv_b, beta, w.colpart, st));
+    GENIE_TRY(dgrad(w.g, lw.temporal.qkv_w, dx, dx, M, 3 * d, d, 1.0f, st));     // dx += dqkv . Wqkv
+
+    // ---- spatial: x1 = x0 + proj(attn(qkv(norm1(x0))))  (st_transformer.py:73-74)
+    GENIE_TRY(launch_wgrad_f32(dx, d, L + a.o_aos, d, (float*)g.spatial.proj_w, M, d, d, 1.0f, beta, w.slabs, w.slab_floats,
+                               st));
+    if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.spatial.proj_b, beta, w.colpart, st));
+    GENIE_TRY(dgrad(dx, lw.spatial.proj_w, nullptr, w.d1, M, d, d, 1.0f, st));
+    GENIE_TRY(spatial_attn_bwd(c, L + a.o_qkvs, w.d1, w.g, w, B, st));
+    GENIE_TRY(launch_wgrad_f32(w.g, 3 * d, L + a.o_u1, d, (float*)g.spatial.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs,
+                               w.slab_floats, st));
+    if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.spatial.qkv_b, beta, w.colpart, st));
+    GENIE_TRY(dgrad(w.g, lw.spatial.qkv_w, nullptr, w.d1, M, 3 * d, d, 1.0f, st));  // d norm1 output
+    return launch_ln_bwd(L + a.o_x0, lw.norm1_w, w.d1, dx, (float*)g.norm1_w, (float*)g.norm1_b, M, d, 1e-5f, beta, w.lnpart,
+                         st);
+}
+
+int genie_train_backward_embed(const genie_cfg* cfg, const genie_weights* grads, const int64_t* input_ids, int B,
+                               void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+    GENIE_TRY(train_check(cfg, B));
+    GENIE_CHECK_ARG(grads && input_ids && workspace, "genie_train_backward_embed: NULL argument");
+    TrainWs w = train_ws(*cfg, B, workspace);
+    GENIE_CHECK_ARG(workspace_bytes >= w.total, "training workspace too small: %zu < %zu", workspace_bytes, w.total);
+    float* tables[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int j = 0; j < cfg->num_factored && j < 4; ++j) tables[j] = (float*)grads->embed[j];
+    return launch_embed_bwd(*cfg, w.dx, input_ids, B, (float*)grads->pos_embed, (float*)grads->mask_embed, tables,
+                            accumulate ? 1.0f : 0.0f, (hipStream_t)stream);
+}
+
+int genie_sumsq(const float* x, size_t n, double* out, double* scratch, void* stream) {
+    GENIE_CHECK_ARG((x || !n) && out && scratch, "genie_sumsq: NULL argument");
+    return launch_sumsq(x, n, out, scratch, (hipStream_t)stream);
+}
+
+int genie_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_mult, const double* grad_sumsq,
+                     float max_grad_norm, void* stream) {
+    GENIE_CHECK_ARG((params && grads && exp_avg && exp_avg_sq) || !n, "genie_adamw_step: NULL argument");
+    GENIE_CHECK_ARG(step >= 1, "genie_adamw_step: step counts from 1");
+    return launch_adamw(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_mult,
+                        grad_sumsq, max_grad_norm, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -4,11 +4,13 @@ On disk: ``metadata.json`` {num_images, s, vocab_size, hz, token_dtype?}, ``vide
 (uint32 by default), optional ``segment_ids.bin`` = (num_images,) int32.  Windows of ``window_size`` frames spaced
 ``stride`` apart; ``filter_interrupts`` drops windows whose first and last frame belong to different segments,
 ``filter_overlaps`` keeps each frame in at most one window.  Same constructor, attributes (``data``,
-``metadata``, ``valid_start_inds``) and item dict as the reference.  The MaskGIT training collator
-(data.py:109-169) is training-only and out of scope.
+``metadata``, ``valid_start_inds``) and item dict as the reference.  ``get_maskgit_collator`` is the training
+collator of data.py:109-169 (random corruption + MaskGIT masking) on whatever device the clips are on.
 """
 import json
+import math
 import os
+import random
 from pathlib import Path
 
 import numpy as np
@@ -83,3 +85,81 @@ def write_token_dataset(data_dir, tokens: np.ndarray, segment_ids: np.ndarray = 
     with open(data_dir / "metadata.json", "w") as f:
         json.dump(meta, f)
     return meta
+
+
+# ------------------------------------------------------------------ MaskGIT training collator (data.py:109-169)
+class TorchDraws:
+    """The collator's random draws, in the reference's call order, from torch's / Python's global generators."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def rand(self, shape):
+        return torch.rand(tuple(shape), device=self.device)
+
+    rand_like = rand
+
+    def randint(self, high, shape):
+        return torch.randint(low=0, high=high, size=tuple(shape), dtype=torch.long, device=self.device)
+
+    def py_random(self):
+        return random.random()
+
+    def py_randint(self, a, b):
+        return random.randint(a, b)
+
+    def py_uniform(self, a, b):
+        return random.uniform(a, b)
+
+
+def maskgit_collate(input_ids, config, draws=None):
+    """(B, T*S) int64 clips -> {"input_ids", "labels"} following data.py:112-167 draw for draw.
+
+    `draws` replays captured draws (parity tests); None draws fresh ones on the clips' device."""
+    ids = input_ids.to(torch.int64)
+    dev = ids.device
+    draws = draws or TorchDraws(dev)
+    B = ids.shape[0]
+    h = w = math.isqrt(config.S)
+    nv, Vf = config.num_factored_vocabs, config.factored_vocab_size
+    mask_token_id = config.image_vocab_size
+    x_THW = ids.reshape(B, config.T, h, w)
+    powers = Vf ** torch.arange(nv, device=dev)
+    x_THWC = (x_THW.unsqueeze(-1) // powers) % Vf
+    labels = x_THW.clone()
+
+    def t(a, dtype):
+        return torch.as_tensor(a, device=dev).to(dtype)
+
+    r = t(draws.rand(x_THWC.shape), torch.float32)
+    u01 = t(draws.rand(()), torch.float32)
+    random_values = t(draws.randint(Vf, x_THWC.shape), torch.long)
+    m = r < config.max_corrupt_rate * u01
+    x_THWC = torch.where(m, random_values, x_THWC)
+    if draws.py_random() < config.non_mlm_ratio:
+        first = draws.py_randint(config.num_prompt_frames, config.T - 1)
+        correct_rate = draws.py_uniform(0.25, 1.0)
+        for i in range(config.T - first):
+            correct_rate *= draws.py_uniform(0.9, 1.0)
+            r = t(draws.rand((B, h, w, nv)), torch.float32)
+            m = r > correct_rate
+            x_THWC[:, first + i] = torch.where(m, random_values[:, first + i], x_THWC[:, first + i])
+    else:
+        first = 1
+    while True:
+        u = t(draws.rand((B, config.T - first, 1, 1)), torch.float32)
+        prob = torch.cos(u * torch.pi / 2)
+        r = t(draws.rand_like((B, config.T - first, h, w)), torch.float32)
+        mask = r < prob
+        if bool(mask.any()):
+            break
+    x = (x_THWC * powers).sum(-1)
+    x[:, first:][mask] = mask_token_id
+    return {"input_ids": x.reshape(B, -1), "labels": labels.reshape(B, -1)}
+
+
+def get_maskgit_collator(config):
+    """collate_fn(features: list of {"input_ids": (T*S,) tensor}) -> batch dict, as data.py:109."""
+    def collate_fn(features):
+        return maskgit_collate(torch.stack([ex["input_ids"] for ex in features]), config)
+    return collate_fn

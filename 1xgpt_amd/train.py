@@ -1,0 +1,313 @@
+"""Training step on the HIP path -- counterpart of the reference's train.py:426-441 (optimizer + grouping),
+:468-492 (learning-rate schedules) and :600-633 (forward, backward, clip, step), with the data-parallel gradient
+exchange accelerate/DDP does for it.
+
+    trainer = GenieTrainer(model, lr=1e-4, weight_decay=0.0, max_grad_norm=1.0)
+    out = trainer.train_step(collate_fn(features))        # dict(loss, acc, grad_norm, lr)
+
+Design (MI355X-first):
+  * parameters, gradients and both Adam moments live in four flat f32 buffers laid out in the order gradients become
+    READY during the backward (readout, layers L-1..0, embeddings); the model's nn.Parameters are re-pointed at views
+    of the parameter buffer, so `model.state_dict()` / `save_pretrained` keep working;
+  * every activation the backward needs is kept (288 GB of HBM; nothing is recomputed except the spatial softmax);
+  * multi-GPU: one process per GPU, clips sharded, gradients summed with one RCCL all-reduce per bucket of layers,
+    launched as soon as that bucket's backward has been enqueued so the exchange overlaps the remaining backward;
+    1/world_size and the clip coefficient are folded into the AdamW kernel (no host sync in the step);
+  * GPU only: there is no CPU fallback for the model math (the collator in data.py is device-agnostic data prep).
+MuAdamW (--mu_transfer, train.py:439; third-party mup fork) is not built.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+# ------------------------------------------------------------------ schedules (train.py:468-492)
+def lr_factor_custom_cosine(warmup_steps, max_steps, end_ratio=0.1):
+    """train.py:468-477: linear warm-up to 1, cosine decay to `end_ratio`."""
+    def f(step):
+        if step < warmup_steps:
+            return (step + 1) / warmup_steps
+        remaining = max_steps - warmup_steps
+        return ((1 + math.cos(math.pi * (step - warmup_steps) / remaining)) / 2) * (1 - end_ratio) + end_ratio
+    return f
+
+
+def lr_factor_linear(warmup_steps, max_steps):
+    """transformers.get_scheduler("linear", ...) -- the default --lr_scheduler_type (train.py:483-492)."""
+    def f(step):
+        if step < warmup_steps:
+            return step / max(1, warmup_steps)
+        return max(0.0, (max_steps - step) / max(1, max_steps - warmup_steps))
+    return f
+
+
+def decays(name: str) -> bool:
+    """train.py:427-437: names containing "bias" or "layer_norm.weight" are excluded from weight decay.  No GENIE
+    parameter is called layer_norm.* (they are norm1/norm2/norm), so LayerNorm weights DO decay, as in the reference."""
+    return not ("bias" in name or "layer_norm.weight" in name)
+
+
+# ------------------------------------------------------------------ pointer tables
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def weights_table(config, tensors):
+    """genie_weights table over state-dict-named tensors (parameters or gradients).  Returns (table, keepalive)."""
+    L = config.num_layers
+    layers = (_lib.LayerWeights * L)()
+    g = tensors.get
+    for i in range(L):
+        p = f"decoder.layers.{i}."
+        lw = layers[i]
+        lw.norm1_w, lw.norm1_b = _ptr(g(p + "norm1.weight")), _ptr(g(p + "norm1.bias"))
+        lw.norm2_w, lw.norm2_b = _ptr(g(p + "norm2.weight")), _ptr(g(p + "norm2.bias"))
+        for name, aw in (("spatial_attn.", lw.spatial), ("temporal_attn.", lw.temporal)):
+            aw.qkv_w, aw.qkv_b = _ptr(g(p + name + "qkv.weight")), _ptr(g(p + name + "qkv.bias"))
+            aw.proj_w, aw.proj_b = _ptr(g(p + name + "proj.weight")), _ptr(g(p + name + "proj.bias"))
+            aw.norm_w, aw.norm_b = _ptr(g(p + name + "norm.weight")), _ptr(g(p + name + "norm.bias"))
+        lw.fc1_w, lw.fc1_b = _ptr(g(p + "mlp.fc1.weight")), _ptr(g(p + "mlp.fc1.bias"))
+        lw.fc2_w, lw.fc2_b = _ptr(g(p + "mlp.fc2.weight")), _ptr(g(p + "mlp.fc2.bias"))
+    w = _lib.Weights()
+    w.pos_embed = _ptr(g("pos_embed_TSC"))
+    w.mask_embed = _ptr(g("token_embed.mask_token_embed"))
+    for j in range(config.num_factored_vocabs):
+        w.embed[j] = _ptr(g(f"token_embed.factored_embeds.{j}.weight"))
+    w.out_w, w.out_b = _ptr(g("out_x_proj.weight")), _ptr(g("out_x_proj.bias"))
+    w.layers_host = layers
+    return w, layers
+
+
+def ready_order(config, names):
+    """Parameter names in the order their gradients are final during the backward: readout, layers L-1..0 (within a
+    layer: decaying tensors first, so each layer is two AdamW ranges), then the embedding side."""
+    names = list(names)
+    head = [n for n in names if n.startswith("out_x_proj.")]
+    emb = [n for n in names if n.startswith("token_embed.") or n == "pos_embed_TSC"]
+    out = sorted(head, key=lambda n: not decays(n))
+    for i in reversed(range(config.num_layers)):
+        p = f"decoder.layers.{i}."
+        lay = [n for n in names if n.startswith(p)]
+        out += sorted(lay, key=lambda n: not decays(n))
+    out += emb
+    assert sorted(out) == sorted(names), "unexpected parameter names"
+    return out
+
+
+class BucketReducer:
+    """Sum-all-reduce of contiguous slices of one flat gradient buffer, one slice per bucket, asynchronously.
+
+    `ready(hi)` says "gradients [0, hi) are final (their kernels are enqueued on the current stream)"; every bucket
+    that is now complete is handed to the process group at once (RCCL orders itself after the current stream), so
+    the exchange of late layers runs under the backward of early ones.  `finish()` makes the current stream wait for
+    all of them.  Works on any backend (gloo in the CPU tests)."""
+
+    def __init__(self, flat, bounds, group=None):
+        self.flat, self.bounds, self.group = flat, list(bounds), group
+        self.reset()
+
+    def reset(self):
+        self.next, self.works = 0, []
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def ready(self, hi):
+        if self.world == 1:
+            return
+        while self.next < len(self.bounds) and self.bounds[self.next][1] <= hi:
+            lo, up = self.bounds[self.next]
+            self.works.append(dist.all_reduce(self.flat[lo:up], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.next += 1
+
+    def finish(self):
+        self.ready(self.flat.numel())
+        for w in self.works:
+            w.wait()
+        self.reset()
+
+
+def bucket_bounds(segments, target_elems):
+    """Greedy contiguous buckets over [(lo, hi)] segments (in ready order) of at least `target_elems` elements."""
+    out, start, end = [], None, None
+    for lo, hi in segments:
+        if start is None:
+            start = lo
+        end = hi
+        if end - start >= target_elems:
+            out.append((start, end))
+            start = None
+    if start is not None:
+        out.append((start, end))
+    return out
+
+
+class GenieTrainer:
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
+                 gradient_accumulation_steps=1, lr_lambda=None, bucket_mb=64, group=None):
+        self.model, self.config = model, model.config
+        dev = model._device()  # raises on CPU: no fallback
+        if model.precision != "exact":
+            raise NotImplementedError("GenieTrainer: only precision='exact' is built")
+        self.lib = _lib.load()
+        self.cfg = _lib.make_cfg(self.config, _lib.PREC_EXACT)
+        self.base_lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.accum = gradient_accumulation_steps
+        self.lr_lambda = lr_lambda or (lambda step: 1.0)
+        self.completed_steps, self._micro = 0, 0
+
+        named = dict(model.named_parameters())
+        self.order = ready_order(self.config, named.keys())
+        offs, o = {}, 0
+        for n in self.order:
+            offs[n] = (o, o + named[n].numel())
+            o += (named[n].numel() + 63) // 64 * 64  # 256-byte aligned tensors (float4 / MFMA staging loads)
+        self.n_flat = o
+        self.params = torch.zeros(o, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.offsets = offs
+        with torch.no_grad():
+            for n in self.order:
+                lo, hi = offs[n]
+                view = self.params[lo:hi].view(named[n].shape)
+                view.copy_(named[n].data)
+                named[n].data = view  # the module now reads (and checkpoints) the flat buffer
+        model.refresh_weights()
+        self.p_views = {n: self.params[offs[n][0]:offs[n][1]] for n in self.order}
+        self.g_views = {n: self.grads[offs[n][0]:offs[n][1]].view(named[n].shape) for n in self.order}
+        self.w_table, self._wk = weights_table(self.config, {n: named[n].data for n in self.order})
+        self.g_table, self._gk = weights_table(self.config, self.g_views)
+        # AdamW ranges: maximal runs of consecutive tensors with the same decay flag (padding between tensors is zero
+        # and stays zero: zero gradient, zero moments)
+        runs = []
+        for n in self.order:
+            lo, hi = offs[n]
+            hi_pad = lo + (hi - lo + 63) // 64 * 64
+            if runs and runs[-1][2] == decays(n):
+                runs[-1][1] = hi_pad
+            else:
+                runs.append([lo, hi_pad, decays(n)])
+        self.adam_runs = [(lo, hi, dk) for lo, hi, dk in runs]
+        # all-reduce buckets: per-layer segments merged up to bucket_mb
+        segs, L = [], self.config.num_layers
+        groups = [[n for n in self.order if n.startswith("out_x_proj.")]]
+        groups += [[n for n in self.order if n.startswith(f"decoder.layers.{i}.")] for i in reversed(range(L))]
+        groups += [[n for n in self.order if n.startswith("token_embed.") or n == "pos_embed_TSC"]]
+        for gnames in groups:
+            lo = offs[gnames[0]][0]
+            hi = offs[gnames[-1]][0] + (named[gnames[-1]].numel() + 63) // 64 * 64
+            segs.append((lo, hi))
+        self.segments = segs  # [head, layer L-1, ..., layer 0, embeddings]
+        self.reducer = BucketReducer(self.grads, bucket_bounds(segs, bucket_mb * (1 << 20) // 4), group)
+        self.sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.scratch = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self._acts = self._ws = None
+        self._B = 0
+
+    # ------------------------------------------------------------------ buffers
+    def _buffers(self, B):
+        if B != self._B:
+            self._acts = self._ws = None
+            na = self.lib.genie_train_activation_bytes(self.cfg, B)
+            nw = self.lib.genie_train_workspace_bytes(self.cfg, B)
+            if na == 0 or nw == 0:
+                _lib.check(self.lib.genie_check_config(self.cfg), "genie_check_config")
+            self._acts = torch.empty(na, dtype=torch.uint8, device=self.params.device)
+            self._ws = torch.empty(nw, dtype=torch.uint8, device=self.params.device)
+            self._B = B
+        return self._acts, self._ws
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ forward / backward (train.py:611-617)
+    def forward_backward(self, input_ids, labels, accumulate=False, reduce=True):
+        """One micro-batch: loss/acc of STMaskGIT.forward and gradients into the flat buffer (added when
+        `accumulate`).  Returns (loss, acc) as 0-dim float64 CUDA tensors (no host sync)."""
+        if not (input_ids.is_cuda and labels.is_cuda):
+            raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): move the batch to cuda")
+        ids = input_ids.to(torch.int64).contiguous()
+        lab = labels.to(torch.int64).contiguous()
+        B = ids.shape[0]
+        assert ids.shape == lab.shape == (B, self.config.T * self.config.S), ids.shape
+        acts, ws = self._buffers(B)
+        lib, cfg, st = self.lib, self.cfg, self._stream()
+        acc_flag = 1 if accumulate else 0
+        _lib.check(lib.genie_train_forward(cfg, self.w_table, ids.data_ptr(), lab.data_ptr(), B, acts.data_ptr(),
+                                           acts.numel(), self.sums.data_ptr(), st), "genie_train_forward")
+        sums = self.sums.clone()
+        self.reducer.reset()
+        _lib.check(lib.genie_train_backward_head(cfg, self.w_table, self.g_table, B, acts.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), acc_flag, st), "genie_train_backward_head")
+        if reduce:
+            self.reducer.ready(self.segments[0][1])
+        L = self.config.num_layers
+        for k, layer in enumerate(reversed(range(L))):
+            _lib.check(lib.genie_train_backward_layer(cfg, self.w_table, self.g_table, layer, B, acts.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), acc_flag, st),
+                       "genie_train_backward_layer")
+            if reduce:
+                self.reducer.ready(self.segments[1 + k][1])
+        _lib.check(lib.genie_train_backward_embed(cfg, self.g_table, ids.data_ptr(), B, ws.data_ptr(), ws.numel(),
+                                                  acc_flag, st), "genie_train_backward_embed")
+        if reduce:
+            self.reducer.finish()
+        return sums[0] / sums[2], sums[1] / sums[2]
+
+    # ------------------------------------------------------------------ clip + AdamW + scheduler (train.py:628-633)
+    def grad_sumsq(self):
+        self.sumsq.zero_()
+        _lib.check(self.lib.genie_sumsq(self.grads.data_ptr(), self.n_flat, self.sumsq.data_ptr(),
+                                        self.scratch.data_ptr(), self._stream()), "genie_sumsq")
+        return self.sumsq
+
+    def current_lr(self):
+        return self.base_lr * self.lr_lambda(self.completed_steps)
+
+    def optimizer_step(self):
+        world = self.reducer.world
+        mult = 1.0 / (world * self.accum)
+        ss = self.grad_sumsq()
+        lr = self.current_lr()
+        clip = self.max_grad_norm if self.max_grad_norm is not None else 0.0
+        step = self.completed_steps + 1
+        st = self._stream()
+        for lo, hi, dk in self.adam_runs:
+            off = lo * 4
+            _lib.check(self.lib.genie_adamw_step(
+                self.params.data_ptr() + off, self.grads.data_ptr() + off, self.exp_avg.data_ptr() + off,
+                self.exp_avg_sq.data_ptr() + off, hi - lo, lr, self.betas[0], self.betas[1], self.eps,
+                self.weight_decay if dk else 0.0, step, mult, ss.data_ptr() if clip > 0 else None, clip, st),
+                "genie_adamw_step")
+        self.completed_steps += 1
+        self.model.refresh_weights()  # 16-bit copies of the inference precisions (if any) are stale
+        return torch.sqrt(ss[0]) * mult, lr
+
+    def train_step(self, batch):
+        """One micro-batch of the reference loop (train.py:604-633); the optimizer runs every
+        `gradient_accumulation_steps` calls.  Returns device scalars (no host sync)."""
+        is_update = (self._micro + 1) % self.accum == 0
+        loss, acc = self.forward_backward(batch["input_ids"], batch["labels"], accumulate=self._micro % self.accum != 0,
+                                          reduce=is_update and self.accum == 1)
+        self._micro += 1
+        out = {"loss": loss, "acc": acc}
+        if is_update:
+            if self.accum > 1 and self.reducer.world > 1:  # no_sync() micro-batches: reduce once, after the last
+                self.reducer.reset()
+                self.reducer.finish()
+            out["grad_norm"], out["lr"] = self.optimizer_step()
+        return out
+
+    def gradients(self):
+        """{state-dict name: gradient view} (shapes of the parameters)."""
+        return self.g_views

@@ -292,6 +292,50 @@ int genie_group_norm_swish_bf16(const uint16_t* x, const float* gamma, const flo
 int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_pix, int bits, int cpad, void* stream);
 int genie_rescale_u8_nhwc_bf16(const uint16_t* x, uint8_t* out, int n, int HW, int cpad, int cout, void* stream);
 
+/* ---- training step (train.py:600-633) -------------------------------------------
+ * GENIE_PREC_EXACT, qk_norm = false (the shipped config) in this ABI version; anything else returns
+ * GENIE_E_UNSUPPORTED.  Gradients travel in a second genie_weights table whose pointers address the caller's
+ * gradient buffers (same shapes as the parameters; the *_w16 members are ignored).  `accumulate` = 0 overwrites the
+ * gradients (optimizer.zero_grad() + backward), 1 adds to them (gradient accumulation, train.py:607-617).
+ * Every reduction feeding a gradient has a fixed order: results are bit-reproducible run to run. */
+
+/* Bytes of the saved-activation buffer / of the backward scratch for B clips. */
+size_t genie_train_activation_bytes(const genie_cfg* cfg, int B);
+size_t genie_train_workspace_bytes(const genie_cfg* cfg, int B);
+
+/* STMaskGIT.forward in training mode (st_mask_git.py:267-279; dropout is 0 in every shipped config): embeds
+ * input_ids (B,T,S), runs the L blocks keeping what the backward needs, the readout, and the masked factored CE of
+ * compute_loss_and_acc (:231-253) against labels (B,T,S).  sums_out (3 doubles, overwritten) =
+ * [sum CE over counted tokens, sum (all factors argmax-correct), n counted] with counted = frame >= 1 and
+ * input id == mask id; loss = sums[0]/sums[2], acc = sums[1]/sums[2] (0/0 = nan as in the reference).
+ * On return the logits slot of `acts` holds d loss / d logits. */
+int genie_train_forward(const genie_cfg* cfg, const genie_weights* w, const int64_t* input_ids, const int64_t* labels,
+                        int B, float* acts, size_t acts_bytes, double* sums_out, void* stream);
+
+/* loss.backward() (train.py:617), split so that the caller can all-reduce finished gradients while earlier layers
+ * are still running: head (readout weight/bias, d loss / d x_L into the workspace), then layers L-1 .. 0 (each
+ * consumes and replaces the running d loss / d x in the workspace), then the embedding tables, mask embedding and
+ * pos_embed.  Must be called in exactly that order on one stream after genie_train_forward. */
+int genie_train_backward_head(const genie_cfg* cfg, const genie_weights* w, const genie_weights* grads, int B,
+                              const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream);
+int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* w, const genie_weights* grads, int layer, int B,
+                               const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream);
+int genie_train_backward_embed(const genie_cfg* cfg, const genie_weights* grads, const int64_t* input_ids, int B,
+                               void* workspace, size_t workspace_bytes, int accumulate, void* stream);
+
+/* *out += sum x[i]^2 in f64, two-stage with a fixed order (scratch: 1024 doubles).  The global gradient norm of
+ * clip_grad_norm_ (train.py:628-629) is sqrt of this summed over all gradient buffers. */
+int genie_sumsq(const float* x, size_t n, double* out, double* scratch, void* stream);
+
+/* torch.optim.AdamW.step() on one flat range (train.py:440-441, 631): decoupled decay p *= 1 - lr*wd, then the
+ * bias-corrected Adam update; `step` counts from 1.  The gradient is first multiplied by grad_mult (1/world_size
+ * after a SUM all-reduce, 1/accumulation steps) and, when grad_sumsq != NULL and max_grad_norm > 0, by
+ * min(1, max_grad_norm / (grad_mult * sqrt(*grad_sumsq) + 1e-6)) -- clip_grad_norm_ without a host sync.
+ * The reference's grouping (train.py:426-437) is the caller's: weight_decay = 0 for names containing "bias". */
+int genie_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_mult, const double* grad_sumsq,
+                     float max_grad_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+"""Training step on the HIP path (through the C ABI via 1xgpt_amd/train.py) against the reference's own autograd
+gradients / AdamW results (tests/golden/train_*.npz) and the CPU oracle.  Needs a real MI355X: ``-m gpu``.
+
+Tolerances (f32 MFMA, f32 accumulation order only): loss within 1e-5 relative; every gradient tensor within
+1e-4 of its largest element (reference autograd itself is f32); parameters after two clipped AdamW steps within
+2.5e-5 absolute (updates are ~2e-3).
+"""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import genie_train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+GRAD_TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def make_trainer(cfg, sd, **kw):
+    model = pkg("st_mask_git").STMaskGIT(cfg, precision="exact").load_numpy_state_dict(sd).to("cuda")
+    return pkg("train").GenieTrainer(model, **kw)
+
+
+def rel_err(a, ref):
+    return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def test_every_gradient_vs_reference_autograd(golden):
+    z, cfg, sd = golden("train_tiny_ln")
+    tr = make_trainer(cfg, sd)
+    loss, acc = tr.forward_backward(dev(z["s0_input_ids"]), dev(z["s0_labels"]))
+    assert abs(float(loss) - float(z["s0_loss"])) < 1e-5 * float(z["s0_loss"])
+    assert abs(float(acc) - float(z["s0_acc"])) < 1e-7
+    worst = {}
+    for k, g in tr.gradients().items():
+        worst[k] = rel_err(g.cpu().numpy(), z[f"s0_grad/{k}"])
+    bad = {k: v for k, v in worst.items() if v > GRAD_TOL}
+    assert not bad, bad
+    gn = float(torch.sqrt(tr.grad_sumsq()[0]))
+    assert abs(gn - float(z["s0_grad_norm"])) < 1e-5 * gn
+
+
+def test_two_optimizer_steps_vs_reference(golden):
+    """collate (replayed draws) -> forward/backward -> clip_grad_norm_ -> AdamW with the reference's grouping -> the
+    custom_cosine schedule, twice; compare with torch.optim.AdamW's parameters."""
+    z, cfg, sd = golden("train_tiny_ln")
+    tm = pkg("train")
+    tr = make_trainer(cfg, sd, lr=float(z["lr"]), betas=(float(z["beta1"]), float(z["beta2"])), eps=float(z["eps"]),
+                      weight_decay=float(z["weight_decay"]), max_grad_norm=float(z["max_grad_norm"]),
+                      lr_lambda=tm.lr_factor_custom_cosine(1, 4))
+    data = pkg("data")
+    for step in range(2):
+        kinds = z[f"s{step}_draw_kinds"]
+        draws = TO.ReplayDraws(kinds, [z[f"s{step}_draw_{i}"] for i in range(len(kinds))])
+        batch = data.maskgit_collate(dev(z[f"s{step}_ids"]), cfg, draws)
+        assert np.array_equal(batch["input_ids"].cpu().numpy(), z[f"s{step}_input_ids"])
+        out = tr.train_step(batch)
+        assert abs(float(out["loss"]) - float(z[f"s{step}_loss"])) < 2e-5 * float(z[f"s{step}_loss"])
+        assert abs(float(out["grad_norm"]) - float(z[f"s{step}_grad_norm"])) < 2e-5 * float(z[f"s{step}_grad_norm"])
+        assert abs(out["lr"] - float(z[f"s{step}_lr"])) < 1e-12
+    state = tr.model.state_dict()
+    for k in sd:
+        assert np.abs(state[k].cpu().numpy() - z[f"final_param/{k}"]).max() < 2.5e-5, k
+
+
+def test_real_geometry_vs_reference_samples(golden):
+    """T=16, S=256, Dh=64: the production tile shapes (MFMA attention forward, 256x256 score GEMMs backward)."""
+    z, cfg, sd = golden("train_shape_dh64")
+    tr = make_trainer(cfg, sd)
+    loss, _ = tr.forward_backward(dev(z["s0_input_ids"]), dev(z["s0_labels"]))
+    assert abs(float(loss) - float(z["s0_loss"])) < 1e-5 * float(z["s0_loss"])
+    for k, g in tr.gradients().items():
+        g = g.cpu().numpy()
+        n_ref = float(z[f"s0_gradnorm/{k}"])
+        assert abs(np.sqrt((g.astype(np.float64) ** 2).sum()) - n_ref) <= 2e-4 * n_ref + 1e-12, k
+        samp = g.reshape(-1)[:: max(1, g.size // 64)][:64]
+        assert np.abs(samp - z[f"s0_gradsample/{k}"]).max() <= 2e-4 * np.abs(g).max() + 1e-12, k
+
+
+@pytest.mark.parametrize("H,d,B", [(4, 128, 3), (2, 64, 1)])
+def test_gradients_vs_oracle(H, d, B):
+    """Other widths / head sizes (Dh = 32) and an odd batch against the NumPy restatement."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=H, d_model=d, T=4, S=16, num_factored_vocabs=2,
+                                    qk_norm=False, num_prompt_frames=2)
+    syn = pkg("synthetic")
+    sd = syn.make_state_dict(cfg, seed=77 + H, law="conditioned")
+    ids = syn.make_clips(B, cfg, seed=900 + d)
+    batch = TO.maskgit_collate(ids, cfg, TO.NumpyDraws(5 + B))
+    loss_o, acc_o, g_o = TO.forward_backward(batch["input_ids"], batch["labels"], sd, cfg)
+    tr = make_trainer(cfg, sd)
+    loss, acc = tr.forward_backward(dev(batch["input_ids"]), dev(batch["labels"]))
+    assert abs(float(loss) - loss_o) < 1e-5 * abs(loss_o)
+    assert abs(float(acc) - acc_o) < 1e-7
+    for k, g in tr.gradients().items():
+        assert rel_err(g.cpu().numpy(), g_o[k]) < GRAD_TOL, k
+
+
+def test_bit_reproducible_and_accumulation(golden):
+    z, cfg, sd = golden("train_tiny_ln")
+    tr = make_trainer(cfg, sd)
+    a_ids, a_lab = dev(z["s0_input_ids"]), dev(z["s0_labels"])
+    b_ids, b_lab = dev(z["s1_input_ids"]), dev(z["s1_labels"])
+    tr.forward_backward(a_ids, a_lab)
+    g1 = tr.grads.clone()
+    tr.forward_backward(a_ids, a_lab)
+    assert torch.equal(g1, tr.grads)  # fixed reduction order everywhere
+    tr.forward_backward(b_ids, b_lab)
+    g2 = tr.grads.clone()
+    tr.forward_backward(a_ids, a_lab)
+    tr.forward_backward(b_ids, b_lab, accumulate=True)
+    assert float((tr.grads - (g1 + g2)).abs().max()) <= 1e-6 * float(g1.abs().max())
+
+
+def test_unsupported_configs_fail_loudly(golden):
+    z, cfg, sd = golden("train_tiny_qknorm")
+    model = pkg("st_mask_git").STMaskGIT(cfg, precision="exact").load_numpy_state_dict(sd).to("cuda")
+    tr = pkg("train").GenieTrainer(model)
+    with pytest.raises(pkg("_lib").GenieHipError):
+        tr.forward_backward(dev(z["s0_input_ids"]), dev(z["s0_labels"]))
+    with pytest.raises(NotImplementedError):
+        pkg("train").GenieTrainer(pkg("st_mask_git").STMaskGIT(cfg, precision="bf16").to("cuda"))
+    with pytest.raises(RuntimeError):
+        tr.forward_backward(torch.from_numpy(z["s0_input_ids"]), torch.from_numpy(z["s0_labels"]))
