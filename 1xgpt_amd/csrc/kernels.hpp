@@ -117,8 +117,13 @@ int launch_gelu_fwd(const float* z, float* h, size_t n, hipStream_t st);
 int launch_gelu_bwd(const float* z, float* g, size_t n, hipStream_t st);
 int launch_softmax_rows(float* P, long rows, int N, hipStream_t st);
 int launch_softmax_bwd_rows(const float* P, float* dP, long rows, int N, hipStream_t st);
-int launch_attn_temporal_bwd(const float* qkv, const float* dO, float* dqkv, int B, int T, int S, int d, int H, int Dh,
-                             float scale, hipStream_t st);
+// q, k rows are read from `qk` (leading dim qk_ld; q at column 0, k at column d), v from qkv
+int launch_attn_temporal_bwd(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, int B, int T,
+                             int S, int d, int H, int Dh, float scale, hipStream_t st);
+int launch_qk_norm_fwd(const float* qkv, float* qkn, const float* nw, const float* nb, long M, int H, int Dh, int d,
+                       hipStream_t st);
+int launch_qk_norm_bwd(const float* qkv, float* dqkv, const float* nw, float* dnw, float* dnb, long M, int H, int Dh,
+                       int d, float beta, float* part, hipStream_t st);
 int launch_ce_fwd_bwd(const genie_cfg& c, float* logits, const int64_t* ids, const int64_t* labels, int B, double* sums,
                       hipStream_t st);
 int launch_embed_bwd(const genie_cfg& c, const float* dx, const int64_t* ids, int B, float* dpos, float* dmask,

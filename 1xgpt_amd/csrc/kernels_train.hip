@@ -398,7 +398,8 @@ int launch_softmax_bwd_rows(const float* P, float* dP, long rows, int N, hipStre
 //   dq_i = scale sum_j ds_ij k_j;  dk_j = scale sum_{i>=j} ds_ij q_i;  dv_j = sum_{i>=j} p_ij dO_i
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+__global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ qk,
+                                                               long qk_ld, const float* __restrict__ dO,
                                                                float* __restrict__ dqkv, int B, int T, int S, int d, int H,
                                                                float scale) {
     constexpr int GPB = 4, NMAX = 16, DHP = DH + 4;  // padded rows: threads of a group read different rows, same column
@@ -421,13 +422,14 @@ __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float* __re
         const long b = bs / S, s = bs - b * S;
         row = (b * T + i) * (long)S + s;
         const float* base = qkv + (size_t)row * 3 * d + head * DH;
+        const float* qb = qk + (size_t)row * qk_ld + head * DH;  // q at column 0, k at column d of the (normalised) source
         const float* dob = dO + (size_t)row * d + head * DH;
 #pragma unroll 4
         for (int c = 0; c < DH; c += 4) {
-            float4 q4 = *reinterpret_cast<const float4*>(base + c);
+            float4 q4 = *reinterpret_cast<const float4*>(qb + c);
             q4.x *= scale; q4.y *= scale; q4.z *= scale; q4.w *= scale;
             *reinterpret_cast<float4*>(sq + i * DHP + c) = q4;
-            *reinterpret_cast<float4*>(sk + i * DHP + c) = *reinterpret_cast<const float4*>(base + d + c);
+            *reinterpret_cast<float4*>(sk + i * DHP + c) = *reinterpret_cast<const float4*>(qb + d + c);
             *reinterpret_cast<float4*>(sv + i * DHP + c) = *reinterpret_cast<const float4*>(base + 2 * d + c);
             *reinterpret_cast<float4*>(sd + i * DHP + c) = *reinterpret_cast<const float4*>(dob + c);
         }
@@ -505,8 +507,8 @@ __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float* __re
             *reinterpret_cast<float4*>(o + 2 * d + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
     }
 }
-int launch_attn_temporal_bwd(const float* qkv, const float* dO, float* dqkv, int B, int T, int S, int d, int H, int Dh,
-                             float scale, hipStream_t st) {
+int launch_attn_temporal_bwd(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, int B, int T,
+                             int S, int d, int H, int Dh, float scale, hipStream_t st) {
     GENIE_CHECK_SHAPE(T <= 16, "temporal attention backward: T=%d > 16", T);
     const long n_grp = (long)B * S * H;
     if (n_grp <= 0) return GENIE_OK;
@@ -517,7 +519,7 @@ int launch_attn_temporal_bwd(const float* qkv, const float* dO, float* dqkv, int
         const size_t lds = (size_t)4 * (4 * 16 * (DH_ + 4) + 2 * 16 * 16) * sizeof(float);                        \
         (void)hipFuncSetAttribute((const void*)attn_temporal_bwd_kernel<DH_>,                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-        attn_temporal_bwd_kernel<DH_><<<blocks, 64, lds, st>>>(qkv, dO, dqkv, B, T, S, d, H, scale);         \
+        attn_temporal_bwd_kernel<DH_><<<blocks, 64, lds, st>>>(qkv, qk, qk_ld, dO, dqkv, B, T, S, d, H, scale); \
     }
     if (Dh == 64) TB_LAUNCH(64)
     else if (Dh == 32) TB_LAUNCH(32)
@@ -529,6 +531,110 @@ int launch_attn_temporal_bwd(const float* qkv, const float* dO, float* dqkv, int
 #undef TB_LAUNCH
     GENIE_LAUNCH_CHECK("attn_temporal_bwd");
     return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// qk-norm (attention.py:42-47): LayerNorm over head_dim of every q and k head row, ONE affine shared by q, k and all
+// heads.  Forward writes the normalised operands qkn (M, 2d) = [LN(q) | LN(k)] for the score GEMMs of the backward;
+// backward turns d/d(normalised) into d/d(raw) in place on the q,k columns of dqkv and emits the affine's gradient
+// partials.  DH/4 lanes per (row, q|k, head) item, float4 each.
+// ------------------------------------------------------------------------------------------------
+template <int LPI>
+__device__ __forceinline__ float sub_sum(float v) {
+#pragma unroll
+    for (int o = LPI / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int DH>
+__global__ __launch_bounds__(256) void qk_norm_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ qkn,
+                                                          const float* __restrict__ nw, const float* __restrict__ nb,
+                                                          long n_items, int H, int d) {
+    constexpr int LPI = DH / 4, IPB = 256 / LPI;
+    const long item = (long)blockIdx.x * IPB + threadIdx.x / LPI;
+    const int sub = threadIdx.x % LPI;
+    if (item >= n_items) return;
+    const long row = item / (2 * H);
+    const int rem = (int)(item - row * 2 * H), which = rem / H, head = rem - which * H;
+    const float4 v = *reinterpret_cast<const float4*>(qkv + (size_t)row * 3 * d + which * d + head * DH + sub * 4);
+    const float mean = sub_sum<LPI>(v.x + v.y + v.z + v.w) * (1.0f / DH);
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+    const float rstd = 1.0f / sqrtf(sub_sum<LPI>(a * a + b * b + c * c + e * e) * (1.0f / DH) + 1e-5f);
+    const float4 g = *reinterpret_cast<const float4*>(nw + sub * 4), bb = *reinterpret_cast<const float4*>(nb + sub * 4);
+    *reinterpret_cast<float4*>(qkn + (size_t)row * 2 * d + which * d + head * DH + sub * 4) =
+        make_float4(a * rstd * g.x + bb.x, b * rstd * g.y + bb.y, c * rstd * g.z + bb.z, e * rstd * g.w + bb.w);
+}
+constexpr int QKN_BLOCKS = 512;
+template <int DH>
+__global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const float* __restrict__ qkv, float* __restrict__ dqkv,
+                                                          const float* __restrict__ nw, float* __restrict__ part,
+                                                          long n_items, int H, int d) {
+    constexpr int LPI = DH / 4, IPB = 256 / LPI;
+    __shared__ float red[256][8];
+    const int sub = threadIdx.x % LPI;
+    const float4 g = *reinterpret_cast<const float4*>(nw + sub * 4);
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long item = (long)blockIdx.x * IPB + threadIdx.x / LPI; item < n_items; item += (long)gridDim.x * IPB) {
+        const long row = item / (2 * H);
+        const int rem = (int)(item - row * 2 * H), which = rem / H, head = rem - which * H;
+        const size_t off = (size_t)row * 3 * d + which * d + head * DH + sub * 4;
+        const float4 v = *reinterpret_cast<const float4*>(qkv + off);
+        const float4 dy = *reinterpret_cast<const float4*>(dqkv + off);
+        const float mean = sub_sum<LPI>(v.x + v.y + v.z + v.w) * (1.0f / DH);
+        float xh[4] = {v.x - mean, v.y - mean, v.z - mean, v.w - mean};
+        const float rstd =
+            1.0f / sqrtf(sub_sum<LPI>(xh[0] * xh[0] + xh[1] * xh[1] + xh[2] * xh[2] + xh[3] * xh[3]) * (1.0f / DH) + 1e-5f);
+        const float dyv[4] = {dy.x, dy.y, dy.z, dy.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        float gy[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xh[k] *= rstd;
+            gy[k] = dyv[k] * gv[k];
+            s1 += gy[k];
+            s2 += gy[k] * xh[k];
+            dg[k] += dyv[k] * xh[k];
+            db[k] += dyv[k];
+        }
+        s1 = sub_sum<LPI>(s1) * (1.0f / DH);
+        s2 = sub_sum<LPI>(s2) * (1.0f / DH);
+        *reinterpret_cast<float4*>(dqkv + off) = make_float4((gy[0] - s1 - xh[0] * s2) * rstd, (gy[1] - s1 - xh[1] * s2) * rstd,
+                                                            (gy[2] - s1 - xh[2] * s2) * rstd, (gy[3] - s1 - xh[3] * s2) * rstd);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = dg[k]; red[threadIdx.x][4 + k] = db[k]; }
+    __syncthreads();
+    if (threadIdx.x < 2 * DH) {  // part[block][which][DH]: channel c is held by the threads with sub == c/4
+        const int which = threadIdx.x / DH, c = threadIdx.x - which * DH;
+        float s = 0.f;
+        for (int t = c / 4; t < 256; t += LPI) s += red[t][which * 4 + (c & 3)];
+        part[(size_t)blockIdx.x * 2 * DH + threadIdx.x] = s;
+    }
+}
+int launch_qk_norm_fwd(const float* qkv, float* qkn, const float* nw, const float* nb, long M, int H, int Dh, int d,
+                       hipStream_t st) {
+    const long n_items = M * 2 * H;
+    if (n_items <= 0) return GENIE_OK;
+    const unsigned blocks = (unsigned)((n_items + (1024 / Dh) - 1) / (1024 / Dh));
+    if (Dh == 64) qk_norm_fwd_kernel<64><<<blocks, 256, 0, st>>>(qkv, qkn, nw, nb, n_items, H, d);
+    else if (Dh == 32) qk_norm_fwd_kernel<32><<<blocks, 256, 0, st>>>(qkv, qkn, nw, nb, n_items, H, d);
+    else if (Dh == 128) qk_norm_fwd_kernel<128><<<blocks, 256, 0, st>>>(qkv, qkn, nw, nb, n_items, H, d);
+    else { set_error("qk-norm: head_dim %d not in {32, 64, 128}", Dh); return GENIE_E_UNSUPPORTED; }
+    GENIE_LAUNCH_CHECK("qk_norm_fwd");
+    return GENIE_OK;
+}
+// in place on the q,k columns of dqkv; dnw/dnb (Dh) = beta * old + sums over rows, q and k, and heads
+int launch_qk_norm_bwd(const float* qkv, float* dqkv, const float* nw, float* dnw, float* dnb, long M, int H, int Dh,
+                       int d, float beta, float* part, hipStream_t st) {
+    const long n_items = M * 2 * H;
+    if (n_items <= 0) return GENIE_OK;
+    if (Dh == 64) qk_norm_bwd_kernel<64><<<QKN_BLOCKS, 256, 0, st>>>(qkv, dqkv, nw, part, n_items, H, d);
+    else if (Dh == 32) qk_norm_bwd_kernel<32><<<QKN_BLOCKS, 256, 0, st>>>(qkv, dqkv, nw, part, n_items, H, d);
+    else if (Dh == 128) qk_norm_bwd_kernel<128><<<QKN_BLOCKS, 256, 0, st>>>(qkv, dqkv, nw, part, n_items, H, d);
+    else { set_error("qk-norm: head_dim %d not in {32, 64, 128}", Dh); return GENIE_E_UNSUPPORTED; }
+    GENIE_LAUNCH_CHECK("qk_norm_bwd");
+    float* tmp = part + (size_t)QKN_BLOCKS * 2 * Dh;
+    GENIE_TRY(launch_slab_reduce(part, QKN_BLOCKS, (size_t)2 * Dh, tmp, 0.f, st));
+    GENIE_TRY(launch_slab_reduce(tmp, 1, (size_t)Dh, dnw, beta, st));
+    return launch_slab_reduce(tmp + Dh, 1, (size_t)Dh, dnb, beta, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ static TrainActs train_acts(const genie_cfg& c, int B) {
 
 struct TrainWs {
     float *dx, *d1, *g, *p, *dp, *slabs, *lnpart, *colpart;
+    float* qkn;  // (M, 2d) normalised q | k of the attention being differentiated (qk_norm only)
     double* dscratch;  // 1024 doubles (sumsq partials)
     size_t slab_floats, total;
 };
@@ -59,11 +60,13 @@ static TrainWs train_ws(const genie_cfg& c, int B, void* base) {
     w.slab_floats = 64 * maxw;
     const size_t o_sl = take(w.slab_floats), o_ln = take(ln_bwd_scratch_floats((int)d));
     const size_t o_cp = take((size_t)COLSUM_SCRATCH_ROWS * maxn), o_ds = take(2 * 1024);
+    const size_t o_qkn = take(c.qk_norm ? M * 2 * d : 0);
     w.total = o;
     char* b = (char*)base;
     w.dx = (float*)(b + o_dx); w.d1 = (float*)(b + o_d1); w.g = (float*)(b + o_g); w.p = (float*)(b + o_p);
     w.dp = (float*)(b + o_dp); w.slabs = (float*)(b + o_sl); w.lnpart = (float*)(b + o_ln);
     w.colpart = (float*)(b + o_cp); w.dscratch = (double*)(b + o_ds);
+    w.qkn = (float*)(b + o_qkn);
     return w;
 }
 
@@ -72,10 +75,6 @@ static int train_check(const genie_cfg* c, int B) {
     GENIE_TRY(genie_check_config(c));
     if (c->precision != GENIE_PREC_EXACT) {
         set_error("training step: only GENIE_PREC_EXACT is built (precision=%d)", c->precision);
-        return GENIE_E_UNSUPPORTED;
-    }
-    if (c->qk_norm) {
-        set_error("training step: qk_norm=true is not built yet (LayerNorm over head_dim in the attention backward)");
         return GENIE_E_UNSUPPORTED;
     }
     GENIE_CHECK_SHAPE(c->S % 16 == 0 && c->head_dim % 16 == 0 && c->d_model % 16 == 0 && c->hidden % 16 == 0 && c->T <= 16,
@@ -95,31 +94,55 @@ static int dgrad(const float* dy, const float* W, const float* R, float* dx, int
                                st);
 }
 
-static int spatial_attn_fwd(const genie_cfg& c, const float* qkv, float* ao, int B, hipStream_t st) {
+static int spatial_attn_fwd(const genie_cfg& c, const genie_attn_weights& aw, const float* qkv, float* ao, int B,
+                            hipStream_t st) {
+    const float* nw = c.qk_norm ? aw.norm_w : nullptr;
+    const float* nb = c.qk_norm ? aw.norm_b : nullptr;
     int rc = launch_attn_spatial_f32_mfma(qkv, ao, c.S, (long)B * c.T, c.d_model, c.num_heads, c.head_dim, c.attn_scale,
-                                          nullptr, nullptr, st);
+                                          nw, nb, st);
     if (rc == GENIE_E_UNSUPPORTED)
         rc = launch_attn_generic(qkv, ao, c.S, (long)B * c.T, 1, c.S, 0, 1, c.d_model, c.num_heads, c.head_dim,
-                                 c.attn_scale, 0, nullptr, nullptr, st);
+                                 c.attn_scale, 0, nw, nb, st);
     return rc;
 }
-static int temporal_attn_fwd(const genie_cfg& c, const float* qkv, float* ao, int B, hipStream_t st) {
-    int rc = launch_attn_temporal_f32_mfma(qkv, ao, B, c.T, c.S, c.d_model, c.num_heads, c.head_dim, c.attn_scale, nullptr,
-                                           nullptr, st);
+static int temporal_attn_fwd(const genie_cfg& c, const genie_attn_weights& aw, const float* qkv, float* ao, int B,
+                             hipStream_t st) {
+    const float* nw = c.qk_norm ? aw.norm_w : nullptr;
+    const float* nb = c.qk_norm ? aw.norm_b : nullptr;
+    int rc = launch_attn_temporal_f32_mfma(qkv, ao, B, c.T, c.S, c.d_model, c.num_heads, c.head_dim, c.attn_scale, nw, nb,
+                                           st);
     if (rc == GENIE_E_UNSUPPORTED)
         rc = launch_attn_generic(qkv, ao, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, c.d_model, c.num_heads,
-                                 c.head_dim, c.attn_scale, 1, nullptr, nullptr, st);
+                                 c.head_dim, c.attn_scale, 1, nw, nb, st);
     return rc;
+}
+// where the backward reads q and k: the saved qkv itself, or (qk_norm) their LayerNorm'd copies in w.qkn
+struct QkSrc { const float* p; long ld; };
+static int qk_source(const genie_cfg& c, const genie_attn_weights& aw, const float* qkv, TrainWs& w, int B, QkSrc* out,
+                     hipStream_t st) {
+    if (!c.qk_norm) { *out = QkSrc{qkv, 3L * c.d_model}; return GENIE_OK; }
+    GENIE_TRY(launch_qk_norm_fwd(qkv, w.qkn, aw.norm_w, aw.norm_b, (long)B * c.T * c.S, c.num_heads, c.head_dim, c.d_model,
+                                 st));
+    *out = QkSrc{w.qkn, 2L * c.d_model};
+    return GENIE_OK;
+}
+// d/d(normalised q,k) -> d/d(raw q,k) in place, and the shared affine's gradient
+static int qk_norm_backward(const genie_cfg& c, const genie_attn_weights& aw, const genie_attn_weights& g, const float* qkv,
+                            float* dqkv, TrainWs& w, int B, float beta, hipStream_t st) {
+    if (!c.qk_norm) return GENIE_OK;
+    return launch_qk_norm_bwd(qkv, dqkv, aw.norm_w, (float*)g.norm_w, (float*)g.norm_b, (long)B * c.T * c.S, c.num_heads,
+                              c.head_dim, c.d_model, beta, w.lnpart, st);
 }
 
 // spatial attention backward through materialised scores: qkv (M,3d), dao (M,d) -> dqkv (M,3d)
-static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, const float* dao, float* dqkv, TrainWs& w, int B,
-                            hipStream_t st) {
+static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, QkSrc qk, const float* dao, float* dqkv, TrainWs& w,
+                            int B, hipStream_t st) {
     const int S = c.S, d = c.d_model, H = c.num_heads, Dh = c.head_dim, BT = B * c.T;
     const long q3 = (long)S * 3 * d, ss = (long)S * S, hss = (long)H * ss, sd = (long)S * d;
+    const long qld = qk.ld, qs = (long)S * qk.ld;
     const float sc = c.attn_scale;
     // P = softmax(scale Q K^T)
-    GENIE_TRY(launch_gemm_f32_gen(false, false, qkv, 3 * d, q3, Dh, qkv + d, 3 * d, q3, Dh, nullptr, nullptr, w.p, S, hss,
+    GENIE_TRY(launch_gemm_f32_gen(false, false, qk.p, qld, qs, Dh, qk.p + d, qld, qs, Dh, nullptr, nullptr, w.p, S, hss,
                                   ss, S, S, Dh, BT, H, 1, 0, sc, st));
     GENIE_TRY(launch_softmax_rows(w.p, (long)BT * H * S, S, st));
     // dV = P^T dO
@@ -130,9 +153,9 @@ static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, const float* d
                                   ss, S, S, Dh, BT, H, 1, 0, 1.0f, st));
     GENIE_TRY(launch_softmax_bwd_rows(w.p, w.dp, (long)BT * H * S, S, st));
     // dQ = scale dS K,  dK = scale dS^T Q
-    GENIE_TRY(launch_gemm_f32_gen(false, true, w.dp, S, hss, ss, qkv + d, 3 * d, q3, Dh, nullptr, nullptr, dqkv, 3 * d, q3,
+    GENIE_TRY(launch_gemm_f32_gen(false, true, w.dp, S, hss, ss, qk.p + d, qld, qs, Dh, nullptr, nullptr, dqkv, 3 * d, q3,
                                   Dh, S, Dh, S, BT, H, 1, 0, sc, st));
-    GENIE_TRY(launch_gemm_f32_gen(true, true, w.dp, S, hss, ss, qkv, 3 * d, q3, Dh, nullptr, nullptr, dqkv + d, 3 * d, q3,
+    GENIE_TRY(launch_gemm_f32_gen(true, true, w.dp, S, hss, ss, qk.p, qld, qs, Dh, nullptr, nullptr, dqkv + d, 3 * d, q3,
                                   Dh, S, Dh, S, BT, H, 1, 0, sc, st));
     return GENIE_OK;
 }
@@ -167,19 +190,22 @@ int genie_train_forward(const genie_cfg* cfg, const genie_weights* wt, const int
         const genie_layer_weights& lw = wt->layers_host[l];
         float* L = acts + a.per_layer * l;
         float* xnext = (l + 1 < c.num_layers) ? acts + a.per_layer * (l + 1) + a.o_x0 : acts + a.o_xL;
-        GENIE_TRY(launch_layer_norm(L + a.o_x0, lw.norm1_w, lw.norm1_b, L + a.o_u1, M, d, 1e-5f, st));
-        GENIE_TRY(lin(L + a.o_u1, d, lw.spatial.qkv_w, c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, L + a.o_qkvs,
+        // qk_norm: norm1/norm2 are Identity (st_transformer.py:44,67) and the u1/u2 slots stay unused
+        const float* u1 = c.qk_norm ? L + a.o_x0 : L + a.o_u1;
+        const float* u2 = c.qk_norm ? L + a.o_x2 : L + a.o_u2;
+        if (!c.qk_norm) GENIE_TRY(launch_layer_norm(L + a.o_x0, lw.norm1_w, lw.norm1_b, L + a.o_u1, M, d, 1e-5f, st));
+        GENIE_TRY(lin(u1, d, lw.spatial.qkv_w, c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, L + a.o_qkvs,
                       3 * d, M, 3 * d, d, 1.0f, st));
-        GENIE_TRY(spatial_attn_fwd(c, L + a.o_qkvs, L + a.o_aos, B, st));
+        GENIE_TRY(spatial_attn_fwd(c, lw.spatial, L + a.o_qkvs, L + a.o_aos, B, st));
         GENIE_TRY(lin(L + a.o_aos, d, lw.spatial.proj_w, c.proj_bias ? lw.spatial.proj_b : nullptr, L + a.o_x0,
                       L + a.o_x1, d, M, d, d, 1.0f, st));
         GENIE_TRY(lin(L + a.o_x1, d, lw.temporal.qkv_w, c.qkv_bias ? lw.temporal.qkv_b : nullptr, nullptr, L + a.o_qkvt,
                       3 * d, M, 3 * d, d, 1.0f, st));
-        GENIE_TRY(temporal_attn_fwd(c, L + a.o_qkvt, L + a.o_aot, B, st));
+        GENIE_TRY(temporal_attn_fwd(c, lw.temporal, L + a.o_qkvt, L + a.o_aot, B, st));
         GENIE_TRY(lin(L + a.o_aot, d, lw.temporal.proj_w, c.proj_bias ? lw.temporal.proj_b : nullptr, L + a.o_x1,
                       L + a.o_x2, d, M, d, d, 1.0f, st));
-        GENIE_TRY(launch_layer_norm(L + a.o_x2, lw.norm2_w, lw.norm2_b, L + a.o_u2, M, d, 1e-5f, st));
-        GENIE_TRY(lin(L + a.o_u2, d, lw.fc1_w, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, L + a.o_z, hid, M, hid, d, 1.0f,
+        if (!c.qk_norm) GENIE_TRY(launch_layer_norm(L + a.o_x2, lw.norm2_w, lw.norm2_b, L + a.o_u2, M, d, 1e-5f, st));
+        GENIE_TRY(lin(u2, d, lw.fc1_w, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, L + a.o_z, hid, M, hid, d, 1.0f,
                       st));
         GENIE_TRY(launch_gelu_fwd(L + a.o_z, L + a.o_h, (size_t)M * hid, st));
         GENIE_TRY(lin(L + a.o_h, hid, lw.fc2_w, c.mlp_bias ? lw.fc2_b : nullptr, L + a.o_x2, xnext, d, M, d, hid, 1.0f,
@@ -228,25 +254,34 @@ int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* wt, co
     const genie_layer_weights& g = grads->layers_host[layer];
     const float* L = acts + a.per_layer * layer;
     float* dx = w.dx;
+    const float* u1 = c.qk_norm ? L + a.o_x0 : L + a.o_u1;
+    const float* u2 = c.qk_norm ? L + a.o_x2 : L + a.o_u2;
+    QkSrc qk;
 
     // ---- MLP: x3 = x2 + fc2(gelu(fc1(norm2(x2))))  (st_transformer.py:81, 16-25)
     GENIE_TRY(launch_wgrad_f32(dx, d, L + a.o_h, hid, (float*)g.fc2_w, M, d, hid, 1.0f, beta, w.slabs, w.slab_floats, st));
     if (c.mlp_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.fc2_b, beta, w.colpart, st));
     GENIE_TRY(dgrad(dx, lw.fc2_w, nullptr, w.g, M, d, hid, 1.0f, st));          // dh
     GENIE_TRY(launch_gelu_bwd(L + a.o_z, w.g, (size_t)M * hid, st));            // dz
-    GENIE_TRY(launch_wgrad_f32(w.g, hid, L + a.o_u2, d, (float*)g.fc1_w, M, hid, d, 1.0f, beta, w.slabs, w.slab_floats,
-                               st));
+    GENIE_TRY(launch_wgrad_f32(w.g, hid, u2, d, (float*)g.fc1_w, M, hid, d, 1.0f, beta, w.slabs, w.slab_floats, st));
     if (c.mlp_bias) GENIE_TRY(launch_colsum(w.g, hid, M, hid, (float*)g.fc1_b, beta, w.colpart, st));
-    GENIE_TRY(dgrad(w.g, lw.fc1_w, nullptr, w.d1, M, hid, d, 1.0f, st));        // d norm2 output
-    GENIE_TRY(launch_ln_bwd(L + a.o_x2, lw.norm2_w, w.d1, dx, (float*)g.norm2_w, (float*)g.norm2_b, M, d, 1e-5f, beta,
-                            w.lnpart, st));
+    if (c.qk_norm) {
+        GENIE_TRY(dgrad(w.g, lw.fc1_w, dx, dx, M, hid, d, 1.0f, st));           // Identity norm: dx += dz . W1
+    } else {
+        GENIE_TRY(dgrad(w.g, lw.fc1_w, nullptr, w.d1, M, hid, d, 1.0f, st));    // d norm2 output
+        GENIE_TRY(launch_ln_bwd(L + a.o_x2, lw.norm2_w, w.d1, dx, (float*)g.norm2_w, (float*)g.norm2_b, M, d, 1e-5f, beta,
+                                w.lnpart, st));
+    }
 
     // ---- temporal: x2 = x1 + proj(attn(qkv(x1))), no pre-norm  (st_transformer.py:77-78)
     GENIE_TRY(launch_wgrad_f32(dx, d, L + a.o_aot, d, (float*)g.temporal.proj_w, M, d, d, 1.0f, beta, w.slabs,
                                w.slab_floats, st));
     if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.temporal.proj_b, beta, w.colpart, st));
     GENIE_TRY(dgrad(dx, lw.temporal.proj_w, nullptr, w.d1, M, d, d, 1.0f, st));  // d attention output
-    GENIE_TRY(launch_attn_temporal_bwd(L + a.o_qkvt, w.d1, w.g, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, st));
+    GENIE_TRY(qk_source(c, lw.temporal, L + a.o_qkvt, w, B, &qk, st));
+    GENIE_TRY(launch_attn_temporal_bwd(L + a.o_qkvt, qk.p, qk.ld, w.d1, w.g, B, c.T, c.S, d, c.num_heads, c.head_dim,
+                                       c.attn_scale, st));
+    GENIE_TRY(qk_norm_backward(c, lw.temporal, g.temporal, L + a.o_qkvt, w.g, w, B, beta, st));
     GENIE_TRY(launch_wgrad_f32(w.g, 3 * d, L + a.o_x1, d, (float*)g.temporal.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs,
                                w.slab_floats, st));
     if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.temporal.qkv_b, beta, w.colpart, st));
@@ -257,10 +292,13 @@ int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* wt, co
                                st));
     if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.spatial.proj_b, beta, w.colpart, st));
     GENIE_TRY(dgrad(dx, lw.spatial.proj_w, nullptr, w.d1, M, d, d, 1.0f, st));
-    GENIE_TRY(spatial_attn_bwd(c, L + a.o_qkvs, w.d1, w.g, w, B, st));
-    GENIE_TRY(launch_wgrad_f32(w.g, 3 * d, L + a.o_u1, d, (float*)g.spatial.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs,
+    GENIE_TRY(qk_source(c, lw.spatial, L + a.o_qkvs, w, B, &qk, st));
+    GENIE_TRY(spatial_attn_bwd(c, L + a.o_qkvs, qk, w.d1, w.g, w, B, st));
+    GENIE_TRY(qk_norm_backward(c, lw.spatial, g.spatial, L + a.o_qkvs, w.g, w, B, beta, st));
+    GENIE_TRY(launch_wgrad_f32(w.g, 3 * d, u1, d, (float*)g.spatial.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs,
                                w.slab_floats, st));
     if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.spatial.qkv_b, beta, w.colpart, st));
+    if (c.qk_norm) return dgrad(w.g, lw.spatial.qkv_w, dx, dx, M, 3 * d, d, 1.0f, st);
     GENIE_TRY(dgrad(w.g, lw.spatial.qkv_w, nullptr, w.d1, M, 3 * d, d, 1.0f, st));  // d norm1 output
     return launch_ln_bwd(L + a.o_x0, lw.norm1_w, w.d1, dx, (float*)g.norm1_w, (float*)g.norm1_b, M, d, 1e-5f, beta, w.lnpart,
                          st);

@@ -293,8 +293,8 @@ int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_
 int genie_rescale_u8_nhwc_bf16(const uint16_t* x, uint8_t* out, int n, int HW, int cpad, int cout, void* stream);
 
 /* ---- training step (train.py:600-633) -------------------------------------------
- * GENIE_PREC_EXACT, qk_norm = false (the shipped config) in this ABI version; anything else returns
- * GENIE_E_UNSUPPORTED.  Gradients travel in a second genie_weights table whose pointers address the caller's
+ * GENIE_PREC_EXACT in this ABI version (other precisions return GENIE_E_UNSUPPORTED); both the LayerNorm
+ * (qk_norm = false, the shipped config) and the qk-norm block variants.  Gradients travel in a second genie_weights table whose pointers address the caller's
  * gradient buffers (same shapes as the parameters; the *_w16 members are ignored).  `accumulate` = 0 overwrites the
  * gradients (optimizer.zero_grad() + backward), 1 adds to them (gradient accumulation, train.py:607-617).
  * Every reduction feeding a gradient has a fixed order: results are bit-reproducible run to run. */
