@@ -81,10 +81,13 @@ SIGNATURES = {
     "genie_train_workspace_bytes": (C.c_size_t, [C.POINTER(GenieCfg), C.c_int]),
     "genie_train_forward": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t,
                                       c_ptr, c_ptr]),
-    "genie_train_backward_head": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), C.POINTER(Weights), C.c_int, c_ptr,
-                                            c_ptr, C.c_size_t, C.c_int, c_ptr]),
-    "genie_train_backward_layer": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), C.POINTER(Weights), C.c_int, C.c_int,
-                                             c_ptr, c_ptr, C.c_size_t, C.c_int, c_ptr]),
+    "genie_train_pack_weights": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), C.POINTER(Weights),
+                                           C.POINTER(Weights), c_ptr]),
+    "genie_train_backward_head": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), C.POINTER(Weights),
+                                            C.POINTER(Weights), C.c_int, c_ptr, c_ptr, C.c_size_t, C.c_int, c_ptr]),
+    "genie_train_backward_layer": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), C.POINTER(Weights),
+                                             C.POINTER(Weights), C.c_int, C.c_int, c_ptr, c_ptr, C.c_size_t, C.c_int,
+                                             c_ptr]),
     "genie_train_backward_embed": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, c_ptr, C.c_size_t,
                                              C.c_int, c_ptr]),
     "genie_sumsq": (C.c_int, [c_ptr, C.c_size_t, c_ptr, c_ptr, c_ptr]),

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
                                                         const float* __restrict__ bias, float* __restrict__ Cf,
                                                         uint16_t* __restrict__ C16, long plane16, long ldc, int M,
                                                         int N, int K, int flags, float alpha, long strideA,
-                                                        long strideC) {
+                                                        long strideC, const float* Rf, long strideW) {
     constexpr int BM = 128, BN = 128;
     constexpr int ROWB = BK * 2;              // bytes per tile row
     constexpr int SPR = ROWB / 16;            // 16-byte slots per row
@@ -61,8 +61,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
     const int n_tiles = (N + BN - 1) / BN;
     const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
     A += (size_t)blockIdx.y * strideA;
+    W += (size_t)blockIdx.y * strideW;
     if (Cf) Cf += (size_t)blockIdx.y * strideC;
     if (C16) C16 += (size_t)blockIdx.y * strideC;
+    // residual source of G16_ACCUM: Cf itself (in place) unless the caller keeps the input (training: Rf != Cf)
+    const float* Rsrc = Rf ? Rf + (size_t)blockIdx.y * strideC : Cf;
 
     // ---- staging addresses: wave w moves chunks w*NCHUNK/4 .. of every plane tile
     constexpr int CPW = NCHUNK / 4;  // chunks per wave per plane tile
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
             if (do_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
             const size_t idx = (size_t)row * ldc + col;
             if (do_acc) {
-                const float4 o = *reinterpret_cast<const float4*>(Cf + idx);
+                const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
                 float v = vv[c] * alpha + (bias ? bias[col + c] : 0.f);
                 if (do_gelu) v = gelu_erf(v);
                 const size_t idx = (size_t)row * ldc + col + c;
-                if (do_acc) v += Cf[idx];
+                if (do_acc) v += Rsrc[idx];
                 if (outf) Cf[idx] = v;
                 if (out16) store16<NPL>(C16, (size_t)plane16, idx, v);
             }
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
                                                            const float* __restrict__ bias, float* __restrict__ Cf,
                                                            uint16_t* __restrict__ C16, long plane16, long ldc, int M,
                                                            int N, int K, int flags, float alpha, long strideA,
-                                                           long strideC) {
+                                                           long strideC, const float* Rf, long strideW) {
     constexpr int BM = 256, BN = 128, NST = 3;
     constexpr int ROWB = BK * 2, SPR = ROWB / 16, RPB = 256 / ROWB;
     constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB;
@@ -265,8 +268,11 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     A += (size_t)blockIdx.y * strideA;
+    W += (size_t)blockIdx.y * strideW;
     if (Cf) Cf += (size_t)blockIdx.y * strideC;
     if (C16) C16 += (size_t)blockIdx.y * strideC;
+    // residual source of G16_ACCUM: Cf itself (in place) unless the caller keeps the input (training: Rf != Cf)
+    const float* Rsrc = Rf ? Rf + (size_t)blockIdx.y * strideC : Cf;
 
     // ---- staging: chunk c = wid + 8*i of the stage image [A pl0 .. | W pl0 ..]
     const uint16_t* gsrc[CPW];
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
         if (do_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         const size_t idx = (size_t)row * ldc + col;
         if (do_acc) {
-            const float4 o = *reinterpret_cast<const float4*>(Cf + idx);
+            const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
         if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
@@ -484,7 +490,8 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
 template <int NPL>
 static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                          const float* bias, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,
-                         int flags, float alpha, hipStream_t st, int batch = 1, long strideA = 0, long strideC = 0) {
+                         int flags, float alpha, hipStream_t st, int batch = 1, long strideA = 0, long strideC = 0,
+                         const float* Rf = nullptr, long strideW = 0) {
     constexpr int BK = NPL == 1 ? 64 : 32;
     GENIE_CHECK_SHAPE(K % BK == 0 && K > 0, "gemm16: K=%d must be a positive multiple of %d", K, BK);
     GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
@@ -508,12 +515,14 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
             (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             gemm16_v2_kernel<NPL, BK, 4><<<dim3(mt2 * nt2, batch), 1024, lds2, st>>>(
-                A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC);
+                A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,
+                strideW);
         } else {
             (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK, 2>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             gemm16_v2_kernel<NPL, BK, 2><<<dim3(mt2 * nt2, batch), 512, lds2, st>>>(
-                A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC);
+                A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,
+                strideW);
         }
         GENIE_LAUNCH_CHECK("gemm16_v2");
         return GENIE_OK;
@@ -528,9 +537,22 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
                               (int)lds);
     gemm16_nt_kernel<NPL, BK><<<dim3(mt * nt, batch), 256, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,
                                                                       plane16, ldc, M, N, K, flags, alpha, strideA,
-                                                                      strideC);
+                                                                      strideC, Rf, strideW);
     GENIE_LAUNCH_CHECK("gemm16");
     return GENIE_OK;
+}
+
+// Non-template entry for the training step (kernels_train16.hip): npl = 1 bf16, 2 = f16 split planes.
+//   Rf: residual source when it must differ from Cf (G16_ACCUM);  batch > 1 strides A, W and C (split-K slabs:
+//   strideA = strideW = K elements of one slab, strideC = M*N)
+int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
+                     const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N,
+                     int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC) {
+    if (npl == 1)
+        return launch_gemm16<1>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, st,
+                                batch, strideA, strideC, Rf, strideW);
+    return launch_gemm16<2>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, st, batch,
+                            strideA, strideC, Rf, strideW);
 }
 
 // ---- elementwise helpers -----------------------------------------------------------------------

@@ -170,17 +170,34 @@ int launch_gemm_f32_gen(bool ta, bool tb, const float* A, long lda, long sA1, lo
     return GENIE_OK;
 }
 
-// out[i] = beta * out[i] + sum_{s < ns} part[s*n + i]   (fixed order)
-__global__ void slab_reduce_kernel(const float* __restrict__ part, int ns, size_t n, float* __restrict__ out, float beta) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < ns; ++k) s += part[(size_t)k * n + i];
-    out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
+// out[i] = beta * out[i] + sum_{s < ns} part[s*n + i].  Fixed order: thread group g (0..3) of a block sums slabs
+// g, g+4, g+8, ... of its 64 columns with 4 independent chains, then the 4 group sums are added 0+1+2+3.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, int ns, size_t n,
+                                                          float* __restrict__ out, float beta) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int k = g;
+        for (; k + 12 < ns; k += 16) {
+            s0 += part[(size_t)k * n + i];
+            s1 += part[(size_t)(k + 4) * n + i];
+            s2 += part[(size_t)(k + 8) * n + i];
+            s3 += part[(size_t)(k + 12) * n + i];
+        }
+        for (; k < ns; k += 4) s0 += part[(size_t)k * n + i];
+    }
+    red[g][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < n) {
+        const float s = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+        out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
+    }
 }
 int launch_slab_reduce(const float* part, int ns, size_t n, float* out, float beta, hipStream_t st) {
     if (!n) return GENIE_OK;
-    slab_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, ns, n, out, beta);
+    slab_reduce_kernel<<<(unsigned)((n + 63) / 64), 256, 0, st>>>(part, ns, n, out, beta);
     GENIE_LAUNCH_CHECK("slab_reduce");
     return GENIE_OK;
 }
@@ -744,30 +761,47 @@ __global__ __launch_bounds__(256) void embed_bwd_tables_kernel(const float* __re
                                                                long n_tok, int d, int vf, int nfac, int64_t mask_id,
                                                                EmbedTables tables, float* __restrict__ dmask,
                                                                float beta) {
-    __shared__ int64_t sid[1024];
+    // One block per table row (and one for the mask row).  The block sweeps the ids 1024 at a time: every thread tests
+    // 4 tokens, wave ballots give an ORDERED match list (token index ascending), and the (rare: 1/vf) matching rows
+    // of dx are summed channel-parallel in that order -- no atomics, no sort, bit-reproducible.
+    __shared__ unsigned long long masks[4][4];  // [k][wave]: tokens base + k*256 + wave*64 + bit
     const int blk = blockIdx.x;
     const bool is_mask_row = blk == nfac * vf;
     const int f = is_mask_row ? 0 : blk / vf, v = is_mask_row ? 0 : blk - f * vf;
     int64_t div = 1;
     for (int k = 0; k < f; ++k) div *= vf;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};  // channels threadIdx.x + 256*k, d <= 1024
     for (long base = 0; base < n_tok; base += 1024) {
-        const int cnt = (int)((n_tok - base) < 1024 ? (n_tok - base) : 1024);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += 256) sid[i] = ids[base + i];
-        __syncthreads();
-        for (int i = 0; i < cnt; ++i) {
-            const int64_t id = sid[i];
-            const bool m = is_mask_row ? (id == mask_id) : (id != mask_id && (int)((id / div) % vf) == v);
-            if (m) {
-                const float* r = dx + (size_t)(base + i) * d;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = threadIdx.x + 256 * k;
-                    if (c < d) acc[k] += r[c];
+        for (int k = 0; k < 4; ++k) {
+            const long i = base + k * 256 + threadIdx.x;
+            bool m = false;
+            if (i < n_tok) {
+                const int64_t id = ids[i];
+                m = is_mask_row ? (id == mask_id) : (id != mask_id && (int)((id / div) % vf) == v);
+            }
+            const unsigned long long bal = __ballot(m);
+            if (lane == 0) masks[k][wid] = bal;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long bits = masks[k][w];
+                while (bits) {
+                    const int bit = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const float* r = dx + (size_t)(base + k * 256 + w * 64 + bit) * d;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const int c = threadIdx.x + 256 * c4;
+                        if (c < d) acc[c4] += r[c];
+                    }
                 }
             }
-        }
+        __syncthreads();
     }
     float* out = is_mask_row ? dmask : tables.p[f] + (size_t)v * d;
 #pragma unroll

@@ -73,10 +73,10 @@ static TrainWs train_ws(const genie_cfg& c, int B, void* base) {
 static int train_check(const genie_cfg* c, int B) {
     GENIE_CHECK_ARG(c != nullptr && B > 0, "training: cfg is NULL or B <= 0");
     GENIE_TRY(genie_check_config(c));
-    if (c->precision != GENIE_PREC_EXACT) {
-        set_error("training step: only GENIE_PREC_EXACT is built (precision=%d)", c->precision);
-        return GENIE_E_UNSUPPORTED;
-    }
+    if (c->precision != GENIE_PREC_EXACT)  // 16-bit GEMM operands: 64x64 transposition tiles, K-steps of 64
+        GENIE_CHECK_SHAPE(c->d_model % 64 == 0 && c->hidden % 64 == 0 && (c->T * c->S) % 64 == 0 &&
+                              (c->factored_vocab * c->num_factored) % 64 == 0,
+                          "training step (16-bit): d_model, hidden, T*S and the vocabulary rows must be multiples of 64");
     GENIE_CHECK_SHAPE(c->S % 16 == 0 && c->head_dim % 16 == 0 && c->d_model % 16 == 0 && c->hidden % 16 == 0 && c->T <= 16,
                       "training step: S, head_dim, d_model, hidden must be multiples of 16 and T <= 16");
     return GENIE_OK;
@@ -160,6 +160,257 @@ static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, QkSrc qk, cons
     return GENIE_OK;
 }
 
+
+// ================================================================================================
+// 16-bit matrix-core variant (GENIE_PREC_BF16 / GENIE_PREC_F16X3): every Linear product -- forward, dgrad, wgrad --
+// runs on the NT 16-bit GEMM of kernels_bf16.hip; LayerNorm, softmax, both attention cores (forward and backward),
+// GELU, the residual stream, CE and all gradient reductions stay f32 exactly as in the exact variant.
+// Saved per layer (bytes/token: 52 d f32 + 18 d NPL 16-bit): f32 x0, qkv_s, x1, qkv_t, x2, z;  16-bit GEMM operands
+// u1 = norm1(x0), ao_s, x1, ao_t, u2 = norm2(x2), h = gelu(z).
+// ================================================================================================
+struct TrainActs16 {
+    size_t per_layer;                            // bytes
+    size_t x0, qkvs, x1, qkvt, x2, z;            // byte offsets inside a layer (f32)
+    size_t u1, aos, x1h, aot, u2, h;             // byte offsets inside a layer (16-bit, NPL planes)
+    size_t xL, xL16, logits, total;              // byte offsets in the buffer
+};
+static TrainActs16 train_acts16(const genie_cfg& c, int B, int npl) {
+    const size_t M = (size_t)B * c.T * c.S, d = c.d_model, hid = c.hidden;
+    const size_t V = (size_t)c.factored_vocab * c.num_factored;
+    TrainActs16 a;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    a.x0 = take(M * d * 4); a.qkvs = take(M * 3 * d * 4); a.x1 = take(M * d * 4); a.qkvt = take(M * 3 * d * 4);
+    a.x2 = take(M * d * 4); a.z = take(M * hid * 4);
+    a.u1 = take(M * d * 2 * npl); a.aos = take(M * d * 2 * npl); a.x1h = take(M * d * 2 * npl);
+    a.aot = take(M * d * 2 * npl); a.u2 = take(M * d * 2 * npl); a.h = take(M * hid * 2 * npl);
+    a.per_layer = o;
+    o = a.per_layer * c.num_layers;
+    a.xL = take(M * d * 4); a.xL16 = take(M * d * 2 * npl); a.logits = take(M * V * 4);
+    a.total = o;
+    return a;
+}
+struct TrainWs16 {
+    uint16_t *dy16, *dy16T, *xT16;
+    size_t total;
+};
+// appended behind the exact workspace
+static TrainWs16 train_ws16(const genie_cfg& c, int B, int npl, void* base, size_t exact_total) {
+    const size_t M = (size_t)B * c.T * c.S, d = c.d_model;
+    const size_t V = (size_t)c.factored_vocab * c.num_factored;
+    size_t wide = (size_t)(3 * d > (size_t)c.hidden ? 3 * d : c.hidden);
+    if (V > wide) wide = V;
+    size_t o = exact_total;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    const size_t o1 = take(M * wide * 2 * npl), o2 = take(M * wide * 2 * npl), o3 = take(M * wide * 2 * npl);
+    TrainWs16 w;
+    w.total = o;
+    char* b = (char*)base;
+    w.dy16 = (uint16_t*)(b + o1); w.dy16T = (uint16_t*)(b + o2); w.xT16 = (uint16_t*)(b + o3);
+    return w;
+}
+static inline int npl_of(const genie_cfg& c) { return c.precision == GENIE_PREC_BF16 ? 1 : 2; }
+static inline long PL(int npl, size_t n) { return npl == 2 ? (long)n : 0; }
+
+// y(f32) / y16 = x16 . W16^T (+b) (+R)
+static int lin16(int npl, const uint16_t* x16, size_t nx, const uint16_t* W16, const float* b, const float* R, float* y,
+                 uint16_t* y16, int M, int N, int K, float alpha, hipStream_t st) {
+    int flags = 0;
+    if (y) flags |= G16X_OUTF32;
+    if (y16) flags |= G16X_OUT16;
+    if (R) flags |= G16X_ACCUM;
+    return launch_gemm16_ex(npl, x16, K, PL(npl, nx), W16, K, PL(npl, (size_t)N * K), b, (R && R != y) ? R : nullptr, y, y16,
+                            PL(npl, (size_t)M * N), N, M, N, K, flags, alpha, st, 1, 0, 0, 0);
+}
+// dW[N,K] (beta*dW +)= alpha * dY^T . X from the TRANSPOSED 16-bit copies dYT (N, Mtok), XT (K, Mtok)
+static int wgrad16(int npl, const uint16_t* dYT, const uint16_t* XT, float* dW, int Mtok, int N, int K, float alpha,
+                   float beta, float* slabs, size_t slab_floats, hipStream_t st) {
+    const int tiles = ((N + 255) / 256) * ((K + 127) / 128);
+    int ns = 1;
+    while (ns < 64 && tiles * ns < 256 && Mtok % (64 * ns * 2) == 0 && (size_t)(ns * 2) * N * K <= slab_floats) ns *= 2;
+    const long pa = PL(npl, (size_t)N * Mtok), pw = PL(npl, (size_t)K * Mtok);
+    if (ns == 1)
+        return launch_gemm16_ex(npl, dYT, Mtok, pa, XT, Mtok, pw, nullptr, nullptr, dW, nullptr, 0, K, N, K, Mtok,
+                                G16X_OUTF32 | (beta != 0.f ? G16X_ACCUM : 0), alpha, st, 1, 0, 0, 0);
+    const int kc = Mtok / ns;
+    GENIE_TRY(launch_gemm16_ex(npl, dYT, Mtok, pa, XT, Mtok, pw, nullptr, nullptr, slabs, nullptr, 0, K, N, K, kc,
+                               G16X_OUTF32, alpha, st, ns, kc, kc, (long)N * K));
+    return launch_slab_reduce(slabs, ns, (size_t)N * K, dW, beta, st);
+}
+
+static int attn_fwd16(const genie_cfg& c, const genie_attn_weights& aw, const float* qkv, bool temporal, uint16_t* out16,
+                      float* tmp, int B, int npl, hipStream_t st) {
+    const float* nw = c.qk_norm ? aw.norm_w : nullptr;
+    const float* nb = c.qk_norm ? aw.norm_b : nullptr;
+    const size_t pd = (size_t)B * c.T * c.S * c.d_model;
+    int rc;
+    if (!temporal) {
+        rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, c.d_model, c.num_heads, c.head_dim, c.attn_scale,
+                                       nw, nb, st, out16, PL(npl, pd));
+        if (rc == GENIE_E_UNSUPPORTED) {
+            GENIE_TRY(launch_attn_generic(qkv, tmp, c.S, (long)B * c.T, 1, c.S, 0, 1, c.d_model, c.num_heads, c.head_dim,
+                                          c.attn_scale, 0, nw, nb, st));
+            rc = launch_cast16(npl, tmp, out16, pd, st);
+        }
+    } else {
+        rc = launch_attn_temporal_f32_mfma(qkv, nullptr, B, c.T, c.S, c.d_model, c.num_heads, c.head_dim, c.attn_scale, nw,
+                                           nb, st, out16, PL(npl, pd));
+        if (rc == GENIE_E_UNSUPPORTED) {
+            GENIE_TRY(launch_attn_generic(qkv, tmp, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, c.d_model,
+                                          c.num_heads, c.head_dim, c.attn_scale, 1, nw, nb, st));
+            rc = launch_cast16(npl, tmp, out16, pd, st);
+        }
+    }
+    return rc;
+}
+
+static int need16(const genie_weights* wt, const genie_cfg& c, const char* what) {
+    GENIE_CHECK_ARG(wt && wt->out_w16, "%s: 16-bit weight copies missing (genie_train_pack_weights)", what);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const genie_layer_weights& lw = wt->layers_host[l];
+        GENIE_CHECK_ARG(lw.spatial.qkv_w16 && lw.spatial.proj_w16 && lw.temporal.qkv_w16 && lw.temporal.proj_w16 &&
+                            lw.fc1_w16 && lw.fc2_w16,
+                        "%s: 16-bit weight copies missing in layer %d (genie_train_pack_weights)", what, l);
+    }
+    return GENIE_OK;
+}
+
+static int train_forward16(const genie_cfg& c, const genie_weights* wt, const int64_t* input_ids, const int64_t* labels,
+                           int B, char* acts, size_t acts_bytes, double* sums, hipStream_t st) {
+    const int npl = npl_of(c);
+    GENIE_TRY(need16(wt, c, "genie_train_forward"));
+    const TrainActs16 a = train_acts16(c, B, npl);
+    GENIE_CHECK_ARG(acts_bytes >= a.total, "genie_train_forward: activation buffer too small: %zu < %zu", acts_bytes, a.total);
+    const int d = c.d_model, hid = c.hidden, M = B * c.T * c.S, V = c.factored_vocab * c.num_factored;
+    GENIE_CHECK_SHAPE(V >= d, "training step (16-bit): vocabulary rows %d < d_model %d", V, d);
+    const size_t pd = (size_t)M * d, ph = (size_t)M * hid;
+    float* tmp = (float*)(acts + a.logits);  // free until the readout
+    auto F = [&](int l, size_t off) { return (float*)(acts + a.per_layer * l + off); };
+    auto H16 = [&](int l, size_t off) { return (uint16_t*)(acts + a.per_layer * l + off); };
+    GENIE_TRY(launch_embed(c, *wt, input_ids, B, F(0, a.x0), st));
+    if (c.qk_norm) GENIE_TRY(launch_cast16(npl, F(0, a.x0), H16(0, a.u1), pd, st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const genie_layer_weights& lw = wt->layers_host[l];
+        const bool last = l + 1 == c.num_layers;
+        float* xnext = last ? (float*)(acts + a.xL) : F(l + 1, a.x0);
+        uint16_t* xnext16 = last ? (uint16_t*)(acts + a.xL16) : H16(l + 1, a.u1);
+        if (!c.qk_norm) {
+            if (npl == 1) GENIE_TRY(launch_layer_norm_bf16(F(l, a.x0), lw.norm1_w, lw.norm1_b, H16(l, a.u1), M, d, 1e-5f, st));
+            else GENIE_TRY(launch_layer_norm_split(F(l, a.x0), lw.norm1_w, lw.norm1_b, H16(l, a.u1), pd, M, d, 1e-5f, st));
+        }
+        GENIE_TRY(lin16(npl, H16(l, a.u1), pd, lw.spatial.qkv_w16, c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr,
+                        F(l, a.qkvs), nullptr, M, 3 * d, d, 1.0f, st));
+        GENIE_TRY(attn_fwd16(c, lw.spatial, F(l, a.qkvs), false, H16(l, a.aos), tmp, B, npl, st));
+        GENIE_TRY(lin16(npl, H16(l, a.aos), pd, lw.spatial.proj_w16, c.proj_bias ? lw.spatial.proj_b : nullptr, F(l, a.x0),
+                        F(l, a.x1), H16(l, a.x1h), M, d, d, 1.0f, st));
+        GENIE_TRY(lin16(npl, H16(l, a.x1h), pd, lw.temporal.qkv_w16, c.qkv_bias ? lw.temporal.qkv_b : nullptr, nullptr,
+                        F(l, a.qkvt), nullptr, M, 3 * d, d, 1.0f, st));
+        GENIE_TRY(attn_fwd16(c, lw.temporal, F(l, a.qkvt), true, H16(l, a.aot), tmp, B, npl, st));
+        GENIE_TRY(lin16(npl, H16(l, a.aot), pd, lw.temporal.proj_w16, c.proj_bias ? lw.temporal.proj_b : nullptr,
+                        F(l, a.x1), F(l, a.x2), c.qk_norm ? H16(l, a.u2) : nullptr, M, d, d, 1.0f, st));
+        if (!c.qk_norm) {
+            if (npl == 1) GENIE_TRY(launch_layer_norm_bf16(F(l, a.x2), lw.norm2_w, lw.norm2_b, H16(l, a.u2), M, d, 1e-5f, st));
+            else GENIE_TRY(launch_layer_norm_split(F(l, a.x2), lw.norm2_w, lw.norm2_b, H16(l, a.u2), pd, M, d, 1e-5f, st));
+        }
+        GENIE_TRY(lin16(npl, H16(l, a.u2), pd, lw.fc1_w16, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, F(l, a.z), nullptr, M,
+                        hid, d, 1.0f, st));
+        GENIE_TRY(launch_gelu_fwd16(npl, F(l, a.z), H16(l, a.h), ph, st));
+        GENIE_TRY(lin16(npl, H16(l, a.h), ph, lw.fc2_w16, c.mlp_bias ? lw.fc2_b : nullptr, F(l, a.x2), xnext,
+                        c.qk_norm ? xnext16 : nullptr, M, d, hid, 1.0f, st));
+    }
+    if (!c.qk_norm) GENIE_TRY(launch_cast16(npl, (float*)(acts + a.xL), (uint16_t*)(acts + a.xL16), pd, st));
+    GENIE_TRY(lin16(npl, (uint16_t*)(acts + a.xL16), pd, wt->out_w16, wt->out_b, nullptr, (float*)(acts + a.logits), nullptr,
+                    M, V, d, c.readout_mult, st));
+    if (hipMemsetAsync(sums, 0, 3 * sizeof(double), st) != hipSuccess) {
+        set_error("genie_train_forward: hipMemsetAsync failed");
+        return GENIE_E_LAUNCH;
+    }
+    return launch_ce_fwd_bwd(c, (float*)(acts + a.logits), input_ids, labels, B, sums, st);
+}
+
+static int train_backward_head16(const genie_cfg& c, const genie_weights* wt, const genie_weights* wT,
+                                 const genie_weights* grads, int B, char* acts, TrainWs& w, TrainWs16& h, float beta,
+                                 hipStream_t st) {
+    const int npl = npl_of(c);
+    GENIE_TRY(need16(wT, c, "genie_train_backward_head (transposed copies)"));
+    const TrainActs16 a = train_acts16(c, B, npl);
+    const int d = c.d_model, M = B * c.T * c.S, V = c.factored_vocab * c.num_factored;
+    float* dl = (float*)(acts + a.logits);
+    GENIE_TRY(launch_cast_transpose16(npl, dl, V, nullptr, h.dy16, h.dy16T, M, V, st));
+    GENIE_TRY(launch_transpose16(npl, (const uint16_t*)(acts + a.xL16), h.xT16, M, d, st));
+    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)grads->out_w, M, V, d, c.readout_mult, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(launch_colsum(dl, V, M, V, (float*)grads->out_b, beta, w.colpart, st));
+    return lin16(npl, h.dy16, (size_t)M * V, wT->out_w16, nullptr, nullptr, w.dx, nullptr, M, d, V, c.readout_mult, st);
+}
+
+static int train_backward_layer16(const genie_cfg& c, const genie_weights* wt, const genie_weights* wT,
+                                  const genie_weights* grads, int layer, int B, char* acts, TrainWs& w, TrainWs16& h,
+                                  float beta, hipStream_t st) {
+    const int npl = npl_of(c);
+    const TrainActs16 a = train_acts16(c, B, npl);
+    const int d = c.d_model, hid = c.hidden, M = B * c.T * c.S;
+    const size_t pd = (size_t)M * d, ph = (size_t)M * hid, p3 = (size_t)M * 3 * d;
+    const genie_layer_weights& lw = wt->layers_host[layer];
+    const genie_layer_weights& lt = wT->layers_host[layer];
+    const genie_layer_weights& g = grads->layers_host[layer];
+    char* L = acts + a.per_layer * layer;
+    auto F = [&](size_t off) { return (float*)(L + off); };
+    auto H16 = [&](size_t off) { return (const uint16_t*)(L + off); };
+    float* dx = w.dx;
+    QkSrc qk;
+
+    // ---- MLP
+    GENIE_TRY(launch_cast_transpose16(npl, dx, d, nullptr, h.dy16, h.dy16T, M, d, st));
+    GENIE_TRY(launch_transpose16(npl, H16(a.h), h.xT16, M, hid, st));
+    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.fc2_w, M, d, hid, 1.0f, beta, w.slabs, w.slab_floats, st));
+    if (c.mlp_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.fc2_b, beta, w.colpart, st));
+    GENIE_TRY(lin16(npl, h.dy16, pd, lt.fc2_w16, nullptr, nullptr, w.g, nullptr, M, hid, d, 1.0f, st));         // dh
+    GENIE_TRY(launch_cast_transpose16(npl, w.g, hid, F(a.z), h.dy16, h.dy16T, M, hid, st));                     // dz
+    GENIE_TRY(launch_transpose16(npl, H16(a.u2), h.xT16, M, d, st));
+    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.fc1_w, M, hid, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    if (c.mlp_bias) GENIE_TRY(launch_colsum(w.g, hid, M, hid, (float*)g.fc1_b, beta, w.colpart, st));
+    if (c.qk_norm) {
+        GENIE_TRY(lin16(npl, h.dy16, ph, lt.fc1_w16, nullptr, dx, dx, nullptr, M, d, hid, 1.0f, st));
+    } else {
+        GENIE_TRY(lin16(npl, h.dy16, ph, lt.fc1_w16, nullptr, nullptr, w.d1, nullptr, M, d, hid, 1.0f, st));
+        GENIE_TRY(launch_ln_bwd(F(a.x2), lw.norm2_w, w.d1, dx, (float*)g.norm2_w, (float*)g.norm2_b, M, d, 1e-5f, beta,
+                                w.lnpart, st));
+    }
+
+    // ---- temporal
+    GENIE_TRY(launch_cast_transpose16(npl, dx, d, nullptr, h.dy16, h.dy16T, M, d, st));
+    GENIE_TRY(launch_transpose16(npl, H16(a.aot), h.xT16, M, d, st));
+    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.temporal.proj_w, M, d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.temporal.proj_b, beta, w.colpart, st));
+    GENIE_TRY(lin16(npl, h.dy16, pd, lt.temporal.proj_w16, nullptr, nullptr, w.d1, nullptr, M, d, d, 1.0f, st));
+    GENIE_TRY(qk_source(c, lw.temporal, F(a.qkvt), w, B, &qk, st));
+    GENIE_TRY(launch_attn_temporal_bwd(F(a.qkvt), qk.p, qk.ld, w.d1, w.g, B, c.T, c.S, d, c.num_heads, c.head_dim,
+                                       c.attn_scale, st));
+    GENIE_TRY(qk_norm_backward(c, lw.temporal, g.temporal, F(a.qkvt), w.g, w, B, beta, st));
+    GENIE_TRY(launch_cast_transpose16(npl, w.g, 3 * d, nullptr, h.dy16, h.dy16T, M, 3 * d, st));
+    GENIE_TRY(launch_transpose16(npl, H16(a.x1h), h.xT16, M, d, st));
+    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.temporal.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.temporal.qkv_b, beta, w.colpart, st));
+    GENIE_TRY(lin16(npl, h.dy16, p3, lt.temporal.qkv_w16, nullptr, dx, dx, nullptr, M, d, 3 * d, 1.0f, st));
+
+    // ---- spatial
+    GENIE_TRY(launch_cast_transpose16(npl, dx, d, nullptr, h.dy16, h.dy16T, M, d, st));
+    GENIE_TRY(launch_transpose16(npl, H16(a.aos), h.xT16, M, d, st));
+    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.spatial.proj_w, M, d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.spatial.proj_b, beta, w.colpart, st));
+    GENIE_TRY(lin16(npl, h.dy16, pd, lt.spatial.proj_w16, nullptr, nullptr, w.d1, nullptr, M, d, d, 1.0f, st));
+    GENIE_TRY(qk_source(c, lw.spatial, F(a.qkvs), w, B, &qk, st));
+    GENIE_TRY(spatial_attn_bwd(c, F(a.qkvs), qk, w.d1, w.g, w, B, st));
+    GENIE_TRY(qk_norm_backward(c, lw.spatial, g.spatial, F(a.qkvs), w.g, w, B, beta, st));
+    GENIE_TRY(launch_cast_transpose16(npl, w.g, 3 * d, nullptr, h.dy16, h.dy16T, M, 3 * d, st));
+    GENIE_TRY(launch_transpose16(npl, H16(a.u1), h.xT16, M, d, st));
+    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.spatial.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.spatial.qkv_b, beta, w.colpart, st));
+    if (c.qk_norm) return lin16(npl, h.dy16, p3, lt.spatial.qkv_w16, nullptr, dx, dx, nullptr, M, d, 3 * d, 1.0f, st);
+    GENIE_TRY(lin16(npl, h.dy16, p3, lt.spatial.qkv_w16, nullptr, nullptr, w.d1, nullptr, M, d, 3 * d, 1.0f, st));
+    return launch_ln_bwd(F(a.x0), lw.norm1_w, w.d1, dx, (float*)g.norm1_w, (float*)g.norm1_b, M, d, 1e-5f, beta, w.lnpart, st);
+}
+
 }  // namespace genie
 
 using namespace genie;
@@ -168,11 +419,38 @@ extern "C" {
 
 size_t genie_train_activation_bytes(const genie_cfg* cfg, int B) {
     if (!cfg || B <= 0) return 0;
+    if (cfg->precision != GENIE_PREC_EXACT) return train_acts16(*cfg, B, npl_of(*cfg)).total;
     return train_acts(*cfg, B).total * sizeof(float);
 }
 size_t genie_train_workspace_bytes(const genie_cfg* cfg, int B) {
     if (!cfg || B <= 0) return 0;
-    return train_ws(*cfg, B, nullptr).total;
+    const size_t exact = train_ws(*cfg, B, nullptr).total;
+    if (cfg->precision != GENIE_PREC_EXACT) return train_ws16(*cfg, B, npl_of(*cfg), nullptr, exact).total;
+    return exact;
+}
+
+int genie_train_pack_weights(const genie_cfg* cfg, const genie_weights* w, const genie_weights* w16,
+                             const genie_weights* w16T, void* stream) {
+    GENIE_CHECK_ARG(cfg && w && w16 && w16T, "genie_train_pack_weights: NULL argument");
+    GENIE_CHECK_ARG(cfg->precision != GENIE_PREC_EXACT, "genie_train_pack_weights: exact precision has no 16-bit copies");
+    const genie_cfg& c = *cfg;
+    const int npl = npl_of(c), d = c.d_model, hid = c.hidden, V = c.factored_vocab * c.num_factored;
+    hipStream_t st = (hipStream_t)stream;
+    auto pack = [&](const float* src, const uint16_t* rowm, const uint16_t* tr, int out, int in) -> int {
+        GENIE_CHECK_ARG(src && rowm && tr, "genie_train_pack_weights: missing pointer");
+        GENIE_TRY(launch_cast16(npl, src, (uint16_t*)rowm, (size_t)out * in, st));
+        return launch_cast_transpose16(npl, (float*)src, in, nullptr, nullptr, (uint16_t*)tr, out, in, st);
+    };
+    for (int l = 0; l < c.num_layers; ++l) {
+        const genie_layer_weights &a = w->layers_host[l], &b = w16->layers_host[l], &t = w16T->layers_host[l];
+        GENIE_TRY(pack(a.spatial.qkv_w, b.spatial.qkv_w16, t.spatial.qkv_w16, 3 * d, d));
+        GENIE_TRY(pack(a.spatial.proj_w, b.spatial.proj_w16, t.spatial.proj_w16, d, d));
+        GENIE_TRY(pack(a.temporal.qkv_w, b.temporal.qkv_w16, t.temporal.qkv_w16, 3 * d, d));
+        GENIE_TRY(pack(a.temporal.proj_w, b.temporal.proj_w16, t.temporal.proj_w16, d, d));
+        GENIE_TRY(pack(a.fc1_w, b.fc1_w16, t.fc1_w16, hid, d));
+        GENIE_TRY(pack(a.fc2_w, b.fc2_w16, t.fc2_w16, d, hid));
+    }
+    return pack(w->out_w, w16->out_w16, w16T->out_w16, V, d);
 }
 
 int genie_train_forward(const genie_cfg* cfg, const genie_weights* wt, const int64_t* input_ids, const int64_t* labels,
@@ -180,6 +458,8 @@ int genie_train_forward(const genie_cfg* cfg, const genie_weights* wt, const int
     GENIE_TRY(train_check(cfg, B));
     GENIE_CHECK_ARG(wt && input_ids && labels && acts && sums, "genie_train_forward: NULL argument");
     const genie_cfg& c = *cfg;
+    if (c.precision != GENIE_PREC_EXACT)
+        return train_forward16(c, wt, input_ids, labels, B, (char*)acts, acts_bytes, sums, (hipStream_t)stream);
     const TrainActs a = train_acts(c, B);
     GENIE_CHECK_ARG(acts_bytes >= a.total * sizeof(float), "genie_train_forward: activation buffer too small: %zu < %zu",
                     acts_bytes, a.total * sizeof(float));
@@ -220,15 +500,21 @@ int genie_train_forward(const genie_cfg* cfg, const genie_weights* wt, const int
     return launch_ce_fwd_bwd(c, acts + a.o_logits, input_ids, labels, B, sums, st);
 }
 
-int genie_train_backward_head(const genie_cfg* cfg, const genie_weights* wt, const genie_weights* grads, int B,
-                              const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+int genie_train_backward_head(const genie_cfg* cfg, const genie_weights* wt, const genie_weights* wT,
+                              const genie_weights* grads, int B, float* acts, void* workspace, size_t workspace_bytes,
+                              int accumulate, void* stream) {
     GENIE_TRY(train_check(cfg, B));
     GENIE_CHECK_ARG(wt && grads && acts && workspace, "genie_train_backward_head: NULL argument");
     const genie_cfg& c = *cfg;
-    const TrainActs a = train_acts(c, B);
     TrainWs w = train_ws(c, B, workspace);
-    GENIE_CHECK_ARG(workspace_bytes >= w.total, "training workspace too small: %zu < %zu", workspace_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
+    if (c.precision != GENIE_PREC_EXACT) {
+        TrainWs16 h = train_ws16(c, B, npl_of(c), workspace, w.total);
+        GENIE_CHECK_ARG(workspace_bytes >= h.total, "training workspace too small: %zu < %zu", workspace_bytes, h.total);
+        return train_backward_head16(c, wt, wT, grads, B, (char*)acts, w, h, accumulate ? 1.0f : 0.0f, st);
+    }
+    const TrainActs a = train_acts(c, B);
+    GENIE_CHECK_ARG(workspace_bytes >= w.total, "training workspace too small: %zu < %zu", workspace_bytes, w.total);
     const int d = c.d_model, M = B * c.T * c.S, V = c.factored_vocab * c.num_factored;
     const float beta = accumulate ? 1.0f : 0.0f;
     const float* dl = acts + a.o_logits;
@@ -238,16 +524,23 @@ int genie_train_backward_head(const genie_cfg* cfg, const genie_weights* wt, con
     return dgrad(dl, wt->out_w, nullptr, w.dx, M, V, d, c.readout_mult, st);
 }
 
-int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* wt, const genie_weights* grads, int layer, int B,
-                               const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* wt, const genie_weights* wT,
+                               const genie_weights* grads, int layer, int B, float* acts, void* workspace,
+                               size_t workspace_bytes, int accumulate, void* stream) {
     GENIE_TRY(train_check(cfg, B));
     GENIE_CHECK_ARG(wt && grads && acts && workspace, "genie_train_backward_layer: NULL argument");
     GENIE_CHECK_ARG(layer >= 0 && layer < cfg->num_layers, "genie_train_backward_layer: layer %d out of range", layer);
     const genie_cfg& c = *cfg;
-    const TrainActs a = train_acts(c, B);
     TrainWs w = train_ws(c, B, workspace);
-    GENIE_CHECK_ARG(workspace_bytes >= w.total, "training workspace too small: %zu < %zu", workspace_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
+    if (c.precision != GENIE_PREC_EXACT) {
+        GENIE_TRY(need16(wT, c, "genie_train_backward_layer (transposed copies)"));
+        TrainWs16 h = train_ws16(c, B, npl_of(c), workspace, w.total);
+        GENIE_CHECK_ARG(workspace_bytes >= h.total, "training workspace too small: %zu < %zu", workspace_bytes, h.total);
+        return train_backward_layer16(c, wt, wT, grads, layer, B, (char*)acts, w, h, accumulate ? 1.0f : 0.0f, st);
+    }
+    const TrainActs a = train_acts(c, B);
+    GENIE_CHECK_ARG(workspace_bytes >= w.total, "training workspace too small: %zu < %zu", workspace_bytes, w.total);
     const int d = c.d_model, hid = c.hidden, M = B * c.T * c.S;
     const float beta = accumulate ? 1.0f : 0.0f;
     const genie_layer_weights& lw = wt->layers_host[layer];

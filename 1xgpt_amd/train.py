@@ -13,6 +13,8 @@ Design (MI355X-first):
   * multi-GPU: one process per GPU, clips sharded, gradients summed with one RCCL all-reduce per bucket of layers,
     launched as soon as that bucket's backward has been enqueued so the exchange overlaps the remaining backward;
     1/world_size and the clip coefficient are folded into the AdamW kernel (no host sync in the step);
+  * precisions: the model's (`exact` f32 MFMA; `f16x3` split-f16 MFMA with f32-class gradients; `bf16` = what
+    accelerate's bf16 autocast computes); parameters, gradients and Adam moments are f32 in all of them;
   * GPU only: there is no CPU fallback for the model math (the collator in data.py is device-agnostic data prep).
 MuAdamW (--mu_transfer, train.py:439; third-party mup fork) is not built.
 """
@@ -56,11 +58,22 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def weights_table(config, tensors):
-    """genie_weights table over state-dict-named tensors (parameters or gradients).  Returns (table, keepalive)."""
+LINEAR_WEIGHTS = ("spatial_attn.qkv", "spatial_attn.proj", "temporal_attn.qkv", "temporal_attn.proj", "mlp.fc1", "mlp.fc2")
+
+
+def linear_weight_names(config):
+    """The nn.Linear weights that have 16-bit operand copies in the bf16 / f16x3 precisions."""
+    out = [f"decoder.layers.{i}.{n}.weight" for i in range(config.num_layers) for n in LINEAR_WEIGHTS]
+    return out + ["out_x_proj.weight"]
+
+
+def weights_table(config, tensors, w16=None):
+    """genie_weights table over state-dict-named tensors (parameters or gradients); `w16` (optional) maps Linear weight
+    names to their 16-bit copies (*_w16 members).  Returns (table, keepalive)."""
     L = config.num_layers
     layers = (_lib.LayerWeights * L)()
     g = tensors.get
+    h = (w16 or {}).get
     for i in range(L):
         p = f"decoder.layers.{i}."
         lw = layers[i]
@@ -70,14 +83,17 @@ def weights_table(config, tensors):
             aw.qkv_w, aw.qkv_b = _ptr(g(p + name + "qkv.weight")), _ptr(g(p + name + "qkv.bias"))
             aw.proj_w, aw.proj_b = _ptr(g(p + name + "proj.weight")), _ptr(g(p + name + "proj.bias"))
             aw.norm_w, aw.norm_b = _ptr(g(p + name + "norm.weight")), _ptr(g(p + name + "norm.bias"))
+            aw.qkv_w16, aw.proj_w16 = _ptr(h(p + name + "qkv.weight")), _ptr(h(p + name + "proj.weight"))
         lw.fc1_w, lw.fc1_b = _ptr(g(p + "mlp.fc1.weight")), _ptr(g(p + "mlp.fc1.bias"))
         lw.fc2_w, lw.fc2_b = _ptr(g(p + "mlp.fc2.weight")), _ptr(g(p + "mlp.fc2.bias"))
+        lw.fc1_w16, lw.fc2_w16 = _ptr(h(p + "mlp.fc1.weight")), _ptr(h(p + "mlp.fc2.weight"))
     w = _lib.Weights()
     w.pos_embed = _ptr(g("pos_embed_TSC"))
     w.mask_embed = _ptr(g("token_embed.mask_token_embed"))
     for j in range(config.num_factored_vocabs):
         w.embed[j] = _ptr(g(f"token_embed.factored_embeds.{j}.weight"))
     w.out_w, w.out_b = _ptr(g("out_x_proj.weight")), _ptr(g("out_x_proj.bias"))
+    w.out_w16 = _ptr(h("out_x_proj.weight"))
     w.layers_host = layers
     return w, layers
 
@@ -152,10 +168,9 @@ class GenieTrainer:
                  gradient_accumulation_steps=1, lr_lambda=None, bucket_mb=64, group=None):
         self.model, self.config = model, model.config
         dev = model._device()  # raises on CPU: no fallback
-        if model.precision != "exact":
-            raise NotImplementedError("GenieTrainer: only precision='exact' is built")
         self.lib = _lib.load()
-        self.cfg = _lib.make_cfg(self.config, _lib.PREC_EXACT)
+        self.precision = model.precision
+        self.cfg = _lib.make_cfg(self.config, model._prec)
         self.base_lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.accum = gradient_accumulation_steps
@@ -183,8 +198,18 @@ class GenieTrainer:
         model.refresh_weights()
         self.p_views = {n: self.params[offs[n][0]:offs[n][1]] for n in self.order}
         self.g_views = {n: self.grads[offs[n][0]:offs[n][1]].view(named[n].shape) for n in self.order}
-        self.w_table, self._wk = weights_table(self.config, {n: named[n].data for n in self.order})
+        # 16-bit operand copies of the Linear weights, both orientations (bf16: 1 plane, f16x3: [hi | lo])
+        self.w16 = self.w16T = None
+        self.wT_table = None
+        if self.precision != "exact":
+            npl = 1 if self.precision == "bf16" else 2
+            lin = linear_weight_names(self.config)
+            self.w16 = {n: torch.empty((npl,) + tuple(named[n].shape), dtype=torch.int16, device=dev) for n in lin}
+            self.w16T = {n: torch.empty((npl,) + tuple(named[n].shape)[::-1], dtype=torch.int16, device=dev) for n in lin}
+            self.wT_table, self._wTk = weights_table(self.config, {}, self.w16T)
+        self.w_table, self._wk = weights_table(self.config, {n: named[n].data for n in self.order}, self.w16)
         self.g_table, self._gk = weights_table(self.config, self.g_views)
+        self.pack_weights()
         # AdamW ranges: maximal runs of consecutive tensors with the same decay flag (padding between tensors is zero
         # and stays zero: zero gradient, zero moments)
         runs = []
@@ -212,6 +237,12 @@ class GenieTrainer:
         self.scratch = torch.zeros(1024, dtype=torch.float64, device=dev)
         self._acts = self._ws = None
         self._B = 0
+
+    def pack_weights(self):
+        """Refresh the 16-bit weight copies from the f32 parameters (no-op in the exact precision)."""
+        if self.precision != "exact":
+            _lib.check(self.lib.genie_train_pack_weights(self.cfg, self.w_table, self.w_table, self.wT_table,
+                                                         self._stream()), "genie_train_pack_weights")
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, B):
@@ -247,14 +278,14 @@ class GenieTrainer:
                                            acts.numel(), self.sums.data_ptr(), st), "genie_train_forward")
         sums = self.sums.clone()
         self.reducer.reset()
-        _lib.check(lib.genie_train_backward_head(cfg, self.w_table, self.g_table, B, acts.data_ptr(), ws.data_ptr(),
-                                                 ws.numel(), acc_flag, st), "genie_train_backward_head")
+        _lib.check(lib.genie_train_backward_head(cfg, self.w_table, self.wT_table, self.g_table, B, acts.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), acc_flag, st), "genie_train_backward_head")
         if reduce:
             self.reducer.ready(self.segments[0][1])
         L = self.config.num_layers
         for k, layer in enumerate(reversed(range(L))):
-            _lib.check(lib.genie_train_backward_layer(cfg, self.w_table, self.g_table, layer, B, acts.data_ptr(),
-                                                      ws.data_ptr(), ws.numel(), acc_flag, st),
+            _lib.check(lib.genie_train_backward_layer(cfg, self.w_table, self.wT_table, self.g_table, layer, B,
+                                                      acts.data_ptr(), ws.data_ptr(), ws.numel(), acc_flag, st),
                        "genie_train_backward_layer")
             if reduce:
                 self.reducer.ready(self.segments[1 + k][1])
@@ -290,7 +321,8 @@ class GenieTrainer:
                 self.weight_decay if dk else 0.0, step, mult, ss.data_ptr() if clip > 0 else None, clip, st),
                 "genie_adamw_step")
         self.completed_steps += 1
-        self.model.refresh_weights()  # 16-bit copies of the inference precisions (if any) are stale
+        self.pack_weights()
+        self.model.refresh_weights()  # the module's own 16-bit copies (inference entry points) are stale
         return torch.sqrt(ss[0]) * mult, lr
 
     def train_step(self, batch):

@@ -293,8 +293,13 @@ int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_
 int genie_rescale_u8_nhwc_bf16(const uint16_t* x, uint8_t* out, int n, int HW, int cpad, int cout, void* stream);
 
 /* ---- training step (train.py:600-633) -------------------------------------------
- * GENIE_PREC_EXACT in this ABI version (other precisions return GENIE_E_UNSUPPORTED); both the LayerNorm
- * (qk_norm = false, the shipped config) and the qk-norm block variants.  Gradients travel in a second genie_weights table whose pointers address the caller's
+ * All three precisions; both the LayerNorm (qk_norm = false, the shipped config) and the qk-norm block variants.
+ * GENIE_PREC_EXACT: every contraction on the f32 matrix instruction.  GENIE_PREC_F16X3 / GENIE_PREC_BF16: every
+ * Linear product (forward, input gradient, weight gradient) on the 16-bit matrix cores with f32 accumulation --
+ * f16x3 keeps f32-class gradients (split operands), bf16 is what `accelerate --mixed_precision bf16` computes --
+ * while LayerNorm, both attention cores, GELU, the residual stream, the loss and every gradient reduction stay f32.
+ * The 16-bit precisions need 16-bit copies of the Linear weights in both orientations (genie_train_pack_weights,
+ * again after every optimizer step); parameters, gradients and optimizer state are always f32.  Gradients travel in a second genie_weights table whose pointers address the caller's
  * gradient buffers (same shapes as the parameters; the *_w16 members are ignored).  `accumulate` = 0 overwrites the
  * gradients (optimizer.zero_grad() + backward), 1 adds to them (gradient accumulation, train.py:607-617).
  * Every reduction feeding a gradient has a fixed order: results are bit-reproducible run to run. */
@@ -312,14 +317,23 @@ size_t genie_train_workspace_bytes(const genie_cfg* cfg, int B);
 int genie_train_forward(const genie_cfg* cfg, const genie_weights* w, const int64_t* input_ids, const int64_t* labels,
                         int B, float* acts, size_t acts_bytes, double* sums_out, void* stream);
 
+/* 16-bit precisions only: refresh the 16-bit copies of every Linear weight from the f32 parameters in `w`:
+ * row-major (out, in) into the *_w16 members of `w16` (read by the forward) and transposed (in, out) into the *_w16
+ * members of `w16T` (read by the input-gradient products; pass it as `wT` below, NULL for GENIE_PREC_EXACT).
+ * bf16: one plane; f16x3: [hi | lo] planes as genie_pack_split_f16. */
+int genie_train_pack_weights(const genie_cfg* cfg, const genie_weights* w, const genie_weights* w16,
+                             const genie_weights* w16T, void* stream);
+
 /* loss.backward() (train.py:617), split so that the caller can all-reduce finished gradients while earlier layers
  * are still running: head (readout weight/bias, d loss / d x_L into the workspace), then layers L-1 .. 0 (each
  * consumes and replaces the running d loss / d x in the workspace), then the embedding tables, mask embedding and
  * pos_embed.  Must be called in exactly that order on one stream after genie_train_forward. */
-int genie_train_backward_head(const genie_cfg* cfg, const genie_weights* w, const genie_weights* grads, int B,
-                              const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream);
-int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* w, const genie_weights* grads, int layer, int B,
-                               const float* acts, void* workspace, size_t workspace_bytes, int accumulate, void* stream);
+int genie_train_backward_head(const genie_cfg* cfg, const genie_weights* w, const genie_weights* wT,
+                              const genie_weights* grads, int B, float* acts, void* workspace, size_t workspace_bytes,
+                              int accumulate, void* stream);
+int genie_train_backward_layer(const genie_cfg* cfg, const genie_weights* w, const genie_weights* wT,
+                               const genie_weights* grads, int layer, int B, float* acts, void* workspace,
+                               size_t workspace_bytes, int accumulate, void* stream);
 int genie_train_backward_embed(const genie_cfg* cfg, const genie_weights* grads, const int64_t* input_ids, int B,
                                void* workspace, size_t workspace_bytes, int accumulate, void* stream);
 

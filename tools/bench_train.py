@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--breakdown", action="store_true")
+    ap.add_argument("--precision", default="exact", choices=["exact", "f16x3", "bf16"])
     a = ap.parse_args()
     cfgm, syn, _lib = pkg("config"), pkg("synthetic"), pkg("_lib")
     cfg = cfgm.c138() if a.config == "c138" else cfgm.c35()
@@ -28,7 +29,7 @@ def main():
     if a.layers:
         cfg.num_layers = a.layers
     sd = syn.make_state_dict(cfg, seed=0, law="init")
-    model = pkg("st_mask_git").STMaskGIT(cfg, precision="exact").load_numpy_state_dict(sd).to("cuda")
+    model = pkg("st_mask_git").STMaskGIT(cfg, precision=a.precision).load_numpy_state_dict(sd).to("cuda")
     tr = pkg("train").GenieTrainer(model, lr=1e-4, max_grad_norm=1.0)
     ids = torch.from_numpy(syn.make_clips(a.batch, cfg, seed=1)).cuda()
     collate = pkg("data").maskgit_collate
