@@ -524,11 +524,159 @@ __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float* __re
             *reinterpret_cast<float4*>(o + 2 * d + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
     }
 }
+// ------------------------------------------------------------------------------------------------
+// The same backward for the production geometry (T = 16 frames, head_dim 32 / 64) on v_mfma_f32_16x16x4_f32: one
+// WAVE per (b, s, head), no LDS.  The 16x16 MFMA D tile puts D[4g+e][r] in lane (r = lane&15, g = lane>>4), so a
+// 16x16 score matrix is available in two register layouts, chosen by operand order:
+//     T-layout  mfma(k, q)  -> lane (r,g) holds X[i = r][j = 4g+e]   (row i across the 4 lane groups; the forward's)
+//     N-layout  mfma(q, k)  -> lane (r,g) holds X[i = 4g+e][j = r]
+// and a tile held in T-layout is directly the A operand (row r, contraction index 4g+e) of a product contracted over
+// j, one held in N-layout of a product contracted over i.  So:  P, dP, dS are computed in BOTH layouts (4 x DH/4
+// MFMAs); dQ = scale dS K uses the T copy, dK = scale dS^T Q and dV = P^T dO the N copy; row statistics (max, 1/sum,
+// D_i = sum_j P dP) are reduced once in the T layout and fetched by lane index for the N layout.
+// Feature permutation of the forward kernel: MFMA output column r of chunk c is feature NV*r + c (NV = DH/16), so
+// every global access is NV contiguous floats per lane.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_temporal_bwd_mfma_kernel(const float* __restrict__ qkv,
+                                                                     const float* __restrict__ qk, long qk_ld,
+                                                                     const float* __restrict__ dO,
+                                                                     float* __restrict__ dqkv, long n_bs, int S, int d,
+                                                                     int H, float scale) {
+    constexpr int T = 16, PER = DH / 4, NV = DH / 16;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long bs = wave / H;
+    const int head = (int)(wave - bs * H);
+    if (bs >= n_bs) return;
+    const long b = bs / S, s = bs - b * S;
+    const size_t row0 = (size_t)(b * T) * S + s;  // token row of frame 0; frame t is row0 + t*S
+    const float* qb = qk + row0 * qk_ld + head * DH;          // q at column 0, k at column d
+    const float* vb = qkv + row0 * 3 * d + 2 * d + head * DH;
+    const float* ob = dO + row0 * d + head * DH;
+    const long qs = (long)S * qk_ld, vs = (long)S * 3 * d, os = (long)S * d;
+    // ---- row operands: lane (r,g) holds features g*PER .. of row r
+    float q[PER], k[PER], v[PER], go[PER];
+#pragma unroll
+    for (int c = 0; c < PER; c += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(qb + (size_t)r * qs + g * PER + c);
+        const float4 bb = *reinterpret_cast<const float4*>(qb + (size_t)r * qs + d + g * PER + c);
+        const float4 cc = *reinterpret_cast<const float4*>(vb + (size_t)r * vs + g * PER + c);
+        const float4 dd = *reinterpret_cast<const float4*>(ob + (size_t)r * os + g * PER + c);
+        q[c] = a.x * scale; q[c + 1] = a.y * scale; q[c + 2] = a.z * scale; q[c + 3] = a.w * scale;
+        k[c] = bb.x; k[c + 1] = bb.y; k[c + 2] = bb.z; k[c + 3] = bb.w;
+        v[c] = cc.x; v[c + 1] = cc.y; v[c + 2] = cc.z; v[c + 3] = cc.w;
+        go[c] = dd.x; go[c + 1] = dd.y; go[c + 2] = dd.z; go[c + 3] = dd.w;
+    }
+    f32x4 sT = {0.f, 0.f, 0.f, 0.f}, pT = {0.f, 0.f, 0.f, 0.f}, sN = {0.f, 0.f, 0.f, 0.f}, pN = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+        sT = __builtin_amdgcn_mfma_f32_16x16x4f32(k[c], q[c], sT, 0, 0, 0);   // S[i=r][j=4g+e]
+        pT = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c], go[c], pT, 0, 0, 0);  // dP[i=r][j=4g+e]
+        sN = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c], k[c], sN, 0, 0, 0);   // S[i=4g+e][j=r]
+        pN = __builtin_amdgcn_mfma_f32_16x16x4f32(go[c], v[c], pN, 0, 0, 0);  // dP[i=4g+e][j=r]
+    }
+    // ---- softmax statistics of row i = r in the T layout (causal: j <= i)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (4 * g + e > r) sT[e] = -INFINITY;
+        mx = fmaxf(mx, sT[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sT[e] = expf(sT[e] - mx); sum += sT[e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    float dsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sT[e] *= inv; dsum += sT[e] * pT[e]; }
+    dsum += __shfl_xor(dsum, 16);
+    dsum += __shfl_xor(dsum, 32);
+    f32x4 dsT, dsN, prN;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dsT[e] = sT[e] * (pT[e] - dsum);  // masked entries: P = 0
+    // ---- the same in the N layout: statistics of row 4g+e come from lane 4g+e (any group holds them)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e;
+        const float mi = __shfl(mx, i), ii = __shfl(inv, i), di = __shfl(dsum, i);
+        const float p = r <= i ? expf(sN[e] - mi) * ii : 0.f;
+        prN[e] = p;
+        dsN[e] = p * (pN[e] - di);
+    }
+    // ---- dQ = scale dS K,  dK = scale dS^T Q,  dV = P^T dO: B operands are rows 4g+e, features NV*r .. NV*r+NV-1
+    float kk[4][NV], qq[4][NV], dd[4][NV];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t t = (size_t)(4 * g + e);
+        if constexpr (NV == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(qb + t * qs + d + NV * r);
+            const float4 bb = *reinterpret_cast<const float4*>(qb + t * qs + NV * r);
+            const float4 cc = *reinterpret_cast<const float4*>(ob + t * os + NV * r);
+            kk[e][0] = a.x; kk[e][1] = a.y; kk[e][2] = a.z; kk[e][3] = a.w;
+            qq[e][0] = bb.x; qq[e][1] = bb.y; qq[e][2] = bb.z; qq[e][3] = bb.w;
+            dd[e][0] = cc.x; dd[e][1] = cc.y; dd[e][2] = cc.z; dd[e][3] = cc.w;
+        } else {
+            const float2 a = *reinterpret_cast<const float2*>(qb + t * qs + d + NV * r);
+            const float2 bb = *reinterpret_cast<const float2*>(qb + t * qs + NV * r);
+            const float2 cc = *reinterpret_cast<const float2*>(ob + t * os + NV * r);
+            kk[e][0] = a.x; kk[e][1] = a.y;
+            qq[e][0] = bb.x; qq[e][1] = bb.y;
+            dd[e][0] = cc.x; dd[e][1] = cc.y;
+        }
+    }
+    f32x4 dq[NV], dk[NV], dv[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsT[e], kk[e][c], dq[c], 0, 0, 0);
+            dk[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsN[e], qq[e][c], dk[c], 0, 0, 0);
+            dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(prN[e], dd[e][c], dv[c], 0, 0, 0);
+        }
+    }
+    // D map: lane (r,g) holds rows 4g+e, features NV*r + c
+    float* outb = dqkv + row0 * 3 * d + head * DH + NV * r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float* o = outb + (size_t)(4 * g + e) * vs;
+        if constexpr (NV == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(dq[0][e] * scale, dq[1][e] * scale, dq[2][e] * scale, dq[3][e] * scale);
+            *reinterpret_cast<float4*>(o + d) = make_float4(dk[0][e] * scale, dk[1][e] * scale, dk[2][e] * scale, dk[3][e] * scale);
+            *reinterpret_cast<float4*>(o + 2 * d) = make_float4(dv[0][e], dv[1][e], dv[2][e], dv[3][e]);
+        } else {
+            *reinterpret_cast<float2*>(o) = make_float2(dq[0][e] * scale, dq[1][e] * scale);
+            *reinterpret_cast<float2*>(o + d) = make_float2(dk[0][e] * scale, dk[1][e] * scale);
+            *reinterpret_cast<float2*>(o + 2 * d) = make_float2(dv[0][e], dv[1][e]);
+        }
+    }
+}
+
 int launch_attn_temporal_bwd(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, int B, int T,
                              int S, int d, int H, int Dh, float scale, hipStream_t st) {
     GENIE_CHECK_SHAPE(T <= 16, "temporal attention backward: T=%d > 16", T);
     const long n_grp = (long)B * S * H;
     if (n_grp <= 0) return GENIE_OK;
+    if (T == 16 && (Dh == 64 || Dh == 32)) {
+        ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 10.0 * n_grp * T * T * Dh, 4.0 * n_grp * T * Dh * 7, st);
+        const unsigned wblocks = (unsigned)((n_grp + 3) / 4);
+        if (Dh == 64)
+            attn_temporal_bwd_mfma_kernel<64><<<wblocks, 256, 0, st>>>(qkv, qk, qk_ld, dO, dqkv, (long)B * S, S, d, H, scale);
+        else
+            attn_temporal_bwd_mfma_kernel<32><<<wblocks, 256, 0, st>>>(qkv, qk, qk_ld, dO, dqkv, (long)B * S, S, d, H, scale);
+        GENIE_LAUNCH_CHECK("attn_temporal_bwd_mfma");
+        return GENIE_OK;
+    }
     const unsigned blocks = (unsigned)((n_grp + 3) / 4);
     ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 10.0 * n_grp * T * T * Dh, 4.0 * n_grp * T * Dh * 7, st);
 #define TB_LAUNCH(DH_)                                                                                       \

@@ -121,10 +121,12 @@ def test_real_geometry_vs_reference_samples(golden, precision):
         assert np.abs(samp - z[f"s0_gradsample/{k}"]).max() <= tol * np.abs(g).max() + 1e-12, k
 
 
-@pytest.mark.parametrize("H,d,B,qk_norm", [(4, 128, 3, False), (2, 64, 1, False), (2, 128, 2, True), (4, 128, 1, True)])
-def test_gradients_vs_oracle(H, d, B, qk_norm):
-    """Other widths / head sizes (Dh = 32, 64) and an odd batch against the NumPy restatement."""
-    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=H, d_model=d, T=4, S=16, num_factored_vocabs=2,
+@pytest.mark.parametrize("H,d,B,qk_norm,T", [(4, 128, 3, False, 4), (2, 64, 1, False, 4), (2, 128, 2, True, 4),
+                                              (4, 128, 1, True, 4), (4, 128, 2, False, 16), (2, 128, 1, True, 16)])
+def test_gradients_vs_oracle(H, d, B, qk_norm, T):
+    """Other widths / head sizes (Dh = 32, 64), an odd batch, and T = 16 (the MFMA temporal kernels, forward and
+    backward, with and without qk-norm) against the NumPy restatement."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=H, d_model=d, T=T, S=16, num_factored_vocabs=2,
                                     qk_norm=qk_norm, num_prompt_frames=2)
     syn = pkg("synthetic")
     sd = syn.make_state_dict(cfg, seed=77 + H, law="conditioned")
