@@ -120,6 +120,8 @@ int launch_softmax_bwd_rows(const float* P, float* dP, long rows, int N, hipStre
 // q, k rows are read from `qk` (leading dim qk_ld; q at column 0, k at column d), v from qkv
 int launch_attn_temporal_bwd(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, int B, int T,
                              int S, int d, int H, int Dh, float scale, hipStream_t st);
+int launch_attn_spatial_bwd_fused(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, long n_bt, int S,
+                                  int d, int H, int Dh, float scale, hipStream_t st);
 int launch_qk_norm_fwd(const float* qkv, float* qkn, const float* nw, const float* nb, long M, int H, int Dh, int d,
                        hipStream_t st);
 int launch_qk_norm_bwd(const float* qkv, float* dqkv, const float* nw, float* dnw, float* dnb, long M, int H, int Dh,

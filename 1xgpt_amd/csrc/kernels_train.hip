@@ -699,6 +699,240 @@ int launch_attn_temporal_bwd(const float* qkv, const float* qk, long qk_ld, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Spatial attention backward, fused (S = 256 tokens of one frame, head_dim 32 / 64, non-causal): one workgroup of 4
+// waves per (b, t, head); K and V of the head stay in LDS (2 x 68 KB at head_dim 64, rows padded to DH+4 floats so
+// the k-permuted ds_read_b128 fragments are conflict-free), queries are streamed in blocks of 32 rows.  Wave w owns
+// keys [64w, 64w+64).  Per query block, on v_mfma_f32_32x32x2_f32:
+//   S = scale Q K^T and dP = dO V^T in BOTH register layouts (the same operand fragments, swapped): T-layout = one
+//     query row per lane (softmax statistics: in-lane + one cross-half shuffle + a 3-value exchange between the 4 waves,
+//     combined like an online softmax), N-layout = one key column per lane;
+//   dS = P (dP - D), D_i = sum_j P dP;   dQ_i += dS K (A = dS in T-layout, partial over the wave's 64 keys, reduced over
+//     the 4 waves through LDS in a FIXED order);   dK += dS^T Q_i and dV += P^T dO_i (A = N-layout tiles), accumulated in
+//     registers over the 8 query blocks and written once.
+// Nothing of size S x S ever touches HBM: 7 d floats per token in, 3 d out.  ~450 VGPRs at one wave per SIMD.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rowmap32(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const float* __restrict__ qkv,
+                                                                        const float* __restrict__ qk, long qk_ld,
+                                                                        const float* __restrict__ dO,
+                                                                        float* __restrict__ dqkv, int d, int H,
+                                                                        float scale) {
+    constexpr int S = 256, LD = DH + 4, IB = 32, NF = DH / 32, NKK = DH / 8, NPF = IB * DH / 4 / 256;
+    static_assert(NPF >= 1, "head_dim >= 32");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sK = sm;
+    float* sV = sK + S * LD;
+    float* sQ = sV + S * LD;
+    float* sdO = sQ + IB * LD;
+    float* sPM = sdO + IB * LD;  // per-wave partial statistics [4][32]
+    float* sPL = sPM + 128;
+    float* sPD = sPL + 128;
+    float* fM = sPD + 128;       // final row max / 1/sum / D  [32]
+    float* fI = fM + 32;
+    float* fD = fI + 32;
+    float* red = sQ;             // dQ reduction buffer [4][16][DH], aliases sQ | sdO
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const long bt = blockIdx.x / H;
+    const int head = (int)(blockIdx.x - bt * H);
+    const size_t row0 = (size_t)bt * S;
+    const float* qb = qk + row0 * qk_ld + head * DH;
+    const float* kb = qb + d;
+    const float* vb = qkv + row0 * 3 * d + 2 * d + head * DH;
+    const float* ob = dO + row0 * d + head * DH;
+    float* outb = dqkv + row0 * 3 * d + head * DH;
+
+    for (int idx = tid; idx < S * DH / 4; idx += 256) {
+        const int row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+        *reinterpret_cast<float4*>(&sK[row * LD + c4]) = *reinterpret_cast<const float4*>(kb + (size_t)row * qk_ld + c4);
+        *reinterpret_cast<float4*>(&sV[row * LD + c4]) = *reinterpret_cast<const float4*>(vb + (size_t)row * 3 * d + c4);
+    }
+    float4 pq[NPF], pd[NPF];
+    auto fetch = [&](int ib) {
+#pragma unroll
+        for (int p = 0; p < NPF; ++p) {
+            const int idx = tid + 256 * p, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+            pq[p] = *reinterpret_cast<const float4*>(qb + (size_t)(ib * IB + row) * qk_ld + c4);
+            pd[p] = *reinterpret_cast<const float4*>(ob + (size_t)(ib * IB + row) * d + c4);
+        }
+    };
+    fetch(0);
+    f32x16 dk[2][NF], dv[2][NF];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dk[jt][ft][e] = 0.f; dv[jt][ft][e] = 0.f; }
+
+    for (int ib = 0; ib < S / IB; ++ib) {
+#pragma unroll
+        for (int p = 0; p < NPF; ++p) {
+            const int idx = tid + 256 * p, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+            *reinterpret_cast<float4*>(&sQ[row * LD + c4]) = pq[p];
+            *reinterpret_cast<float4*>(&sdO[row * LD + c4]) = pd[p];
+        }
+        __syncthreads();  // (A) Q_i, dO_i (and K, V on the first pass) are in LDS
+        if (ib + 1 < S / IB) fetch(ib + 1);
+
+        f32x16 sT[2], sN[2], pT[2], pN[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sT[jt][e] = 0.f; sN[jt][e] = 0.f; pT[jt][e] = 0.f; pN[jt][e] = 0.f; }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int jrow = w * 64 + jt * 32 + c;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const float4 kf = *reinterpret_cast<const float4*>(&sK[jrow * LD + kk * 8 + 4 * h]);
+                const float4 vf = *reinterpret_cast<const float4*>(&sV[jrow * LD + kk * 8 + 4 * h]);
+                const float4 qf = *reinterpret_cast<const float4*>(&sQ[c * LD + kk * 8 + 4 * h]);
+                const float4 of = *reinterpret_cast<const float4*>(&sdO[c * LD + kk * 8 + 4 * h]);
+#define SP_STEP(X)                                                                        \
+    sT[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.X, qf.X, sT[jt], 0, 0, 0);           \
+    sN[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.X, kf.X, sN[jt], 0, 0, 0);           \
+    pT[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.X, of.X, pT[jt], 0, 0, 0);           \
+    pN[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of.X, vf.X, pN[jt], 0, 0, 0);
+                SP_STEP(x) SP_STEP(y) SP_STEP(z) SP_STEP(w)
+#undef SP_STEP
+            }
+        }
+        // ---- T layout: lane (c, h) holds S[i = c][j = 64w + 32jt + rowmap(e, h)]: statistics of row c over this wave's keys
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sT[jt][e] *= scale; m = fmaxf(m, sT[jt][e]); }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f, ds = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = expf(sT[jt][e] - m);
+                sT[jt][e] = p;
+                l += p;
+                ds += p * pT[jt][e];
+            }
+        l += __shfl_xor(l, 32);
+        ds += __shfl_xor(ds, 32);
+        if (h == 0) { sPM[w * 32 + c] = m; sPL[w * 32 + c] = l; sPD[w * 32 + c] = ds; }
+        __syncthreads();  // (B)
+        float gm = sPM[c];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) gm = fmaxf(gm, sPM[ww * 32 + c]);
+        float gl = 0.f, gd = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float f = expf(sPM[ww * 32 + c] - gm);
+            gl += sPL[ww * 32 + c] * f;
+            gd += sPD[ww * 32 + c] * f;
+        }
+        const float inv = 1.0f / gl, Di = gd * inv;
+        if (w == 0 && h == 0) { fM[c] = gm; fI[c] = inv; fD[c] = Di; }
+        const float corr = expf(m - gm) * inv;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = sT[jt][e] * corr;
+                sT[jt][e] = p * (pT[jt][e] - Di);  // dS, T layout
+            }
+        __syncthreads();  // (C) final statistics published
+        // ---- N layout: lane (c, h) holds X[i = rowmap(e, h)][j = 64w + 32jt + c]
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = rowmap32(e, h);
+            const float mi = fM[i], ii = fI[i], di = fD[i];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const float p = expf(sN[jt][e] * scale - mi) * ii;
+                sN[jt][e] = p;                        // P, N layout
+                pN[jt][e] = p * (pN[jt][e] - di);     // dS, N layout
+            }
+        }
+        // ---- dQ (partial over this wave's keys), dK, dV
+        f32x16 dq[NF];
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dq[ft][e] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = rowmap32(e, h);
+                const float* kr = &sK[(w * 64 + jt * 32 + rr) * LD + c];
+                const float* qr = &sQ[rr * LD + c];
+                const float* orow = &sdO[rr * LD + c];
+#pragma unroll
+                for (int ft = 0; ft < NF; ++ft) {
+                    dq[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(sT[jt][e], kr[32 * ft], dq[ft], 0, 0, 0);
+                    dk[jt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(pN[jt][e], qr[32 * ft], dk[jt][ft], 0, 0, 0);
+                    dv[jt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(sN[jt][e], orow[32 * ft], dv[jt][ft], 0, 0, 0);
+                }
+            }
+        __syncthreads();  // (D) every wave is done with sQ / sdO and the statistics
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = 8 * round + e8;
+                    red[(w * 16 + rowmap32(e, h) - 16 * round) * DH + 32 * ft + c] = dq[ft][e];
+                }
+            __syncthreads();
+            if (tid < 16 * DH / 4) {
+                const int row = tid / (DH / 4), f4 = (tid % (DH / 4)) * 4;
+                float4 a = *reinterpret_cast<const float4*>(&red[row * DH + f4]);
+#pragma unroll
+                for (int ww = 1; ww < 4; ++ww) {
+                    const float4 b = *reinterpret_cast<const float4*>(&red[(ww * 16 + row) * DH + f4]);
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
+                a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+                *reinterpret_cast<float4*>(outb + (size_t)(ib * IB + 16 * round + row) * 3 * d + f4) = a;
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float* o = outb + (size_t)(w * 64 + jt * 32 + rowmap32(e, h)) * 3 * d + 32 * ft + c;
+                o[d] = dk[jt][ft][e] * scale;
+                o[2 * d] = dv[jt][ft][e];
+            }
+}
+
+// GENIE_E_UNSUPPORTED for other geometries (the caller then takes the materialised-scores path)
+int launch_attn_spatial_bwd_fused(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, long n_bt, int S,
+                                  int d, int H, int Dh, float scale, hipStream_t st) {
+    if (S != 256 || (Dh != 64 && Dh != 32)) return GENIE_E_UNSUPPORTED;
+    if (n_bt <= 0) return GENIE_OK;
+    const size_t lds = (size_t)((2 * 256 + 2 * 32) * (Dh + 4) + 15 * 32) * sizeof(float);
+    ProfScope prof(GENIE_KC_ATTN_SPATIAL, 14.0 * S * S * Dh * (double)n_bt * H, 4.0 * 10 * S * Dh * (double)n_bt * H, st);
+    if (Dh == 64) {
+        (void)hipFuncSetAttribute((const void*)attn_spatial_bwd_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attn_spatial_bwd_fused_kernel<64><<<(unsigned)(n_bt * H), 256, lds, st>>>(qkv, qk, qk_ld, dO, dqkv, d, H, scale);
+    } else {
+        (void)hipFuncSetAttribute((const void*)attn_spatial_bwd_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attn_spatial_bwd_fused_kernel<32><<<(unsigned)(n_bt * H), 256, lds, st>>>(qkv, qk, qk_ld, dO, dqkv, d, H, scale);
+    }
+    GENIE_LAUNCH_CHECK("attn_spatial_bwd_fused");
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // qk-norm (attention.py:42-47): LayerNorm over head_dim of every q and k head row, ONE affine shared by q, k and all
 // heads.  Forward writes the normalised operands qkn (M, 2d) = [LN(q) | LN(k)] for the score GEMMs of the backward;
 // backward turns d/d(normalised) into d/d(raw) in place on the q,k columns of dqkv and emits the affine's gradient

@@ -141,6 +141,10 @@ static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, QkSrc qk, cons
     const long q3 = (long)S * 3 * d, ss = (long)S * S, hss = (long)H * ss, sd = (long)S * d;
     const long qld = qk.ld, qs = (long)S * qk.ld;
     const float sc = c.attn_scale;
+    {   // production geometry: fused kernel, no S x S traffic
+        const int rc = launch_attn_spatial_bwd_fused(qkv, qk.p, qk.ld, dao, dqkv, BT, S, d, H, Dh, sc, st);
+        if (rc != GENIE_E_UNSUPPORTED) return rc;
+    }
     // P = softmax(scale Q K^T)
     GENIE_TRY(launch_gemm_f32_gen(false, false, qk.p, qld, qs, Dh, qk.p + d, qld, qs, Dh, nullptr, nullptr, w.p, S, hss,
                                   ss, S, S, Dh, BT, H, 1, 0, sc, st));

@@ -141,6 +141,23 @@ def test_gradients_vs_oracle(H, d, B, qk_norm, T):
         assert rel_err(g.cpu().numpy(), g_o[k]) < GRAD_TOL, k
 
 
+@pytest.mark.parametrize("H,d,qk_norm", [(2, 64, False), (1, 64, True)])
+def test_fused_spatial_backward_vs_oracle(H, d, qk_norm):
+    """S = 256 tokens per frame: the fused spatial attention backward (head_dim 32 and 64, with and without qk-norm)."""
+    cfg = pkg("config").GenieConfig(num_layers=1, num_heads=H, d_model=d, T=2, S=256, num_factored_vocabs=2,
+                                    qk_norm=qk_norm, num_prompt_frames=1)
+    syn = pkg("synthetic")
+    sd = syn.make_state_dict(cfg, seed=5 + H, law="conditioned")
+    ids = syn.make_clips(2, cfg, seed=31)
+    batch = TO.maskgit_collate(ids, cfg, TO.NumpyDraws(3))
+    loss_o, _, g_o = TO.forward_backward(batch["input_ids"], batch["labels"], sd, cfg)
+    tr = make_trainer(cfg, sd)
+    loss, _ = tr.forward_backward(dev(batch["input_ids"]), dev(batch["labels"]))
+    assert abs(float(loss) - loss_o) < 1e-5 * abs(loss_o)
+    for k, g in tr.gradients().items():
+        assert rel_err(g.cpu().numpy(), g_o[k]) < GRAD_TOL, k
+
+
 @pytest.mark.parametrize("precision", ["exact", "f16x3", "bf16"])
 def test_bit_reproducible_and_accumulation(golden, precision):
     z, cfg, sd = golden("train_tiny_ln")
