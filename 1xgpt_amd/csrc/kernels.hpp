@@ -129,7 +129,7 @@ int launch_qk_norm_bwd(const float* qkv, float* dqkv, const float* nw, float* dn
 int launch_ce_fwd_bwd(const genie_cfg& c, float* logits, const int64_t* ids, const int64_t* labels, int B, double* sums,
                       hipStream_t st);
 int launch_embed_bwd(const genie_cfg& c, const float* dx, const int64_t* ids, int B, float* dpos, float* dmask,
-                     float* const* tables_host, float beta, hipStream_t st);
+                     float* const* tables_host, float beta, float* colpart, hipStream_t st);
 int launch_sumsq(const float* x, size_t n, double* out, double* scratch, hipStream_t st);
 // 16-bit operand copies (kernels_train16.hip); npl = 1 bf16, 2 = f16 split planes [hi | lo]
 int launch_cast_transpose16(int npl, float* in, long ld, const float* z, uint16_t* out16, uint16_t* out16T, int rows,

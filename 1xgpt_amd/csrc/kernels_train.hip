@@ -229,7 +229,26 @@ __global__ void colsum_partial_kernel(const float* __restrict__ Y, long ld, long
     for (long r = r0; r < r1; ++r) s += Y[(size_t)r * ld + c];
     part[(size_t)blockIdx.y * N + c] = s;
 }
+// the same restricted to the rows whose id equals `key` (gradient of the mask-token embedding)
+__global__ void colsum_where_partial_kernel(const float* __restrict__ Y, long ld, long rows, int N,
+                                            const int64_t* __restrict__ ids, int64_t key, float* __restrict__ part) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r)
+        if (ids[r] == key) s += Y[(size_t)r * ld + c];
+    part[(size_t)blockIdx.y * N + c] = s;
+}
 constexpr int COLSUM_CHUNKS = 256;
+int launch_colsum_where(const float* Y, long ld, long rows, int N, const int64_t* ids, int64_t key, float* out, float beta,
+                        float* part, hipStream_t st) {
+    if (rows <= 0 || N <= 0) return GENIE_OK;
+    colsum_where_partial_kernel<<<dim3((N + 255) / 256, COLSUM_CHUNKS), 256, 0, st>>>(Y, ld, rows, N, ids, key, part);
+    GENIE_LAUNCH_CHECK("colsum_where");
+    return launch_slab_reduce(part, COLSUM_CHUNKS, (size_t)N, out, beta, st);
+}
 int launch_colsum(const float* Y, long ld, long rows, int N, float* out, float beta, float* part, hipStream_t st) {
     if (rows <= 0 || N <= 0) return GENIE_OK;
     colsum_partial_kernel<<<dim3((N + 255) / 256, COLSUM_CHUNKS), 256, 0, st>>>(Y, ld, rows, N, part);
@@ -1128,7 +1147,8 @@ int launch_ce_fwd_bwd(const genie_cfg& c, float* logits, const int64_t* ids, con
 // embedding backward (factorization_utils.py:29-52, st_mask_git.py:257-261), scatter-free and ordered:
 //   dpos[t,s,:]  = sum_b dx[b,t,s,:]
 //   row v of table f (block f*vf + v): sum over tokens n (ascending) with factor_f(id_n) == v and id_n != MASK
-//   mask row (last block): sum over tokens with id_n == MASK
+//   mask row: a predicated column sum over the tokens with id_n == MASK (they are a large fraction of a training
+//   batch, so they get the chunked two-stage reduction instead of one block)
 // ------------------------------------------------------------------------------------------------
 struct EmbedTables { float* p[4]; };
 __global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int B, size_t per_clip,
@@ -1148,8 +1168,8 @@ __global__ __launch_bounds__(256) void embed_bwd_tables_kernel(const float* __re
     // of dx are summed channel-parallel in that order -- no atomics, no sort, bit-reproducible.
     __shared__ unsigned long long masks[4][4];  // [k][wave]: tokens base + k*256 + wave*64 + bit
     const int blk = blockIdx.x;
-    const bool is_mask_row = blk == nfac * vf;
-    const int f = is_mask_row ? 0 : blk / vf, v = is_mask_row ? 0 : blk - f * vf;
+    constexpr bool is_mask_row = false;
+    const int f = blk / vf, v = blk - f * vf;
     int64_t div = 1;
     for (int k = 0; k < f; ++k) div *= vf;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1193,18 +1213,19 @@ __global__ __launch_bounds__(256) void embed_bwd_tables_kernel(const float* __re
     }
 }
 int launch_embed_bwd(const genie_cfg& c, const float* dx, const int64_t* ids, int B, float* dpos, float* dmask,
-                     float* const* tables_host, float beta, hipStream_t st) {
+                     float* const* tables_host, float beta, float* colpart, hipStream_t st) {
     EmbedTables tables_dev;
     for (int j = 0; j < 4; ++j) tables_dev.p[j] = j < c.num_factored ? tables_host[j] : nullptr;
     GENIE_CHECK_SHAPE(c.d_model <= 1024, "embed backward: d_model > 1024");
     const size_t per_clip = (size_t)c.T * c.S * c.d_model;
     embed_bwd_pos_kernel<<<(unsigned)((per_clip + 255) / 256), 256, 0, st>>>(dx, dpos, B, per_clip, beta);
     GENIE_LAUNCH_CHECK("embed_bwd_pos");
-    embed_bwd_tables_kernel<<<c.num_factored * c.factored_vocab + 1, 256, 0, st>>>(
+    embed_bwd_tables_kernel<<<c.num_factored * c.factored_vocab, 256, 0, st>>>(
         dx, ids, (long)B * c.T * c.S, c.d_model, c.factored_vocab, c.num_factored, (int64_t)c.image_vocab_size, tables_dev,
         dmask, beta);
     GENIE_LAUNCH_CHECK("embed_bwd_tables");
-    return GENIE_OK;
+    return launch_colsum_where(dx, c.d_model, (long)B * c.T * c.S, c.d_model, ids, (int64_t)c.image_vocab_size, dmask, beta,
+                               colpart, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -610,7 +610,7 @@ int genie_train_backward_embed(const genie_cfg* cfg, const genie_weights* grads,
     float* tables[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int j = 0; j < cfg->num_factored && j < 4; ++j) tables[j] = (float*)grads->embed[j];
     return launch_embed_bwd(*cfg, w.dx, input_ids, B, (float*)grads->pos_embed, (float*)grads->mask_embed, tables,
-                            accumulate ? 1.0f : 0.0f, (hipStream_t)stream);
+                            accumulate ? 1.0f : 0.0f, w.colpart, (hipStream_t)stream);
 }
 
 int genie_sumsq(const float* x, size_t n, double* out, double* scratch, void* stream) {

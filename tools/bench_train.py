@@ -34,6 +34,8 @@ def main():
     ids = torch.from_numpy(syn.make_clips(a.batch, cfg, seed=1)).cuda()
     collate = pkg("data").maskgit_collate
     torch.manual_seed(0)
+    import random
+    random.seed(0)
     batch = collate(ids, cfg)
     lib = _lib.load()
     for _ in range(a.warmup):
