@@ -68,6 +68,50 @@ def cpu_baseline(cfg, sd, clips, maskgit_steps, timesteps=(8,), max_threads=32):
                       f"{dt:.1f} s on {os.cpu_count()} logical CPUs"}
 
 
+def train_leg(cfg, dev, dist_mod, rank, world, precision, batch, steps):
+    """Secondary leg: the training step -- collate, forward, backward, bucketed
+    gradient all-reduce (RCCL when world > 1, overlapped with the backward), clip, AdamW -- on synthetic clips with
+    init-law weights.  Weak scaling: `batch` clips per GPU.  Never part of the headline timing."""
+    synth = importlib.import_module("1xgpt_amd.synthetic")
+    STMaskGIT = importlib.import_module("1xgpt_amd.st_mask_git").STMaskGIT
+    trainmod = importlib.import_module("1xgpt_amd.train")
+    datamod = importlib.import_module("1xgpt_amd.data")
+    import random
+    tcfg = cfg.shallow_copy()
+    tcfg.qk_norm = False
+    sd = synth.make_state_dict(tcfg, seed=0, law="init")
+    model = STMaskGIT(tcfg, precision=precision).load_numpy_state_dict(sd).to(dev)
+    tr = trainmod.GenieTrainer(model, lr=1e-4, weight_decay=0.0, max_grad_norm=1.0)
+    ids = torch.from_numpy(synth.make_clips(batch, tcfg, seed=77 + rank)).to(dev)
+    torch.manual_seed(rank)
+    random.seed(0)  # same branch of the collator on every rank and run
+    batch_t = datamod.maskgit_collate(ids, tcfg)
+    out = tr.train_step(batch_t)  # warm-up (allocations, first-launch costs)
+    dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.train_step(batch_t)
+    torch.cuda.synchronize()
+    dist_mod.barrier()
+    sec = time.perf_counter() - t0
+    tt = torch.tensor([sec], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    sec = float(tt.item())
+    tokens = batch * tcfg.T * tcfg.S * world
+    n_params = sum(p.numel() for p in model.parameters())
+    res = {"value": tokens * steps / sec, "unit": "tokens/s", "ms_per_step": sec / steps * 1e3, "clips_per_gpu": batch,
+           "n_gpus": world, "precision": precision, "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
+           "tflops_6ND": 6.0 * n_params * tokens * steps / sec / 1e12,
+           "gradient_exchange": "bucketed RCCL all-reduce overlapped with the backward" if world > 1 else "none (1 GPU)",
+           "note": "forward + backward + clip_grad_norm_ + AdamW, f32 parameters/optimizer state, synthetic clips, "
+                   "init-law weights, MaskGIT collator applied once outside the timed region"}
+    del tr, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +127,9 @@ def main():
     ap.add_argument("--no-reuse", action="store_true",
                     help="run the reference's 15 x maskgit_steps FULL forwards per batch instead of teacher-forced "
                          "prefix reuse (1 clean pass + maskgit_steps masked-frame passes, identical outputs)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--train-precision", choices=["exact", "f16x3", "bf16"], default="bf16")
+    ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
@@ -179,6 +226,16 @@ def main():
                             "gbps": round(prof[3] / max(prof[1], 1e-9) / 1e6, 1)}
         lib.genie_profile_enable(0)
 
+    # secondary leg: training step (every rank takes part: the gradient all-reduce is the path's one real exchange)
+    train = None
+    if not args.no_train_leg and os.environ.get("GENIE_BENCH_TRAIN", "1") != "0":
+        del ev, model
+        torch.cuda.empty_cache()
+        try:
+            train = train_leg(cfg, dev, dist_mod, rank, world, args.train_precision, args.train_batch, 2)
+        except Exception as e:  # never let the secondary leg take the headline down
+            train = {"error": f"{type(e).__name__}: {e}"}
+
     if rank != 0:
         return
     m = dist_mod.means_from_sums(sums.tolist())
@@ -233,6 +290,8 @@ def main():
         out["roofline"]["mfma_issue_frac"] = 3.0 * achieved / peak
         out["roofline"]["note"] = ("algorithmic FLOPs counted once; the kernel issues 3 f16 MFMAs per algorithmic MFMA "
                                    "(split operands), so frac <= 1/3 by construction")
+    if train:
+        out["train_step"] = train
     if breakdown:
         out["breakdown"] = breakdown
     if world == 1 and not args.no_cpu_baseline:
