@@ -132,12 +132,13 @@ int launch_embed_bwd(const genie_cfg& c, const float* dx, const int64_t* ids, in
                      float* const* tables_host, float beta, float* colpart, hipStream_t st);
 int launch_sumsq(const float* x, size_t n, double* out, double* scratch, hipStream_t st);
 // 16-bit operand copies (kernels_train16.hip); npl = 1 bf16, 2 = f16 split planes [hi | lo]
+// colpart != NULL: also the column sums of the (post-gelu') values: slabs [rows/64][cols] for launch_slab_reduce
 int launch_cast_transpose16(int npl, float* in, long ld, const float* z, uint16_t* out16, uint16_t* out16T, int rows,
-                            int cols, hipStream_t st);
+                            int cols, hipStream_t st, float* colpart = nullptr);
 int launch_transpose16(int npl, const uint16_t* in, uint16_t* outT, int rows, int cols, hipStream_t st);
 int launch_gelu_fwd16(int npl, const float* z, uint16_t* h16, size_t n, hipStream_t st);
 int launch_cast16(int npl, const float* src, uint16_t* dst, size_t n, hipStream_t st);
-enum { G16X_GELU = 1, G16X_ACCUM = 2, G16X_OUT16 = 4, G16X_OUTF32 = 8 };  // = the G16_* flags of kernels_bf16.hip
+enum { G16X_GELU = 1, G16X_ACCUM = 2, G16X_OUT16 = 4, G16X_OUTF32 = 8, G16X_GELU16 = 16 };  // = the G16_* flags of kernels_bf16.hip
 int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                      const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N,
                      int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC);

@@ -20,7 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-enum { G16_GELU = 1, G16_ACCUM = 2, G16_OUT16 = 4, G16_OUTF32 = 8 };
+enum { G16_GELU = 1, G16_ACCUM = 2, G16_OUT16 = 4, G16_OUTF32 = 8,
+       G16_GELU16 = 16 /* erf-GELU on the 16-bit output only: Cf keeps the pre-activation (training forward) */ };
 
 constexpr float SPLIT_INV = 1.0f / 2048.0f;
 
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
             }
             if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
             if (out16) {
+                if (flags & G16_GELU16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
                 store16<NPL>(C16, (size_t)plane16, idx, v.x); store16<NPL>(C16, (size_t)plane16, idx + 1, v.y);
                 store16<NPL>(C16, (size_t)plane16, idx + 2, v.z); store16<NPL>(C16, (size_t)plane16, idx + 3, v.w);
             }
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
                 const size_t idx = (size_t)row * ldc + col + c;
                 if (do_acc) v += Rsrc[idx];
                 if (outf) Cf[idx] = v;
-                if (out16) store16<NPL>(C16, (size_t)plane16, idx, v);
+                if (out16) store16<NPL>(C16, (size_t)plane16, idx, (flags & G16_GELU16) ? gelu_erf(v) : v);
             }
         }
     }
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
         }
         if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
         if (out16) {
+            if (flags & G16_GELU16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
             if constexpr (NPL == 1) {
                 uint2 pk;
                 pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);

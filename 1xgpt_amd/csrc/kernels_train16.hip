@@ -24,8 +24,10 @@ __device__ __forceinline__ float gelu_grad16(float z) {
 template <int NPL, int MODE>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(float* __restrict__ in, long ld, const float* __restrict__ z,
                                                              uint16_t* __restrict__ out16, uint16_t* __restrict__ out16T,
-                                                             int rows, int cols) {
+                                                             int rows, int cols, float* __restrict__ colpart) {
     __shared__ uint16_t tile[NPL][64][66];
+    __shared__ float csum[4][64];
+    float cs = 0.f;  // column c0+tx over this thread's 16 rows (bias gradient partial)
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const size_t plane = (size_t)rows * cols;
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(float* __restrict__
             v *= gelu_grad16(z[src]);
             in[src] = v;
         }
+        cs += v;
         uint16_t hi, lo;
         to16<NPL>(v, hi, lo);
         tile[0][rl][tx] = hi;
@@ -48,7 +51,10 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(float* __restrict__
             if constexpr (NPL == 2) out16[plane + dst] = lo;
         }
     }
+    if (colpart) csum[ty][tx] = cs;
     __syncthreads();
+    if (colpart && ty == 0)
+        colpart[(size_t)blockIdx.y * cols + c0 + tx] = ((csum[0][tx] + csum[1][tx]) + csum[2][tx]) + csum[3][tx];
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int cl = ty * 16 + i;
@@ -100,17 +106,17 @@ static int check64(int rows, int cols, const char* what) {
 
 // mode 0: plain cast; mode 1: in *= gelu'(z) first (in place).  out16 may be NULL.
 int launch_cast_transpose16(int npl, float* in, long ld, const float* z, uint16_t* out16, uint16_t* out16T, int rows,
-                            int cols, hipStream_t st) {
+                            int cols, hipStream_t st, float* colpart) {
     GENIE_TRY(check64(rows, cols, "cast_transpose16"));
     if (!rows || !cols) return GENIE_OK;
     dim3 grid(cols / 64, rows / 64);
     ProfScope prof(GENIE_KC_OTHER, 0.0, (double)rows * cols * (4.0 + (z ? 8.0 : 0.0) + 2.0 * npl * (out16 ? 2 : 1)), st);
     if (npl == 1) {
-        if (z) cast_transpose_kernel<1, 1><<<grid, 256, 0, st>>>(in, ld, z, out16, out16T, rows, cols);
-        else cast_transpose_kernel<1, 0><<<grid, 256, 0, st>>>(in, ld, nullptr, out16, out16T, rows, cols);
+        if (z) cast_transpose_kernel<1, 1><<<grid, 256, 0, st>>>(in, ld, z, out16, out16T, rows, cols, colpart);
+        else cast_transpose_kernel<1, 0><<<grid, 256, 0, st>>>(in, ld, nullptr, out16, out16T, rows, cols, colpart);
     } else {
-        if (z) cast_transpose_kernel<2, 1><<<grid, 256, 0, st>>>(in, ld, z, out16, out16T, rows, cols);
-        else cast_transpose_kernel<2, 0><<<grid, 256, 0, st>>>(in, ld, nullptr, out16, out16T, rows, cols);
+        if (z) cast_transpose_kernel<2, 1><<<grid, 256, 0, st>>>(in, ld, z, out16, out16T, rows, cols, colpart);
+        else cast_transpose_kernel<2, 0><<<grid, 256, 0, st>>>(in, ld, nullptr, out16, out16T, rows, cols, colpart);
     }
     GENIE_LAUNCH_CHECK("cast_transpose16");
     return GENIE_OK;

@@ -59,7 +59,8 @@ static TrainWs train_ws(const genie_cfg& c, int B, void* base) {
     const size_t o_dx = take(M * d), o_d1 = take(M * d), o_g = take(M * wide), o_p = take(scores), o_dp = take(scores);
     w.slab_floats = 64 * maxw;
     const size_t o_sl = take(w.slab_floats), o_ln = take(ln_bwd_scratch_floats((int)d));
-    const size_t o_cp = take((size_t)COLSUM_SCRATCH_ROWS * maxn), o_ds = take(2 * 1024);
+    const size_t cp_rows = M / 64 > (size_t)COLSUM_SCRATCH_ROWS ? M / 64 : (size_t)COLSUM_SCRATCH_ROWS;
+    const size_t o_cp = take(cp_rows * maxn), o_ds = take(2 * 1024);
     const size_t o_qkn = take(c.qk_norm ? M * 2 * d : 0);
     w.total = o;
     char* b = (char*)base;
@@ -213,6 +214,12 @@ static TrainWs16 train_ws16(const genie_cfg& c, int B, int npl, void* base, size
     w.dy16 = (uint16_t*)(b + o1); w.dy16T = (uint16_t*)(b + o2); w.xT16 = (uint16_t*)(b + o3);
     return w;
 }
+// 16-bit copies of a gradient matrix in both orientations and, in the same pass, its column sums (= the bias gradient)
+static int cast_t_bias(int npl, float* in, int cols, const float* z, TrainWs16& h, int M, float* dbias, float beta,
+                       TrainWs& w, hipStream_t st) {
+    GENIE_TRY(launch_cast_transpose16(npl, in, cols, z, h.dy16, h.dy16T, M, cols, st, dbias ? w.colpart : nullptr));
+    return dbias ? launch_slab_reduce(w.colpart, M / 64, (size_t)cols, dbias, beta, st) : GENIE_OK;
+}
 static inline int npl_of(const genie_cfg& c) { return c.precision == GENIE_PREC_BF16 ? 1 : 2; }
 static inline long PL(int npl, size_t n) { return npl == 2 ? (long)n : 0; }
 
@@ -316,9 +323,10 @@ static int train_forward16(const genie_cfg& c, const genie_weights* wt, const in
             if (npl == 1) GENIE_TRY(launch_layer_norm_bf16(F(l, a.x2), lw.norm2_w, lw.norm2_b, H16(l, a.u2), M, d, 1e-5f, st));
             else GENIE_TRY(launch_layer_norm_split(F(l, a.x2), lw.norm2_w, lw.norm2_b, H16(l, a.u2), pd, M, d, 1e-5f, st));
         }
-        GENIE_TRY(lin16(npl, H16(l, a.u2), pd, lw.fc1_w16, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, F(l, a.z), nullptr, M,
-                        hid, d, 1.0f, st));
-        GENIE_TRY(launch_gelu_fwd16(npl, F(l, a.z), H16(l, a.h), ph, st));
+        // fc1: the f32 pre-activation is kept for gelu'; the 16-bit operand of fc2 gets gelu applied in the epilogue
+        GENIE_TRY(launch_gemm16_ex(npl, H16(l, a.u2), d, PL(npl, pd), lw.fc1_w16, d, PL(npl, (size_t)hid * d),
+                                   c.mlp_bias ? lw.fc1_b : nullptr, nullptr, F(l, a.z), H16(l, a.h), PL(npl, ph), hid, M, hid,
+                                   d, G16X_OUTF32 | G16X_OUT16 | G16X_GELU16, 1.0f, st, 1, 0, 0, 0));
         GENIE_TRY(lin16(npl, H16(l, a.h), ph, lw.fc2_w16, c.mlp_bias ? lw.fc2_b : nullptr, F(l, a.x2), xnext,
                         c.qk_norm ? xnext16 : nullptr, M, d, hid, 1.0f, st));
     }
@@ -340,10 +348,9 @@ static int train_backward_head16(const genie_cfg& c, const genie_weights* wt, co
     const TrainActs16 a = train_acts16(c, B, npl);
     const int d = c.d_model, M = B * c.T * c.S, V = c.factored_vocab * c.num_factored;
     float* dl = (float*)(acts + a.logits);
-    GENIE_TRY(launch_cast_transpose16(npl, dl, V, nullptr, h.dy16, h.dy16T, M, V, st));
+    GENIE_TRY(cast_t_bias(npl, dl, V, nullptr, h, M, (float*)grads->out_b, beta, w, st));
     GENIE_TRY(launch_transpose16(npl, (const uint16_t*)(acts + a.xL16), h.xT16, M, d, st));
     GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)grads->out_w, M, V, d, c.readout_mult, beta, w.slabs, w.slab_floats, st));
-    GENIE_TRY(launch_colsum(dl, V, M, V, (float*)grads->out_b, beta, w.colpart, st));
     return lin16(npl, h.dy16, (size_t)M * V, wT->out_w16, nullptr, nullptr, w.dx, nullptr, M, d, V, c.readout_mult, st);
 }
 
@@ -364,15 +371,13 @@ static int train_backward_layer16(const genie_cfg& c, const genie_weights* wt, c
     QkSrc qk;
 
     // ---- MLP
-    GENIE_TRY(launch_cast_transpose16(npl, dx, d, nullptr, h.dy16, h.dy16T, M, d, st));
+    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.mlp_bias ? (float*)g.fc2_b : nullptr, beta, w, st));
     GENIE_TRY(launch_transpose16(npl, H16(a.h), h.xT16, M, hid, st));
     GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.fc2_w, M, d, hid, 1.0f, beta, w.slabs, w.slab_floats, st));
-    if (c.mlp_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.fc2_b, beta, w.colpart, st));
     GENIE_TRY(lin16(npl, h.dy16, pd, lt.fc2_w16, nullptr, nullptr, w.g, nullptr, M, hid, d, 1.0f, st));         // dh
-    GENIE_TRY(launch_cast_transpose16(npl, w.g, hid, F(a.z), h.dy16, h.dy16T, M, hid, st));                     // dz
+    GENIE_TRY(cast_t_bias(npl, w.g, hid, F(a.z), h, M, c.mlp_bias ? (float*)g.fc1_b : nullptr, beta, w, st));  // dz
     GENIE_TRY(launch_transpose16(npl, H16(a.u2), h.xT16, M, d, st));
     GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.fc1_w, M, hid, d, 1.0f, beta, w.slabs, w.slab_floats, st));
-    if (c.mlp_bias) GENIE_TRY(launch_colsum(w.g, hid, M, hid, (float*)g.fc1_b, beta, w.colpart, st));
     if (c.qk_norm) {
         GENIE_TRY(lin16(npl, h.dy16, ph, lt.fc1_w16, nullptr, dx, dx, nullptr, M, d, hid, 1.0f, st));
     } else {
@@ -382,34 +387,30 @@ static int train_backward_layer16(const genie_cfg& c, const genie_weights* wt, c
     }
 
     // ---- temporal
-    GENIE_TRY(launch_cast_transpose16(npl, dx, d, nullptr, h.dy16, h.dy16T, M, d, st));
+    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.proj_bias ? (float*)g.temporal.proj_b : nullptr, beta, w, st));
     GENIE_TRY(launch_transpose16(npl, H16(a.aot), h.xT16, M, d, st));
     GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.temporal.proj_w, M, d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
-    if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.temporal.proj_b, beta, w.colpart, st));
     GENIE_TRY(lin16(npl, h.dy16, pd, lt.temporal.proj_w16, nullptr, nullptr, w.d1, nullptr, M, d, d, 1.0f, st));
     GENIE_TRY(qk_source(c, lw.temporal, F(a.qkvt), w, B, &qk, st));
     GENIE_TRY(launch_attn_temporal_bwd(F(a.qkvt), qk.p, qk.ld, w.d1, w.g, B, c.T, c.S, d, c.num_heads, c.head_dim,
                                        c.attn_scale, st));
     GENIE_TRY(qk_norm_backward(c, lw.temporal, g.temporal, F(a.qkvt), w.g, w, B, beta, st));
-    GENIE_TRY(launch_cast_transpose16(npl, w.g, 3 * d, nullptr, h.dy16, h.dy16T, M, 3 * d, st));
+    GENIE_TRY(cast_t_bias(npl, w.g, 3 * d, nullptr, h, M, c.qkv_bias ? (float*)g.temporal.qkv_b : nullptr, beta, w, st));
     GENIE_TRY(launch_transpose16(npl, H16(a.x1h), h.xT16, M, d, st));
     GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.temporal.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
-    if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.temporal.qkv_b, beta, w.colpart, st));
     GENIE_TRY(lin16(npl, h.dy16, p3, lt.temporal.qkv_w16, nullptr, dx, dx, nullptr, M, d, 3 * d, 1.0f, st));
 
     // ---- spatial
-    GENIE_TRY(launch_cast_transpose16(npl, dx, d, nullptr, h.dy16, h.dy16T, M, d, st));
+    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.proj_bias ? (float*)g.spatial.proj_b : nullptr, beta, w, st));
     GENIE_TRY(launch_transpose16(npl, H16(a.aos), h.xT16, M, d, st));
     GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.spatial.proj_w, M, d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
-    if (c.proj_bias) GENIE_TRY(launch_colsum(dx, d, M, d, (float*)g.spatial.proj_b, beta, w.colpart, st));
     GENIE_TRY(lin16(npl, h.dy16, pd, lt.spatial.proj_w16, nullptr, nullptr, w.d1, nullptr, M, d, d, 1.0f, st));
     GENIE_TRY(qk_source(c, lw.spatial, F(a.qkvs), w, B, &qk, st));
     GENIE_TRY(spatial_attn_bwd(c, F(a.qkvs), qk, w.d1, w.g, w, B, st));
     GENIE_TRY(qk_norm_backward(c, lw.spatial, g.spatial, F(a.qkvs), w.g, w, B, beta, st));
-    GENIE_TRY(launch_cast_transpose16(npl, w.g, 3 * d, nullptr, h.dy16, h.dy16T, M, 3 * d, st));
+    GENIE_TRY(cast_t_bias(npl, w.g, 3 * d, nullptr, h, M, c.qkv_bias ? (float*)g.spatial.qkv_b : nullptr, beta, w, st));
     GENIE_TRY(launch_transpose16(npl, H16(a.u1), h.xT16, M, d, st));
     GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.spatial.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
-    if (c.qkv_bias) GENIE_TRY(launch_colsum(w.g, 3 * d, M, 3 * d, (float*)g.spatial.qkv_b, beta, w.colpart, st));
     if (c.qk_norm) return lin16(npl, h.dy16, p3, lt.spatial.qkv_w16, nullptr, dx, dx, nullptr, M, d, 3 * d, 1.0f, st);
     GENIE_TRY(lin16(npl, h.dy16, p3, lt.spatial.qkv_w16, nullptr, nullptr, w.d1, nullptr, M, d, 3 * d, 1.0f, st));
     return launch_ln_bwd(F(a.x0), lw.norm1_w, w.d1, dx, (float*)g.norm1_w, (float*)g.norm1_b, M, d, 1e-5f, beta, w.lnpart, st);
