@@ -21,9 +21,20 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum { G16_GELU = 1, G16_ACCUM = 2, G16_OUT16 = 4, G16_OUTF32 = 8,
-       G16_GELU16 = 16 /* erf-GELU on the 16-bit output only: Cf keeps the pre-activation (training forward) */ };
+       G16_GELU16 = 16, /* erf-GELU on the 16-bit output only: Cf keeps the pre-activation (training forward) */
+       G16_NT = 32      /* non-temporal output stores: the output is larger than the on-die caches (launcher) */ };
 
 constexpr float SPLIT_INV = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void store_u2(uint16_t* p, uint2 v, bool nt) {
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    if (nt) {
+        u2v t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(p));
+    } else {
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+}
 
 template <int NPL>
 __device__ __forceinline__ void store16(uint16_t* base, size_t plane_stride, size_t idx, float v) {
@@ -201,7 +212,15 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
                 const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
-            if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
+            if (outf) {
+                if (flags & G16_NT) {
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    nt4 t = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(t, reinterpret_cast<nt4*>(Cf + idx));
+                } else {
+                    *reinterpret_cast<float4*>(Cf + idx) = v;
+                }
+            }
             if (out16) {
                 if (flags & G16_GELU16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
                 store16<NPL>(C16, (size_t)plane16, idx, v.x); store16<NPL>(C16, (size_t)plane16, idx + 1, v.y);
@@ -468,22 +487,30 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
             const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-        if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
+        if (outf) {
+            if (flags & G16_NT) {
+                typedef float nt4 __attribute__((ext_vector_type(4)));
+                nt4 t = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(t, reinterpret_cast<nt4*>(Cf + idx));
+            } else {
+                *reinterpret_cast<float4*>(Cf + idx) = v;
+            }
+        }
         if (out16) {
             if (flags & G16_GELU16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
             if constexpr (NPL == 1) {
                 uint2 pk;
                 pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
                 pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-                *reinterpret_cast<uint2*>(C16 + idx) = pk;
+                store_u2(C16 + idx, pk, flags & G16_NT);
             } else {
                 uint16_t h0, l0, h1, l1, h2, l2, h3, l3;
                 split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3);
                 uint2 ph, pl;
                 ph.x = (uint32_t)h0 | ((uint32_t)h1 << 16); ph.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
                 pl.x = (uint32_t)l0 | ((uint32_t)l1 << 16); pl.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
-                *reinterpret_cast<uint2*>(C16 + idx) = ph;
-                *reinterpret_cast<uint2*>(C16 + (size_t)plane16 + idx) = pl;
+                store_u2(C16 + idx, ph, flags & G16_NT);
+                store_u2(C16 + (size_t)plane16 + idx, pl, flags & G16_NT);
             }
         }
     }
@@ -500,6 +527,12 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
     GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
     if (M <= 0 || N <= 0) return GENIE_OK;
     const double mn = (double)M * N * batch;
+    {   // outputs that cannot stay in the 256 MB Infinity Cache anyway are stored non-temporally: +10..18 % on the
+        // K = 512 GEMMs at >= 8 clips (they no longer evict the A panel / weights they share the L2 with)
+        static const int nt_mode = [] { const char* e = getenv("GENIE_GEMM16_NT"); return e ? atoi(e) : -1; }();
+        const double out_bytes = mn * ((flags & G16_OUTF32 ? 4 : 0) + (flags & G16_OUT16 ? 2 * NPL : 0));
+        if (nt_mode == 1 || (nt_mode < 0 && out_bytes >= 192e6)) flags |= G16_NT;
+    }
     static const int force_v1 = [] { const char* e = getenv("GENIE_GEMM16_V1"); return e ? atoi(e) : 0; }();
     // small problems (batch-1 generate: M = 4096 or 256 rows): 256x128 tiles would leave most of the 256 CUs idle, the
     // 128x128 kernel below makes 2x the workgroups (and runs two of them per CU)
