@@ -268,8 +268,8 @@ def main():
         "model_frac_of_mfma_peak": passes_per_step * F * args.steps / seconds / 1e12 / peak,
         "roofline": {
             "kernel": {"exact": "gemm_f32_nt_kernel (v_mfma_f32_32x32x2_f32)",
-                       "f16x3": "gemm16_nt_kernel<2,32> (3x v_mfma_f32_32x32x16_f16 per K-step)",
-                       "bf16": "gemm16_nt_kernel<1,64> (v_mfma_f32_32x32x16_bf16)"}[args.precision],
+                       "f16x3": "gemm16_v2_kernel<2,32,4> (3x v_mfma_f32_32x32x16_f16 per K-step)",
+                       "bf16": "gemm16_v2_kernel<1,64,2> (v_mfma_f32_32x32x16_bf16)"}[args.precision],
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "launches": int(gemm_launches), "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
             "flops_per_launch": gemm_flops / max(gemm_launches, 1),
