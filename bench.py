@@ -128,6 +128,8 @@ def main():
                     help="run the reference's 15 x maskgit_steps FULL forwards per batch instead of teacher-forced "
                          "prefix reuse (1 clean pass + maskgit_steps masked-frame passes, identical outputs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the full-forward-schedule secondary leg (profiling runs: only headline launches in the trace)")
     ap.add_argument("--train-precision", choices=["exact", "f16x3", "bf16"], default="bf16")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--no-events", action="store_true",
@@ -194,7 +196,7 @@ def main():
 
     # secondary leg (N=1 only): the same batch through the reference's full-forward schedule, 1 timed step
     full_forward = None
-    if reuse and world == 1:
+    if reuse and world == 1 and not args.no_secondary:
         nb = min(B, {"exact": 4, "f16x3": 16, "bf16": 32}[args.precision])
         clips_full, noise_full = clips[:nb], noise[:, :, :nb].contiguous()
         ev.evaluate_metric_sums(clips_full, noise=noise_full)  # warm-up
