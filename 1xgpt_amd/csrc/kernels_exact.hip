@@ -128,12 +128,94 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     }
 }
 
+// The same LayerNorm for C = 256 / 512 (the shipped widths), tuned for bandwidth: a lane owns VPL = C/64 CONTIGUOUS
+// channels (32-byte loads, one 16-byte store per 16-bit plane), a wave walks 4 consecutive rows with the next row's
+// loads in flight while the current one is reduced, and gamma / beta are read once per wave.
+template <typename OutT, bool SPLIT, int VPL>
+__global__ __launch_bounds__(256) void layer_norm_fast_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              const float* __restrict__ b, OutT* __restrict__ y, long rows,
+                                                              float eps, size_t plane) {
+    constexpr int C = 64 * VPL, RPW = 4;
+    const int lane = threadIdx.x & 63;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    float gv[VPL], bv[VPL], cur[VPL], nxt[VPL];
+    auto load = [&](const float* p, float (&v)[VPL]) {
+#pragma unroll
+        for (int k = 0; k < VPL; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p + lane * VPL + k);
+            v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+        }
+    };
+    load(x + (size_t)row0 * C, cur);
+    load(g, gv);
+    load(b, bv);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long row = row0 + r;
+        if (row >= rows) break;
+        if (r + 1 < RPW && row + 1 < rows) load(x + (size_t)(row + 1) * C, nxt);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) s += cur[k];
+        const float mean = wave_sum(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { cur[k] -= mean; q += cur[k] * cur[k]; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+        float o[VPL];
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) o[k] = cur[k] * rstd * gv[k] + bv[k];
+        OutT* yr = y + (size_t)row * C + lane * VPL;
+        if constexpr (SPLIT) {
+            uint32_t ph[VPL / 2], pl[VPL / 2];
+#pragma unroll
+            for (int k = 0; k < VPL; k += 2) {
+                uint16_t h0, l0, h1, l1;
+                split_f16(o[k], h0, l0);
+                split_f16(o[k + 1], h1, l1);
+                ph[k / 2] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                pl[k / 2] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            }
+            if constexpr (VPL == 8) {
+                *reinterpret_cast<uint4*>(yr) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                *reinterpret_cast<uint4*>(yr + plane) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            } else {
+                *reinterpret_cast<uint2*>(yr) = make_uint2(ph[0], ph[1]);
+                *reinterpret_cast<uint2*>(yr + plane) = make_uint2(pl[0], pl[1]);
+            }
+        } else if constexpr (sizeof(OutT) == 2) {
+            uint32_t pk[VPL / 2];
+#pragma unroll
+            for (int k = 0; k < VPL; k += 2) pk[k / 2] = (uint32_t)f32_to_bf16(o[k]) | ((uint32_t)f32_to_bf16(o[k + 1]) << 16);
+            if constexpr (VPL == 8) *reinterpret_cast<uint4*>(yr) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            else *reinterpret_cast<uint2*>(yr) = make_uint2(pk[0], pk[1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VPL; k += 4)
+                *reinterpret_cast<float4*>(yr + k) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) cur[k] = nxt[k];
+    }
+}
+template <typename OutT, bool SPLIT>
+static bool launch_layer_norm_fast(const float* x, const float* g, const float* b, OutT* y, long rows, int C, float eps,
+                                   size_t plane, hipStream_t st) {
+    if (C != 512 && C != 256) return false;
+    const unsigned blocks = (unsigned)((rows + 15) / 16);
+    if (C == 512) layer_norm_fast_kernel<OutT, SPLIT, 8><<<blocks, 256, 0, st>>>(x, g, b, y, rows, eps, plane);
+    else layer_norm_fast_kernel<OutT, SPLIT, 4><<<blocks, 256, 0, st>>>(x, g, b, y, rows, eps, plane);
+    return true;
+}
+
 int launch_layer_norm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps,
                       hipStream_t st) {
     GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
     int blocks = (int)((rows + 3) / 4);
     ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * rows * C, 8.0 * rows * C, st);
-    layer_norm_kernel<float><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
+    if (!launch_layer_norm_fast<float, false>(x, g, b, y, rows, C, eps, 0, st))
+        layer_norm_kernel<float><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
     GENIE_LAUNCH_CHECK("layer_norm");
     return GENIE_OK;
 }
@@ -142,7 +224,8 @@ int launch_layer_norm_bf16(const float* x, const float* g, const float* b, uint1
     GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
     int blocks = (int)((rows + 3) / 4);
     ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * rows * C, 6.0 * rows * C, st);
-    layer_norm_kernel<uint16_t><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
+    if (!launch_layer_norm_fast<uint16_t, false>(x, g, b, y, rows, C, eps, 0, st))
+        layer_norm_kernel<uint16_t><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps);
     GENIE_LAUNCH_CHECK("layer_norm_bf16");
     return GENIE_OK;
 }
@@ -152,7 +235,8 @@ int launch_layer_norm_split(const float* x, const float* g, const float* b, uint
     GENIE_CHECK_SHAPE(C <= 2048, "layer_norm: C=%d > 2048", C);
     int blocks = (int)((rows + 3) / 4);
     ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * rows * C, 8.0 * rows * C, st);
-    layer_norm_kernel<uint16_t, true><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps, plane);
+    if (!launch_layer_norm_fast<uint16_t, true>(x, g, b, y, rows, C, eps, plane, st))
+        layer_norm_kernel<uint16_t, true><<<blocks, 256, 0, st>>>(x, g, b, y, rows, C, eps, plane);
     GENIE_LAUNCH_CHECK("layer_norm_split");
     return GENIE_OK;
 }
