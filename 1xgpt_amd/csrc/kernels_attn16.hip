@@ -85,26 +85,36 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
             *reinterpret_cast<f16x8*>(sKl + off) = vl;
         }
     }
-    // ---- stage V^T: task = (key pair, 8-feature chunk); consecutive lanes write consecutive 4-byte words
-    for (int task = tid; task < (S / 2) * (DH / 8); task += 512) {
-        const int kp2 = task % (S / 2), dc = task / (S / 2);
-        const float* v0 = base + (size_t)(2 * kp2) * 3 * d + 2 * d + dc * 8;
-        const float* v1 = v0 + (size_t)3 * d;
-        float a[8], b[8];
-        *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(v0);
-        *reinterpret_cast<float4*>(a + 4) = *reinterpret_cast<const float4*>(v0 + 4);
-        *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(v1);
-        *reinterpret_cast<float4*>(b + 4) = *reinterpret_cast<const float4*>(v1 + 4);
+    // ---- stage V^T.  Global side like K: two adjacent lanes per key row read its 4*DH bytes contiguously (the former
+    // (key pair, 8-feature) tasks touched 32 bytes per 6 KB-strided row and lane: 4x the L2 traffic).  A 32-bit LDS word
+    // packs keys (2p, 2p+1) of one feature, so each lane swaps its values with the lane holding the neighbouring key
+    // (lane ^ 2); the even-key lane then writes the first half of its features, the odd-key lane the second half.
+    {
+        const int rr = tid >> 1, half = tid & 1;
+        const float* vp = base + (size_t)rr * 3 * d + 2 * d + half * (DH / 2);
+        float vx[DH / 2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 ah, al, bh, bl;
-            split_h(a[j], ah, al);
-            split_h(b[j], bh, bl);
-            const int off = (dc * 8 + j) * VT_PITCH + kp2 * 4;
-            uint32_t wh = (uint32_t)__builtin_bit_cast(uint16_t, ah) | ((uint32_t)__builtin_bit_cast(uint16_t, bh) << 16);
-            uint32_t wl = (uint32_t)__builtin_bit_cast(uint16_t, al) | ((uint32_t)__builtin_bit_cast(uint16_t, bl) << 16);
-            *reinterpret_cast<uint32_t*>(sVh + off) = wh;
-            *reinterpret_cast<uint32_t*>(sVl + off) = wl;
+        for (int c = 0; c < DH / 8; ++c) {
+            float4 t = *reinterpret_cast<const float4*>(vp + 4 * c);
+            vx[4 * c] = t.x; vx[4 * c + 1] = t.y; vx[4 * c + 2] = t.z; vx[4 * c + 3] = t.w;
+        }
+        const bool odd = rr & 1;
+        const int kp2 = rr >> 1;
+#pragma unroll
+        for (int c = 0; c < DH / 2; ++c) {
+            const float other = __shfl_xor(vx[c], 2);
+            const bool mine = (c < DH / 4) != odd;  // even key: features [0, DH/4) of its half, odd key: [DH/4, DH/2)
+            if (mine) {
+                const float a = odd ? other : vx[c], b = odd ? vx[c] : other;  // (key 2p, key 2p+1)
+                _Float16 ah, al, bh, bl;
+                split_h(a, ah, al);
+                split_h(b, bh, bl);
+                const int off = (half * (DH / 2) + c) * VT_PITCH + kp2 * 4;
+                *reinterpret_cast<uint32_t*>(sVh + off) =
+                    (uint32_t)__builtin_bit_cast(uint16_t, ah) | ((uint32_t)__builtin_bit_cast(uint16_t, bh) << 16);
+                *reinterpret_cast<uint32_t*>(sVl + off) =
+                    (uint32_t)__builtin_bit_cast(uint16_t, al) | ((uint32_t)__builtin_bit_cast(uint16_t, bl) << 16);
+            }
         }
     }
     __syncthreads();
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
     const int qb = wid;  // 8 waves x 32 queries = 256
     // ---- Q fragments: lane (r,h) holds Q[r][16kk + 8h + j], split, scale folded in before the split
     f16x8 qh[DH / 16], ql[DH / 16];
+    const float scale_l2 = scale * 1.4426950408889634f;  // scores carried as s*log2(e): softmax = one v_exp_f32 each
     {
         float qf[DH / 2];
         const float* qp = base + (size_t)(qb * 32 + r) * 3 * d + 8 * h;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 _Float16 a, b;
-                split_h(qf[8 * kk + j] * scale, a, b);  // q *= scale (attention.py:48)
+                split_h(qf[8 * kk + j] * scale_l2, a, b);  // q *= scale (attention.py:48), in log2 units (see softmax)
                 qh[kk][j] = a; ql[kk][j] = b;
             }
     }
@@ -170,7 +181,9 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[kt][e] = a0[e] + c0[e] * (1.0f / 2048.0f);
     }
-    // ---- softmax over the 256 keys of query r (128 here, 128 in lane r^32)
+    // ---- softmax over the 256 keys of query r (128 here, 128 in lane r^32).  The kernel is VALU-bound (128 exponentials
+    // and 128 operand splits per lane against 192 MFMAs per wave), so exp is the bare v_exp_f32 on log2-scaled scores
+    // (1 ulp) rather than the ~15-instruction expf.
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { sc[kt][e] = expf(sc[kt][e] - mx); sum += sc[kt][e]; }
+        for (int e = 0; e < 16; ++e) { sc[kt][e] = __builtin_amdgcn_exp2f(sc[kt][e] - mx); sum += sc[kt][e]; }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
     // ---- O = P V
