@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
         if (vec && col + 3 < N) {
             float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 v = make_float4(vv[0] * alpha + bv.x, vv[1] * alpha + bv.y, vv[2] * alpha + bv.z, vv[3] * alpha + bv.w);
-            if (do_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
             const size_t idx = (size_t)row * ldc + col;
             if (do_acc) {
                 const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
                 }
             }
             if (out16) {
-                if (flags & G16_GELU16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+                if (flags & G16_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
                 store16<NPL>(C16, (size_t)plane16, idx, v.x); store16<NPL>(C16, (size_t)plane16, idx + 1, v.y);
                 store16<NPL>(C16, (size_t)plane16, idx + 2, v.z); store16<NPL>(C16, (size_t)plane16, idx + 3, v.w);
             }
@@ -230,11 +230,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
             for (int c = 0; c < 4; ++c) {
                 if (col + c >= N) break;
                 float v = vv[c] * alpha + (bias ? bias[col + c] : 0.f);
-                if (do_gelu) v = gelu_erf(v);
+                if (do_gelu) v = gelu_erf_fast(v);
                 const size_t idx = (size_t)row * ldc + col + c;
                 if (do_acc) v += Rsrc[idx];
                 if (outf) Cf[idx] = v;
-                if (out16) store16<NPL>(C16, (size_t)plane16, idx, (flags & G16_GELU16) ? gelu_erf(v) : v);
+                if (out16) store16<NPL>(C16, (size_t)plane16, idx, (flags & G16_GELU16) ? gelu_erf_fast(v) : v);
             }
         }
     }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
         float4 v = *reinterpret_cast<const float4*>(ct + rl * WN_COLS + c4);
         if (row >= M || col >= N) continue;
         v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
-        if (do_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
         const size_t idx = (size_t)row * ldc + col;
         if (do_acc) {
             const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
             }
         }
         if (out16) {
-            if (flags & G16_GELU16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            if (flags & G16_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
             if constexpr (NPL == 1) {
                 uint2 pk;
                 pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);

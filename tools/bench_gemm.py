@@ -14,7 +14,7 @@ sys.path.insert(0, REPO)
 _lib = importlib.import_module("1xgpt_amd._lib")
 
 
-def run(prec, M, N, K, iters=20, check=True):
+def run(prec, M, N, K, iters=20, check=True, gelu=0):
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
@@ -35,7 +35,7 @@ def run(prec, M, N, K, iters=20, check=True):
         _lib.check(pack(W.data_ptr(), W16.data_ptr(), W.numel(), st), "pack")
 
         def call():
-            _lib.check(lib.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, 0, 0,
+            _lib.check(lib.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, gelu, 0,
                                              st), "lin16")
     call()
     torch.cuda.synchronize()
@@ -43,6 +43,8 @@ def run(prec, M, N, K, iters=20, check=True):
     if check:
         rows = torch.randint(0, M, (64,), device="cuda")
         ref = x[rows].double() @ W.double().T + b.double()
+        if gelu:
+            ref = torch.nn.functional.gelu(ref)
         err = (y[rows].double() - ref).abs().max().item()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -58,6 +60,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--prec", nargs="+", default=["exact", "f16x3", "bf16"])
+    ap.add_argument("--gelu", type=int, default=0, help="fused erf-GELU epilogue (16-bit precisions)")
     a = ap.parse_args()
     M = 4096 * a.batch
     shapes = [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), ("fc2", 512, 2048), ("readout", 1024, 512),
@@ -65,6 +68,6 @@ if __name__ == "__main__":
     for prec in a.prec:
         for name, N, K in shapes:
             m = 4096 if name == "sq4096" else M
-            ms, tf, err = run(prec, m, N, K)
+            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0)
             print(f"{prec:6s} {name:8s} M={m:6d} N={N:5d} K={K:5d}  {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s  max|err| {err:.2e}",
                   flush=True)
