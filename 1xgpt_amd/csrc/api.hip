@@ -192,7 +192,12 @@ static int st_block(const genie_cfg& c, const genie_layer_weights& lw, float* x,
 static int decoder(const genie_cfg& c, const genie_weights& wt, float* x, Workspace& w, int B, hipStream_t st) {
     if (c.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c, x, w, B, st));
     if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, x, w, B, st));
-    for (int i = 0; i < c.num_layers; ++i) GENIE_TRY(st_block(c, wt.layers_host[i], x, w, B, st));
+    for (int i = 0; i < c.num_layers; ++i) {
+        w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
+        const int rc = st_block(c, wt.layers_host[i], x, w, B, st);
+        w.skip_shadow_mlp = false;
+        GENIE_TRY(rc);
+    }
     return GENIE_OK;
 }
 
@@ -373,7 +378,9 @@ static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int
     for (int i = 0; i < c.num_layers; ++i) {
         if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; }
         else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; }
+        w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
         int rc = st_block(c, wt.layers_host[i], w.x, w, B, st);
+        w.skip_shadow_mlp = false;
         w.tqkv = nullptr;
         w.tcache = nullptr;
         GENIE_TRY(rc);
@@ -425,7 +432,10 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_
         w.fcache = cache + i * per_layer;
         w.frame_t = t;
         w.frame_T = cfg->T;
-        GENIE_TRY(st_block(c1, wt->layers_host[i], w.x, w, B, st));
+        w.skip_shadow_mlp = !c1.qk_norm && i + 1 < c1.num_layers;
+        const int rc = st_block(c1, wt->layers_host[i], w.x, w, B, st);
+        w.skip_shadow_mlp = false;
+        GENIE_TRY(rc);
     }
     if (!logits) return GENIE_OK;
     return readout(c1, *wt, w.x, w, B, 0, 1, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);

@@ -27,6 +27,9 @@ struct Workspace {
     float* fcache;
     int frame_t;   // -1 = off
     int frame_T;   // frames per clip in the cache layout
+    // 16-bit precisions: the block's last GEMM need not refresh the 16-bit shadow of x when the next consumer is a
+    // LayerNorm (set by the layer loops for every layer but the last when the block has pre-norms)
+    bool skip_shadow_mlp = false;
 };
 
 // Brackets one launch with HIP events when profiling of `cls` is enabled (see genie_profile_* in the ABI).

@@ -664,8 +664,10 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     }
     }
     GENIE_TRY(rc);
+    // the 16-bit shadow of x is only read by a Linear that has no LayerNorm in front: temporal qkv always, fc1 and the next
+    // block's spatial qkv only in the qk-norm variant, the readout after the last block
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.temporal.proj_w16, d, 0, c.proj_bias ? lw.temporal.proj_b : nullptr, x,
-                               x16, 0, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+                               x16, 0, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
     // MLP
     u = x16;
     if (!c.qk_norm) {
@@ -675,7 +677,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.fc1_w16, d, 0, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, big16, 0, c.hidden,
                                M, c.hidden, d, G16_GELU | G16_OUT16, 1.0f, st));
     GENIE_TRY(launch_gemm16<1>(big16, c.hidden, 0, lw.fc2_w16, c.hidden, 0, c.mlp_bias ? lw.fc2_b : nullptr, x, x16, 0,
-                               d, M, d, c.hidden, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+                               d, M, d, c.hidden, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
     return GENIE_OK;
 }
 
@@ -775,7 +777,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     }
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.temporal.proj_w16, d, pw_proj, c.proj_bias ? lw.temporal.proj_b : nullptr,
-                               x, xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+                               x, xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
     // ---- MLP
     u = xs;
     if (!c.qk_norm) {
@@ -785,7 +787,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.fc1_w16, d, pw_fc, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, hs, ph, hid, M,
                                hid, d, G16_GELU | G16_OUT16, 1.0f, st));
     GENIE_TRY(launch_gemm16<2>(hs, hid, ph, lw.fc2_w16, hid, pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, xs, pd, d, M, d,
-                               hid, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+                               hid, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
     return GENIE_OK;
 }
 
