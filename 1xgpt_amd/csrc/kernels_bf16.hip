@@ -546,7 +546,7 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
                            mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) +
                                  (flags & G16_OUT16 ? 2 * NPL : 0)),
                        st);
-        static const int nwn = [] { const char* e = getenv("GENIE_GEMM16_NWN"); return e ? atoi(e) : (NPL == 2 ? 4 : 2); }();
+        static const int nwn = [] { const char* e = getenv("GENIE_GEMM16_NWN"); return e ? atoi(e) : 4; }();
         if (nwn == 4) {
             (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
