@@ -330,13 +330,84 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         part[(size_t)blockIdx.x * 2 * C + c] = s;  // [block][which][C]
     }
 }
+// The same for C = 256 / 512 with the access pattern of layer_norm_fast_kernel: a lane owns VPL = C/64 contiguous
+// channels (float4 loads / read-modify-write of dxout instead of 4-byte strided ones), the next row's x and dy are in
+// flight while the current row is reduced.
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ dy, float* __restrict__ dxout,
+                                                          float* __restrict__ part, long rows, float eps) {
+    constexpr int C = 64 * VPL;
+    __shared__ float red[4][2][C];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float dg[VPL], db[VPL], gm[VPL], xv[VPL], dv[VPL], xn[VPL], dn[VPL];
+    auto load = [&](const float* p, float (&v)[VPL]) {
+#pragma unroll
+        for (int k = 0; k < VPL; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p + lane * VPL + k);
+            v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+        }
+    };
+    load(gamma, gm);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) { dg[k] = 0.f; db[k] = 0.f; }
+    const long stride = (long)gridDim.x * 4;
+    long row = (long)blockIdx.x * 4 + wid;
+    if (row < rows) { load(x + (size_t)row * C, xv); load(dy + (size_t)row * C, dv); }
+    for (; row < rows; row += stride) {
+        const long nrow = row + stride;
+        if (nrow < rows) { load(x + (size_t)nrow * C, xn); load(dy + (size_t)nrow * C, dn); }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) s += xv[k];
+        const float mean = wave_sum(s) * (1.0f / C);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { xv[k] -= mean; v += xv[k] * xv[k]; }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / C) + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            xv[k] *= rstd;  // xhat
+            const float gy = dv[k] * gm[k];
+            s1 += gy;
+            s2 += gy * xv[k];
+            dg[k] += dv[k] * xv[k];
+            db[k] += dv[k];
+        }
+        s1 = wave_sum(s1) * (1.0f / C);
+        s2 = wave_sum(s2) * (1.0f / C);
+        float* o = dxout + (size_t)row * C + lane * VPL;
+#pragma unroll
+        for (int k = 0; k < VPL; k += 4) {
+            float4 t = *reinterpret_cast<const float4*>(o + k);
+            t.x += (dv[k] * gm[k] - s1 - xv[k] * s2) * rstd;
+            t.y += (dv[k + 1] * gm[k + 1] - s1 - xv[k + 1] * s2) * rstd;
+            t.z += (dv[k + 2] * gm[k + 2] - s1 - xv[k + 2] * s2) * rstd;
+            t.w += (dv[k + 3] * gm[k + 3] - s1 - xv[k + 3] * s2) * rstd;
+            *reinterpret_cast<float4*>(o + k) = t;
+        }
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { xv[k] = xn[k]; dv[k] = dn[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) { red[wid][0][lane * VPL + k] = dg[k]; red[wid][1][lane * VPL + k] = db[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int which = c / C, cc = c - which * C;
+        part[(size_t)blockIdx.x * 2 * C + c] = ((red[0][which][cc] + red[1][which][cc]) + red[2][which][cc]) + red[3][which][cc];
+    }
+}
+
 // part slabs are [block][2][C]: dgamma = reduce of the first C, dbeta of the second C
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dxout, float* dgamma, float* dbeta,
                   long rows, int C, float eps, float beta, float* part, hipStream_t st) {
     GENIE_CHECK_SHAPE(C <= 64 * LNB_MAXI, "ln_bwd: C=%d > %d", C, 64 * LNB_MAXI);
     if (rows <= 0) return GENIE_OK;
     ProfScope prof(GENIE_KC_LAYERNORM, 12.0 * rows * C, 16.0 * rows * C, st);
-    ln_bwd_kernel<<<LNB_BLOCKS, 256, (size_t)8 * C * sizeof(float), st>>>(x, gamma, dy, dxout, part, rows, C, eps);
+    if (C == 512) ln_bwd_fast_kernel<8><<<LNB_BLOCKS, 256, 0, st>>>(x, gamma, dy, dxout, part, rows, eps);
+    else if (C == 256) ln_bwd_fast_kernel<4><<<LNB_BLOCKS, 256, 0, st>>>(x, gamma, dy, dxout, part, rows, eps);
+    else ln_bwd_kernel<<<LNB_BLOCKS, 256, (size_t)8 * C * sizeof(float), st>>>(x, gamma, dy, dxout, part, rows, C, eps);
     GENIE_LAUNCH_CHECK("ln_bwd");
     // the two halves of each slab are contiguous ([2][C]), so one reduce of 2C columns serves both when dbeta follows
     // dgamma in memory; they need not, so reduce separately through strided views

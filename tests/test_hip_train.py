@@ -122,10 +122,12 @@ def test_real_geometry_vs_reference_samples(golden, precision):
 
 
 @pytest.mark.parametrize("H,d,B,qk_norm,T", [(4, 128, 3, False, 4), (2, 64, 1, False, 4), (2, 128, 2, True, 4),
-                                              (4, 128, 1, True, 4), (4, 128, 2, False, 16), (2, 128, 1, True, 16)])
+                                              (4, 128, 1, True, 4), (4, 128, 2, False, 16), (2, 128, 1, True, 16),
+                                              (4, 256, 2, False, 4), (8, 512, 1, False, 4)])
 def test_gradients_vs_oracle(H, d, B, qk_norm, T):
-    """Other widths / head sizes (Dh = 32, 64), an odd batch, and T = 16 (the MFMA temporal kernels, forward and
-    backward, with and without qk-norm) against the NumPy restatement."""
+    """Other widths / head sizes (Dh = 32, 64), an odd batch, T = 16 (the MFMA temporal kernels, forward and backward,
+    with and without qk-norm) and the shipped widths d = 256 / 512 (their bandwidth-tuned LayerNorm forward / backward
+    kernels) against the NumPy restatement."""
     cfg = pkg("config").GenieConfig(num_layers=2, num_heads=H, d_model=d, T=T, S=16, num_factored_vocabs=2,
                                     qk_norm=qk_norm, num_prompt_frames=2)
     syn = pkg("synthetic")
