@@ -833,6 +833,8 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
     const float* vb = qkv + row0 * 3 * d + 2 * d + head * DH;
     const float* ob = dO + row0 * d + head * DH;
     float* outb = dqkv + row0 * 3 * d + head * DH;
+    // scores are carried as s*log2(e) so that every exponential is one v_exp_f32 (the probabilities are the same)
+    const float scale_l2 = scale * 1.4426950408889634f;
 
     for (int idx = tid; idx < S * DH / 4; idx += 256) {
         const int row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
@@ -895,14 +897,14 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sT[jt][e] *= scale; m = fmaxf(m, sT[jt][e]); }
+            for (int e = 0; e < 16; ++e) { sT[jt][e] *= scale_l2; m = fmaxf(m, sT[jt][e]); }
         m = fmaxf(m, __shfl_xor(m, 32));
         float l = 0.f, ds = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = expf(sT[jt][e] - m);
+                const float p = __builtin_amdgcn_exp2f(sT[jt][e] - m);
                 sT[jt][e] = p;
                 l += p;
                 ds += p * pT[jt][e];
@@ -917,13 +919,13 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
         float gl = 0.f, gd = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
-            const float f = expf(sPM[ww * 32 + c] - gm);
+            const float f = __builtin_amdgcn_exp2f(sPM[ww * 32 + c] - gm);
             gl += sPL[ww * 32 + c] * f;
             gd += sPD[ww * 32 + c] * f;
         }
         const float inv = 1.0f / gl, Di = gd * inv;
         if (w == 0 && h == 0) { fM[c] = gm; fI[c] = inv; fD[c] = Di; }
-        const float corr = expf(m - gm) * inv;
+        const float corr = __builtin_amdgcn_exp2f(m - gm) * inv;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -939,7 +941,7 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
             const float mi = fM[i], ii = fI[i], di = fD[i];
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                const float p = expf(sN[jt][e] * scale - mi) * ii;
+                const float p = __builtin_amdgcn_exp2f(fmaf(sN[jt][e], scale_l2, -mi)) * ii;
                 sN[jt][e] = p;                        // P, N layout
                 pN[jt][e] = p * (pN[jt][e] - di);     // dS, N layout
             }
