@@ -249,24 +249,28 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
 //   * XCD-aware block order: the 8 m-tiles of a group go to the 8 XCDs and each XCD walks the n-tiles of ITS
 //     m-tile, so the big operand (A) is fetched into one L2 only; W (<= 2 MB) is resident in every L2.
 // ------------------------------------------------------------------------------------------------
-template <int NPL, int BK, int NWN>
+template <int NPL, int BK, int NWN, int BN_ = 128>
 __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
                                                            const uint16_t* __restrict__ W, long ldw, long planeW,
                                                            const float* __restrict__ bias, float* __restrict__ Cf,
                                                            uint16_t* __restrict__ C16, long plane16, long ldc, int M,
                                                            int N, int K, int flags, float alpha, long strideA,
                                                            long strideC, const float* Rf, long strideW) {
-    constexpr int BM = 256, BN = 128, NST = 3;
+    constexpr int BM = 256, BN = BN_, NST = 3;
     constexpr int ROWB = BK * 2, SPR = ROWB / 16, RPB = 256 / ROWB;
     constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB;
-    constexpr int STAGE_B = NPL * (A_TILE + W_TILE);       // 48 KB
+    constexpr int STAGE_B = NPL * (A_TILE + W_TILE);       // 48 KB (256x128 tiles) or 32 KB (bf16 256x256, BK = 32)
     constexpr int NW = 4 * NWN;                             // waves per block: 4 (M) x NWN (N)
     constexpr int NJ = BN / NWN / 32;                       // 32-wide MFMA tiles per wave along N
     constexpr int WN_COLS = BN / NWN;                       // columns per wave
     constexpr int NCH = STAGE_B / 1024;                     // 1 KB chunks per stage (48)
     constexpr int CPW = NCH / NW;                           // per wave (6 or 3)
     constexpr int CHUNK_ROWS = 1024 / ROWB;
-    static_assert(STAGE_B == 48 * 1024 && CPW * NW == NCH, "stage geometry");
+    // epilogue transposition: the ring holds EROUNDS-th of every wave's 64 x WN_COLS accumulator tile at a time
+    constexpr int EROUNDS = (NW * 64 * WN_COLS * 4 + NST * STAGE_B - 1) / (NST * STAGE_B) <= 1 ? 1 : 4;
+    constexpr int RR = 64 / EROUNDS;                        // rows of the wave tile per round
+    static_assert(NST * STAGE_B <= 144 * 1024 && CPW * NW == NCH && NW * RR * WN_COLS * 4 <= NST * STAGE_B,
+                  "stage / epilogue geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -455,17 +459,7 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     // whole rows: 16 lanes x float4 = one 256-byte row segment per quarter-wave for the residual read, the f32
     // store and the 16-bit operand store.
     __syncthreads();  // every wave is done with the stage buffers (and has drained its loads)
-    float* ct = reinterpret_cast<float*>(smem) + wid * (64 * WN_COLS);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e];
-                if constexpr (NPL == 2) v += corr[i][j][e] * SPLIT_INV;
-                ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * WN_COLS + j * 32 + r] = v;
-            }
+    float* ct = reinterpret_cast<float*>(smem) + wid * (RR * WN_COLS);
     const bool do_gelu = flags & G16_GELU, do_acc = flags & G16_ACCUM;
     const bool out16 = flags & G16_OUT16, outf = flags & G16_OUTF32;
     constexpr int LPR = WN_COLS / 4;  // lanes per row (float4 each)
@@ -474,10 +468,26 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     const int col = n0 + wn * WN_COLS + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias && col < N) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+    for (int q = 0; q < EROUNDS; ++q) {
+    // round q: rows [q*RR, (q+1)*RR) of the wave tile = MFMA tile i, e>>2 groups as below
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rowt = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // row inside the 64-row wave tile
+                if (EROUNDS > 1 && (i * 32 + 8 * (e >> 2)) / RR != q) continue;  // compile-time: (e&3) + 4h < 8 <= RR
+                float v = acc[i][j][e];
+                if constexpr (NPL == 2) v += corr[i][j][e] * SPLIT_INV;
+                ct[(rowt - q * RR) * WN_COLS + j * 32 + r] = v;
+            }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-    for (int it = 0; it < 64 / RPI; ++it) {
+    for (int it = 0; it < RR / RPI; ++it) {
         const int rl = it * RPI + lane / LPR;
-        const int row = m0 + wm * 64 + rl;
+        const int row = m0 + wm * 64 + q * RR + rl;
         float4 v = *reinterpret_cast<const float4*>(ct + rl * WN_COLS + c4);
         if (row >= M || col >= N) continue;
         v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
@@ -514,6 +524,8 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
             }
         }
     }
+    __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next round
+    }
 }
 
 // A, W: 16-bit operands (NPL planes each, plane strides in elements); Cf f32 (ACCUM / OUTF32), C16 16-bit out.
@@ -547,6 +559,23 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
                                  (flags & G16_OUT16 ? 2 * NPL : 0)),
                        st);
         static const int nwn = [] { const char* e = getenv("GENIE_GEMM16_NWN"); return e ? atoi(e) : 4; }();
+        static const int big = [] { const char* e = getenv("GENIE_GEMM16_BN256"); return e ? atoi(e) : 1; }();
+        const long tiles_256 = (long)mt2 * ((N + 255) / 256) * batch;
+        if constexpr (NPL == 1) {
+            if (big && N % 4 == 0 && tiles_256 >= 224) {
+                // bf16 only (one accumulator set): 256x256 tiles, BK = 32, 3 x 32 KB stages -- a third of the LDS-DMA
+                // bytes and two thirds of the fragment reads per MFMA of the 256x128 tile, 16 MFMAs per barrier
+                const int nt4 = (N + 255) / 256;
+                const size_t lds4 = 3 * 32 * 1024;
+                (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<1, 32, 4, 256>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                gemm16_v2_kernel<1, 32, 4, 256><<<dim3(mt2 * nt4, batch), 1024, lds4, st>>>(
+                    A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,
+                    strideW);
+                GENIE_LAUNCH_CHECK("gemm16_v2_256");
+                return GENIE_OK;
+            }
+        }
         if (nwn == 4) {
             (void)hipFuncSetAttribute((const void*)gemm16_v2_kernel<NPL, BK, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
