@@ -111,7 +111,7 @@ int launch_gemm_f32_gen(bool ta, bool tb, const float* A, long lda, long sA1, lo
 int launch_slab_reduce(const float* part, int ns, size_t n, float* out, float beta, hipStream_t st);
 int launch_wgrad_f32(const float* dY, long ldy, const float* X, long ldx, float* dW, int Mtok, int N, int K, float alpha,
                      float beta, float* slabs, size_t slab_floats, hipStream_t st);
-constexpr int COLSUM_SCRATCH_ROWS = 256;
+constexpr int COLSUM_CHUNKS = 256;  // row chunks of the two-stage column sums (= slabs of their scratch)
 int launch_colsum(const float* Y, long ld, long rows, int N, float* out, float beta, float* part, hipStream_t st);
 size_t ln_bwd_scratch_floats(int C);
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dxout, float* dgamma, float* dbeta,
@@ -139,7 +139,6 @@ int launch_sumsq(const float* x, size_t n, double* out, double* scratch, hipStre
 int launch_cast_transpose16(int npl, float* in, long ld, const float* z, uint16_t* out16, uint16_t* out16T, int rows,
                             int cols, hipStream_t st, float* colpart = nullptr);
 int launch_transpose16(int npl, const uint16_t* in, uint16_t* outT, int rows, int cols, hipStream_t st);
-int launch_gelu_fwd16(int npl, const float* z, uint16_t* h16, size_t n, hipStream_t st);
 int launch_cast16(int npl, const float* src, uint16_t* dst, size_t n, hipStream_t st);
 enum { G16X_GELU = 1, G16X_ACCUM = 2, G16X_OUT16 = 4, G16X_OUTF32 = 8, G16X_GELU16 = 16 };  // = the G16_* flags of kernels_bf16.hip
 int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,

@@ -265,7 +265,6 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     constexpr int WN_COLS = BN / NWN;                       // columns per wave
     constexpr int NCH = STAGE_B / 1024;                     // 1 KB chunks per stage (48)
     constexpr int CPW = NCH / NW;                           // per wave (6 or 3)
-    constexpr int CHUNK_ROWS = 1024 / ROWB;
     // epilogue transposition: the ring holds EROUNDS-th of every wave's 64 x WN_COLS accumulator tile at a time
     constexpr int EROUNDS = (NW * 64 * WN_COLS * 4 + NST * STAGE_B - 1) / (NST * STAGE_B) <= 1 ? 1 : 4;
     constexpr int RR = 64 / EROUNDS;                        // rows of the wave tile per round

@@ -241,7 +241,6 @@ __global__ void colsum_where_partial_kernel(const float* __restrict__ Y, long ld
         if (ids[r] == key) s += Y[(size_t)r * ld + c];
     part[(size_t)blockIdx.y * N + c] = s;
 }
-constexpr int COLSUM_CHUNKS = 256;
 int launch_colsum_where(const float* Y, long ld, long rows, int N, const int64_t* ids, int64_t key, float* out, float beta,
                         float* part, hipStream_t st) {
     if (rows <= 0 || N <= 0) return GENIE_OK;

@@ -89,16 +89,6 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
     }
 }
 
-template <int NPL>
-__global__ void gelu_fwd16_kernel(const float* __restrict__ z, uint16_t* __restrict__ h16, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint16_t hi, lo;
-    to16<NPL>(gelu_erf(z[i]), hi, lo);
-    h16[i] = hi;
-    if constexpr (NPL == 2) h16[n + i] = lo;
-}
-
 static int check64(int rows, int cols, const char* what) {
     GENIE_CHECK_SHAPE(rows % 64 == 0 && cols % 64 == 0, "%s: rows=%d and cols=%d must be multiples of 64", what, rows, cols);
     return GENIE_OK;
@@ -129,13 +119,6 @@ int launch_transpose16(int npl, const uint16_t* in, uint16_t* outT, int rows, in
     if (npl == 1) transpose16_kernel<1><<<grid, 256, 0, st>>>(in, outT, rows, cols);
     else transpose16_kernel<2><<<grid, 256, 0, st>>>(in, outT, rows, cols);
     GENIE_LAUNCH_CHECK("transpose16");
-    return GENIE_OK;
-}
-int launch_gelu_fwd16(int npl, const float* z, uint16_t* h16, size_t n, hipStream_t st) {
-    if (!n) return GENIE_OK;
-    if (npl == 1) gelu_fwd16_kernel<1><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(z, h16, n);
-    else gelu_fwd16_kernel<2><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(z, h16, n);
-    GENIE_LAUNCH_CHECK("gelu_fwd16");
     return GENIE_OK;
 }
 // f32 -> 16-bit planes, same orientation

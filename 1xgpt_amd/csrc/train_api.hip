@@ -59,7 +59,7 @@ static TrainWs train_ws(const genie_cfg& c, int B, void* base) {
     const size_t o_dx = take(M * d), o_d1 = take(M * d), o_g = take(M * wide), o_p = take(scores), o_dp = take(scores);
     w.slab_floats = 64 * maxw;
     const size_t o_sl = take(w.slab_floats), o_ln = take(ln_bwd_scratch_floats((int)d));
-    const size_t cp_rows = M / 64 > (size_t)COLSUM_SCRATCH_ROWS ? M / 64 : (size_t)COLSUM_SCRATCH_ROWS;
+    const size_t cp_rows = M / 64 > (size_t)COLSUM_CHUNKS ? M / 64 : (size_t)COLSUM_CHUNKS;
     const size_t o_cp = take(cp_rows * maxn), o_ds = take(2 * 1024);
     const size_t o_qkn = take(c.qk_norm ? M * 2 * d : 0);
     w.total = o;
