@@ -597,6 +597,18 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
                    2.0 * NPL * ((double)M * K * batch + (double)N * K) +
                        mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) + (flags & G16_OUT16 ? 2 * NPL : 0)),
                    st);
+    // Problems this small (batch-1 generate: a GEMM is 21..36 us) are bound by the serial chain of K-steps -- each one a
+    // barrier plus an L2 round trip -- not by throughput, and fewer workgroups than CUs are resident anyway: double the
+    // K-step (128 KB of LDS, one workgroup per CU) to halve the chain.
+    static const int wide_k = [] { const char* e = getenv("GENIE_GEMM16_WIDEK"); return e ? atoi(e) : 1; }();
+    if (wide_k && mt * nt * batch <= 256 && K % (2 * BK) == 0) {
+        (void)hipFuncSetAttribute((const void*)gemm16_nt_kernel<NPL, 2 * BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(2 * lds));
+        gemm16_nt_kernel<NPL, 2 * BK><<<dim3(mt * nt, batch), 256, 2 * lds, st>>>(
+            A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW);
+        GENIE_LAUNCH_CHECK("gemm16_widek");
+        return GENIE_OK;
+    }
     (void)hipFuncSetAttribute((const void*)gemm16_nt_kernel<NPL, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     gemm16_nt_kernel<NPL, BK><<<dim3(mt * nt, batch), 256, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,
