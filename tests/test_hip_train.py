@@ -209,3 +209,37 @@ def test_overfitting_one_batch_reduces_the_loss(golden, precision):
     # the module's inference entry point sees the trained weights (shared flat buffer + refreshed 16-bit copies)
     out = tr.model(batch["input_ids"], batch["labels"])
     assert abs(float(out.loss) - last) < 0.5
+
+
+def test_train_cli_on_a_dataset_directory(tmp_path):
+    """tools/train.py end to end on the on-disk dataset layout (video.bin / segment_ids.bin / metadata.json, a GenieConfig
+    json): windows -> collator -> updates -> eval -> `save_pretrained`; the checkpoint reloads through `from_pretrained`."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    data, cfgm = pkg("data"), pkg("config")
+    g = np.random.default_rng(0)
+    for split in ("train", "val"):
+        data.write_token_dataset(tmp_path / split, g.integers(0, 262144, (60, 4, 4)), np.zeros(60, np.int32), hz=30)
+    cfg = cfgm.GenieConfig(num_layers=1, num_heads=2, d_model=64, T=4, S=16, num_factored_vocabs=2, qk_norm=False,
+                           num_prompt_frames=2)
+    cfg.save_pretrained(tmp_path / "cfg.json")
+    out = tmp_path / "out"
+    cmd = [sys.executable, f"{REPO}/tools/train.py", "--genie_config", str(tmp_path / "cfg.json"), "--train_data_dir",
+           str(tmp_path / "train"), "--val_data_dir", str(tmp_path / "val"), "--window_size", "4", "--stride", "2",
+           "--output_dir", str(out), "--per_device_train_batch_size", "4", "--per_device_eval_batch_size", "4",
+           "--max_train_steps", "3", "--eval_every_n_steps", "3", "--gradient_accumulation_steps", "2", "--seed", "1",
+           "--precision", "exact", "--lr_scheduler_type", "custom_cosine", "--num_warmup_steps", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "step 3: train_loss" in res.stdout and "eval_loss" in res.stdout
+    ckpt = out / "final_checkpt"
+    assert json.load(open(ckpt / "config.json"))["d_model"] == 64
+    model = pkg("st_mask_git").STMaskGIT.from_pretrained(str(ckpt)).to("cuda")
+    ds = data.RawTokenDataset(tmp_path / "val", window_size=4, stride=2, filter_overlaps=True)
+    ids = ds.batch(range(2)).cuda()
+    x = ids.clone().view(2, 4, 16)
+    x[:, 2:] = cfg.image_vocab_size
+    loss = float(model(x.view(2, -1), ids).loss)
+    assert np.isfinite(loss) and 10.0 < loss < 15.0
