@@ -792,6 +792,8 @@ int launch_attn_temporal_bwd(const float* qkv, const float* qk, long qk_ld, cons
 // waves per (b, t, head); K and V of the head stay in LDS (2 x 68 KB at head_dim 64, rows padded to DH+4 floats so
 // the k-permuted ds_read_b128 fragments are conflict-free), queries are streamed in blocks of 32 rows.  Wave w owns
 // keys [64w, 64w+64).  Per query block, on v_mfma_f32_32x32x2_f32:
+//   [two passes over the query blocks -- pass A: T layout, statistics and dQ; pass B: N layout, dK and dV -- so that only
+//   one layout's tiles are live at a time (the single-pass form needed all 512 registers and spilled)]
 //   S = scale Q K^T and dP = dO V^T in BOTH register layouts (the same operand fragments, swapped): T-layout = one
 //     query row per lane (softmax statistics: in-lane + one cross-half shuffle + a 3-value exchange between the 4 waves,
 //     combined like an online softmax), N-layout = one key column per lane;
@@ -818,9 +820,9 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
     float* sPM = sdO + IB * LD;  // per-wave partial statistics [4][32]
     float* sPL = sPM + 128;
     float* sPD = sPL + 128;
-    float* fM = sPD + 128;       // final row max / 1/sum / D  [32]
-    float* fI = fM + 32;
-    float* fD = fI + 32;
+    float* stM = sPD + 128;      // final row max (log2 units) / 1/sum / D for all 256 query rows (pass A -> pass B)
+    float* stI = stM + S;
+    float* stD = stI + S;
     float* red = sQ;             // dQ reduction buffer [4][16][DH], aliases sQ | sdO
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -849,30 +851,26 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
             pd[p] = *reinterpret_cast<const float4*>(ob + (size_t)(ib * IB + row) * d + c4);
         }
     };
-    fetch(0);
-    f32x16 dk[2][NF], dv[2][NF];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int ft = 0; ft < NF; ++ft)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { dk[jt][ft][e] = 0.f; dv[jt][ft][e] = 0.f; }
-
-    for (int ib = 0; ib < S / IB; ++ib) {
+    auto publish = [&]() {  // prefetched Q_i, dO_i -> LDS
 #pragma unroll
         for (int p = 0; p < NPF; ++p) {
             const int idx = tid + 256 * p, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
             *reinterpret_cast<float4*>(&sQ[row * LD + c4]) = pq[p];
             *reinterpret_cast<float4*>(&sdO[row * LD + c4]) = pd[p];
         }
-        __syncthreads();  // (A) Q_i, dO_i (and K, V on the first pass) are in LDS
-        if (ib + 1 < S / IB) fetch(ib + 1);
+    };
 
-        f32x16 sT[2], sN[2], pT[2], pN[2];
+    // ================= pass A: T layout (one query row per lane): row statistics and dQ =================
+    fetch(0);
+    for (int ib = 0; ib < S / IB; ++ib) {
+        publish();
+        __syncthreads();  // Q_i, dO_i (and K, V on the first pass) are in LDS
+        fetch(ib + 1 < S / IB ? ib + 1 : 0);  // next block; after the last one: block 0 again for pass B
+        f32x16 sT[2], pT[2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sT[jt][e] = 0.f; sN[jt][e] = 0.f; pT[jt][e] = 0.f; pN[jt][e] = 0.f; }
+            for (int e = 0; e < 16; ++e) { sT[jt][e] = 0.f; pT[jt][e] = 0.f; }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
             const int jrow = w * 64 + jt * 32 + c;
@@ -882,16 +880,14 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
                 const float4 vf = *reinterpret_cast<const float4*>(&sV[jrow * LD + kk * 8 + 4 * h]);
                 const float4 qf = *reinterpret_cast<const float4*>(&sQ[c * LD + kk * 8 + 4 * h]);
                 const float4 of = *reinterpret_cast<const float4*>(&sdO[c * LD + kk * 8 + 4 * h]);
-#define SP_STEP(X)                                                                        \
-    sT[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.X, qf.X, sT[jt], 0, 0, 0);           \
-    sN[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.X, kf.X, sN[jt], 0, 0, 0);           \
-    pT[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.X, of.X, pT[jt], 0, 0, 0);           \
-    pN[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of.X, vf.X, pN[jt], 0, 0, 0);
+#define SP_STEP(X)                                                              \
+    sT[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.X, qf.X, sT[jt], 0, 0, 0); \
+    pT[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.X, of.X, pT[jt], 0, 0, 0);
                 SP_STEP(x) SP_STEP(y) SP_STEP(z) SP_STEP(w)
 #undef SP_STEP
             }
         }
-        // ---- T layout: lane (c, h) holds S[i = c][j = 64w + 32jt + rowmap(e, h)]: statistics of row c over this wave's keys
+        // lane (c, h) holds S[i = c][j = 64w + 32jt + rowmap(e, h)]: statistics of row c over this wave's keys
         float m = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -911,7 +907,7 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
         l += __shfl_xor(l, 32);
         ds += __shfl_xor(ds, 32);
         if (h == 0) { sPM[w * 32 + c] = m; sPL[w * 32 + c] = l; sPD[w * 32 + c] = ds; }
-        __syncthreads();  // (B)
+        __syncthreads();
         float gm = sPM[c];
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) gm = fmaxf(gm, sPM[ww * 32 + c]);
@@ -923,29 +919,13 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
             gd += sPD[ww * 32 + c] * f;
         }
         const float inv = 1.0f / gl, Di = gd * inv;
-        if (w == 0 && h == 0) { fM[c] = gm; fI[c] = inv; fD[c] = Di; }
+        if (w == 0 && h == 0) { stM[ib * IB + c] = gm; stI[ib * IB + c] = inv; stD[ib * IB + c] = Di; }
         const float corr = __builtin_amdgcn_exp2f(m - gm) * inv;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = sT[jt][e] * corr;
-                sT[jt][e] = p * (pT[jt][e] - Di);  // dS, T layout
-            }
-        __syncthreads();  // (C) final statistics published
-        // ---- N layout: lane (c, h) holds X[i = rowmap(e, h)][j = 64w + 32jt + c]
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = rowmap32(e, h);
-            const float mi = fM[i], ii = fI[i], di = fD[i];
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sN[jt][e], scale_l2, -mi)) * ii;
-                sN[jt][e] = p;                        // P, N layout
-                pN[jt][e] = p * (pN[jt][e] - di);     // dS, N layout
-            }
-        }
-        // ---- dQ (partial over this wave's keys), dK, dV
+            for (int e = 0; e < 16; ++e) sT[jt][e] = sT[jt][e] * corr * (pT[jt][e] - Di);  // dS
+        // dQ partial over this wave's 64 keys: A = dS (row c, contraction index = key rowmap(e, h))
         f32x16 dq[NF];
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft)
@@ -955,18 +935,12 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rr = rowmap32(e, h);
-                const float* kr = &sK[(w * 64 + jt * 32 + rr) * LD + c];
-                const float* qr = &sQ[rr * LD + c];
-                const float* orow = &sdO[rr * LD + c];
+                const float* kr = &sK[(w * 64 + jt * 32 + rowmap32(e, h)) * LD + c];
 #pragma unroll
-                for (int ft = 0; ft < NF; ++ft) {
+                for (int ft = 0; ft < NF; ++ft)
                     dq[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(sT[jt][e], kr[32 * ft], dq[ft], 0, 0, 0);
-                    dk[jt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(pN[jt][e], qr[32 * ft], dk[jt][ft], 0, 0, 0);
-                    dv[jt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(sN[jt][e], orow[32 * ft], dv[jt][ft], 0, 0, 0);
-                }
             }
-        __syncthreads();  // (D) every wave is done with sQ / sdO and the statistics
+        __syncthreads();  // every wave is done with sQ / sdO and the partial statistics
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
 #pragma unroll
@@ -991,6 +965,67 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_bwd_fused_kernel(const fl
             __syncthreads();
         }
     }
+
+    // ================= pass B: N layout (one key column per lane): dK and dV =================
+    f32x16 dk[2][NF], dv[2][NF];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dk[jt][ft][e] = 0.f; dv[jt][ft][e] = 0.f; }
+    for (int ib = 0; ib < S / IB; ++ib) {
+        publish();
+        __syncthreads();
+        if (ib + 1 < S / IB) fetch(ib + 1);
+        f32x16 sN[2], pN[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sN[jt][e] = 0.f; pN[jt][e] = 0.f; }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int jrow = w * 64 + jt * 32 + c;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const float4 kf = *reinterpret_cast<const float4*>(&sK[jrow * LD + kk * 8 + 4 * h]);
+                const float4 vf = *reinterpret_cast<const float4*>(&sV[jrow * LD + kk * 8 + 4 * h]);
+                const float4 qf = *reinterpret_cast<const float4*>(&sQ[c * LD + kk * 8 + 4 * h]);
+                const float4 of = *reinterpret_cast<const float4*>(&sdO[c * LD + kk * 8 + 4 * h]);
+#define SP_STEP(X)                                                              \
+    sN[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.X, kf.X, sN[jt], 0, 0, 0); \
+    pN[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of.X, vf.X, pN[jt], 0, 0, 0);
+                SP_STEP(x) SP_STEP(y) SP_STEP(z) SP_STEP(w)
+#undef SP_STEP
+            }
+        }
+        // lane (c, h) holds X[i = rowmap(e, h)][j = 64w + 32jt + c]; the statistics of row i were published by pass A
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = ib * IB + rowmap32(e, h);
+            const float mi = stM[i], ii = stI[i], di = stD[i];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sN[jt][e], scale_l2, -mi)) * ii;
+                sN[jt][e] = p;                        // P
+                pN[jt][e] = p * (pN[jt][e] - di);     // dS
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = rowmap32(e, h);
+                const float* qr = &sQ[rr * LD + c];
+                const float* orow = &sdO[rr * LD + c];
+#pragma unroll
+                for (int ft = 0; ft < NF; ++ft) {
+                    dk[jt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(pN[jt][e], qr[32 * ft], dk[jt][ft], 0, 0, 0);
+                    dv[jt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(sN[jt][e], orow[32 * ft], dv[jt][ft], 0, 0, 0);
+                }
+            }
+        __syncthreads();  // sQ / sdO are rewritten by the next block
+    }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -1008,7 +1043,7 @@ int launch_attn_spatial_bwd_fused(const float* qkv, const float* qk, long qk_ld,
                                   int d, int H, int Dh, float scale, hipStream_t st) {
     if (S != 256 || (Dh != 64 && Dh != 32)) return GENIE_E_UNSUPPORTED;
     if (n_bt <= 0) return GENIE_OK;
-    const size_t lds = (size_t)((2 * 256 + 2 * 32) * (Dh + 4) + 15 * 32) * sizeof(float);
+    const size_t lds = (size_t)((2 * 256 + 2 * 32) * (Dh + 4) + 12 * 32 + 3 * 256) * sizeof(float);
     ProfScope prof(GENIE_KC_ATTN_SPATIAL, 14.0 * S * S * Dh * (double)n_bt * H, 4.0 * 10 * S * Dh * (double)n_bt * H, st);
     if (Dh == 64) {
         (void)hipFuncSetAttribute((const void*)attn_spatial_bwd_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
