@@ -343,3 +343,28 @@ class GenieTrainer:
     def gradients(self):
         """{state-dict name: gradient view} (shapes of the parameters)."""
         return self.g_views
+
+    # ------------------------------------------------------------------ optimizer checkpoint (train.py:560-590 resume)
+    def state_dict(self):
+        """Optimizer state in torch.optim.AdamW's vocabulary, keyed by parameter NAME (the model's own weights are
+        saved by `model.save_pretrained` / `state_dict`)."""
+        named = dict(self.model.named_parameters())
+        st = {}
+        for n in self.order:
+            lo, hi = self.offsets[n]
+            st[n] = {"exp_avg": self.exp_avg[lo:hi].view(named[n].shape).clone(),
+                     "exp_avg_sq": self.exp_avg_sq[lo:hi].view(named[n].shape).clone()}
+        return {"state": st, "completed_steps": self.completed_steps, "micro_step": self._micro,
+                "hyper": {"lr": self.base_lr, "betas": tuple(self.betas), "eps": self.eps,
+                          "weight_decay": self.weight_decay, "max_grad_norm": self.max_grad_norm,
+                          "gradient_accumulation_steps": self.accum}}
+
+    def load_state_dict(self, sd):
+        """Inverse of `state_dict` (moments, step counters); hyper-parameters stay those of this trainer."""
+        for n in self.order:
+            lo, hi = self.offsets[n]
+            self.exp_avg[lo:hi].copy_(sd["state"][n]["exp_avg"].reshape(-1))
+            self.exp_avg_sq[lo:hi].copy_(sd["state"][n]["exp_avg_sq"].reshape(-1))
+        self.completed_steps = int(sd["completed_steps"])
+        self._micro = int(sd.get("micro_step", 0))
+        self.pack_weights()

@@ -124,12 +124,15 @@ def test_real_geometry_vs_reference_samples(golden, precision):
 @pytest.mark.parametrize("H,d,B,qk_norm,T", [(4, 128, 3, False, 4), (2, 64, 1, False, 4), (2, 128, 2, True, 4),
                                               (4, 128, 1, True, 4), (4, 128, 2, False, 16), (2, 128, 1, True, 16),
                                               (4, 256, 2, False, 4), (8, 512, 1, False, 4)])
-def test_gradients_vs_oracle(H, d, B, qk_norm, T):
+@pytest.mark.parametrize("use_mup", [False, True])
+def test_gradients_vs_oracle(H, d, B, qk_norm, T, use_mup):
     """Other widths / head sizes (Dh = 32, 64), an odd batch, T = 16 (the MFMA temporal kernels, forward and backward,
     with and without qk-norm) and the shipped widths d = 256 / 512 (their bandwidth-tuned LayerNorm forward / backward
     kernels) against the NumPy restatement."""
+    if use_mup and (B != 1 or T != 4):
+        pytest.skip("muP scaling (attention scale 8/Dh, readout multiplier 256/d) is covered on the single-clip cases")
     cfg = pkg("config").GenieConfig(num_layers=2, num_heads=H, d_model=d, T=T, S=16, num_factored_vocabs=2,
-                                    qk_norm=qk_norm, num_prompt_frames=2)
+                                    qk_norm=qk_norm, num_prompt_frames=2, use_mup=use_mup)
     syn = pkg("synthetic")
     sd = syn.make_state_dict(cfg, seed=77 + H, law="conditioned")
     ids = syn.make_clips(B, cfg, seed=900 + d)
@@ -243,3 +246,24 @@ def test_train_cli_on_a_dataset_directory(tmp_path):
     x[:, 2:] = cfg.image_vocab_size
     loss = float(model(x.view(2, -1), ids).loss)
     assert np.isfinite(loss) and 10.0 < loss < 15.0
+
+
+def test_optimizer_state_round_trip(golden):
+    """trainer.state_dict() / load_state_dict(): a resumed trainer takes bit-identical steps."""
+    z, cfg, sd = golden("train_tiny_ln")
+    batch = {"input_ids": dev(z["s0_input_ids"]), "labels": dev(z["s0_labels"])}
+    a = make_trainer(cfg, sd, lr=1e-3, weight_decay=0.1)
+    a.train_step(batch)
+    a.train_step(batch)
+    ck_model = {k: v.clone() for k, v in a.model.state_dict().items()}
+    ck_opt = a.state_dict()
+    ref = a.train_step(batch)
+    want = {k: v.clone() for k, v in a.model.state_dict().items()}
+    model_b = pkg("st_mask_git").STMaskGIT(cfg, precision="exact").to("cuda")
+    model_b.load_state_dict(ck_model)
+    b = pkg("train").GenieTrainer(model_b, lr=1e-3, weight_decay=0.1)
+    b.load_state_dict(ck_opt)
+    got = b.train_step(batch)
+    assert float(got["loss"]) == float(ref["loss"]) and b.completed_steps == a.completed_steps == 3
+    for k, v in b.model.state_dict().items():
+        assert torch.equal(v, want[k]), k
