@@ -239,6 +239,13 @@ def test_train_cli_on_a_dataset_directory(tmp_path):
     assert "step 3: train_loss" in res.stdout and "eval_loss" in res.stdout
     ckpt = out / "final_checkpt"
     assert json.load(open(ckpt / "config.json"))["d_model"] == 64
+    # resume: two more updates from the saved weights + optimizer state
+    cmd2 = [a for a in cmd]
+    cmd2[cmd2.index("--max_train_steps") + 1] = "5"
+    cmd2[cmd2.index("--output_dir") + 1] = str(tmp_path / "out2")
+    res2 = subprocess.run(cmd2 + ["--resume_from_checkpoint", str(ckpt)], capture_output=True, text=True, timeout=600)
+    assert res2.returncode == 0, res2.stdout[-2000:] + res2.stderr[-2000:]
+    assert "step 4: train_loss" in res2.stdout and "step 5: train_loss" in res2.stdout and "step 3:" not in res2.stdout
     model = pkg("st_mask_git").STMaskGIT.from_pretrained(str(ckpt)).to("cuda")
     ds = data.RawTokenDataset(tmp_path / "val", window_size=4, stride=2, filter_overlaps=True)
     ids = ds.batch(range(2)).cuda()

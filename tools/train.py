@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """CLI counterpart of the reference's `python train.py` (train.py:396-737) on the MI355X path: the same argument names for
 what is built (dataset windows, GenieConfig json, AdamW + decay grouping, linear / custom_cosine schedules, gradient
-accumulation, clipping, periodic teacher-forced eval and `save_pretrained` checkpoints).  Not built: accelerate/wandb
-logging, resume bookkeeping, torch.compile, the Llama baseline, MuAdamW (--mu_transfer).
+accumulation, clipping, periodic teacher-forced eval, `save_pretrained` checkpoints with the optimizer state, resume).
+Not built: accelerate/wandb logging, torch.compile, the Llama baseline, MuAdamW (--mu_transfer).
 
   python tools/train.py --genie_config genie/configs/magvit_n32_h8_d256.json --train_data_dir data/train_v1.1 \\
       --val_data_dir data/val_v1.1 --output_dir out --per_device_train_batch_size 8 --max_train_steps 1000
@@ -30,6 +30,8 @@ def parse_args():
     p.add_argument("--filter_overlaps", action="store_true")
     p.add_argument("--genie_config", type=str, help="GenieConfig json")
     p.add_argument("--warmstart_path", type=str, default=None)
+    p.add_argument("--resume_from_checkpoint", type=str, default=None,
+                   help="a step_N / final_checkpt directory written by this script (weights + trainer_state.pt)")
     p.add_argument("--output_dir", type=str, required=True)
     p.add_argument("--per_device_train_batch_size", type=int, default=4)
     p.add_argument("--per_device_eval_batch_size", type=int, default=4)
@@ -93,9 +95,10 @@ def main():
         cfg.__post_init__()
         get_train, get_eval, n_train, n_eval = tds.batch, eds.batch, len(tds), len(eds)
 
-    model = (STMaskGIT.from_pretrained(args.warmstart_path, precision=args.precision) if args.warmstart_path
+    load_from = args.resume_from_checkpoint or args.warmstart_path
+    model = (STMaskGIT.from_pretrained(load_from, precision=args.precision) if load_from
              else STMaskGIT(cfg, precision=args.precision))
-    if not args.warmstart_path:
+    if not load_from:
         model.init_weights()
     model = model.to(dev)
 
@@ -109,6 +112,8 @@ def main():
     tr = trainmod.GenieTrainer(model, lr=args.learning_rate, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps,
                                weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm,
                                gradient_accumulation_steps=accum, lr_lambda=lr_lambda)
+    if args.resume_from_checkpoint:  # optimizer moments, step counters (train.py:560-590)
+        tr.load_state_dict(torch.load(os.path.join(args.resume_from_checkpoint, "trainer_state.pt"), map_location=dev))
     n_params = sum(p.numel() for p in model.parameters())
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
@@ -130,12 +135,13 @@ def main():
         return (sums[0] / sums[2]).item(), (sums[1] / sums[2]).item()
 
     ckpt_every = int(args.checkpointing_steps) if args.checkpointing_steps.isdigit() else None
-    completed, t0 = 0, time.time()
+    completed, t0 = tr.completed_steps, time.time()
     loss_info = torch.zeros(2, dtype=torch.float64, device=dev)
-    for epoch in range(10 ** 9):
+    consumed = completed * accum  # micro-batches already trained on (resume): skip them in the data order
+    for epoch in range(consumed // micro_per_epoch, 10 ** 9):
         g = torch.Generator().manual_seed((args.seed or 0) + epoch)
         perm = torch.randperm(n_train, generator=g)  # same permutation on every rank; rank r takes its slice
-        for m in range(micro_per_epoch):
+        for m in range(consumed % micro_per_epoch if epoch == consumed // micro_per_epoch else 0, micro_per_epoch):
             idx = perm[(m * world + rank) * B:(m * world + rank + 1) * B].tolist()
             batch = datamod.maskgit_collate(get_train(idx).to(dev), cfg)
             out = tr.train_step(batch)
@@ -156,8 +162,9 @@ def main():
                 if rank == 0:
                     print(f"step {completed}: eval_loss {el:.4f} eval_teacher_acc {ea:.4f}", flush=True)
             if rank == 0 and ((ckpt_every and completed % ckpt_every == 0) or completed == max_steps):
-                model.save_pretrained(os.path.join(args.output_dir, "final_checkpt" if completed == max_steps
-                                                   else f"step_{completed}"))
+                ck = os.path.join(args.output_dir, "final_checkpt" if completed == max_steps else f"step_{completed}")
+                model.save_pretrained(ck)
+                torch.save(tr.state_dict(), os.path.join(ck, "trainer_state.pt"))
             if completed >= max_steps:
                 dist_mod.barrier()
                 return
