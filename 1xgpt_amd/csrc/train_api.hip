@@ -1,13 +1,15 @@
 // C ABI of the training step (include/genie_hip.h, "training" section): forward with saved activations, masked
 // factored CE, backward layer by layer (so the caller can overlap the gradient all-reduce of finished layers with
-// the backward of earlier ones), AdamW.  GENIE_PREC_EXACT only in this round: f32 storage, f32 MFMA contractions.
+// the backward of earlier ones), AdamW.  Two variants: GENIE_PREC_EXACT (this first part: f32 storage, every contraction on
+// the f32 matrix instruction) and the 16-bit matrix-core variant for GENIE_PREC_BF16 / _F16X3 further down.
 //
-// HBM layout of the saved activations (floats; M = B*T*S tokens, token-major rows):
+// HBM layout of the saved activations, exact variant (floats; M = B*T*S tokens, token-major rows):
 //   per layer l at l*per_layer:  x0 (M,d) layer input | u1 (M,d) norm1(x0) | qkv_s (M,3d) | ao_s (M,d) spatial attention
 //   output before proj | x1 (M,d) | qkv_t (M,3d) | ao_t (M,d) | x2 (M,d) | u2 (M,d) norm2(x2) | z (M,hid) fc1 pre-activation
 //   | h (M,hid) gelu(z);  after the layers: xL (M,d) | logits (M,V) (replaced in place by d loss / d logits)
 // 21*d floats per token and layer: 5.6 GB per clip for the C138 shape -- sized for 288 GB, nothing is recomputed
-// except the spatial softmax (materialised per layer in the workspace, never saved).
+// except the attention probabilities (rebuilt inside the fused attention backward kernels; for S != 256 the spatial scores are
+// materialised per layer in the workspace, never saved).
 #include "kernels.hpp"
 
 namespace genie {
