@@ -1,7 +1,9 @@
 // Kernels of the training step: what autograd derives for STMaskGIT.forward
-// (genie/st_mask_git.py:231-279) plus the optimizer of train.py:426-441, 628-633.  f32 throughout ("exact"
-// precision): every contraction runs on v_mfma_f32_32x32x2_f32 through ONE general GEMM that reads either operand
-// in either orientation, so no activation or weight is ever physically transposed for a backward product:
+// (genie/st_mask_git.py:231-279) plus the optimizer of train.py:426-441, 628-633.  Everything here is f32 and serves all
+// three precisions (LayerNorm / attention / loss / embedding backward, reductions, AdamW); the Linear products of the
+// "exact" precision run on v_mfma_f32_32x32x2_f32 through ONE general GEMM that reads either operand in either orientation,
+// so no activation or weight is ever physically transposed for a backward product (the 16-bit precisions take the NT GEMM
+// of kernels_bf16.hip with the operand copies of kernels_train16.hip instead):
 //     forward   Y  = X . W^T          A = X  [rows][k]      B = W  [cols][k]
 //     dgrad     dX = dY . W           A = dY [rows][k]      B = W  [k][cols]   (TB)
 //     wgrad     dW = dY^T . X         A = dY [k][rows] (TA) B = X  [k][cols]   (TB), split over the token axis
