@@ -532,7 +532,7 @@ template <int NPL>
 static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                          const float* bias, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,
                          int flags, float alpha, hipStream_t st, int batch = 1, long strideA = 0, long strideC = 0,
-                         const float* Rf = nullptr, long strideW = 0) {
+                         const float* Rf = nullptr, long strideW = 0, bool weights_on_w = true) {
     constexpr int BK = NPL == 1 ? 64 : 32;
     GENIE_CHECK_SHAPE(K % BK == 0 && K > 0, "gemm16: K=%d must be a positive multiple of %d", K, BK);
     GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
@@ -543,6 +543,18 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
         static const int nt_mode = [] { const char* e = getenv("GENIE_GEMM16_NT"); return e ? atoi(e) : -1; }();
         const double out_bytes = mn * ((flags & G16_OUTF32 ? 4 : 0) + (flags & G16_OUT16 ? 2 * NPL : 0));
         if (nt_mode == 1 || (nt_mode < 0 && out_bytes >= 192e6)) flags |= G16_NT;
+    }
+    {   // the 256x256 phase-scheduled kernel (kernels_gemm_pp.hip) takes every problem that fills the chip with its tiles.
+        // Its split-f16 form multiplies the W operand's hi plane by 2^11 in registers, so W must be a weight matrix
+        // (|w| < 32): the training step's activation-by-activation products keep the two-accumulator kernel below.
+        static const int pp = [] { const char* e = getenv("GENIE_GEMM16_PP"); return e ? atoi(e) : 1; }();
+        static const int terms = [] { const char* e = getenv("GENIE_F16_TERMS"); return e ? atoi(e) : 3; }();
+        if (pp && (NPL == 1 || weights_on_w)) {
+            const int npl = (NPL == 2 && terms == 1) ? 1 : NPL;
+            const int rc = launch_gemm16_pp(npl, terms, NPL == 2, A, lda, planeA, W, ldw, planeW, bias, Rf, Cf, C16, plane16,
+                                            ldc, M, N, K, flags, alpha, st, batch, strideA, strideW, strideC);
+            if (rc != GENIE_E_UNSUPPORTED) return rc;
+        }
     }
     static const int force_v1 = [] { const char* e = getenv("GENIE_GEMM16_V1"); return e ? atoi(e) : 0; }();
     // small problems (batch-1 generate: M = 4096 or 256 rows): 256x128 tiles would leave most of the 256 CUs idle, the
@@ -628,7 +640,7 @@ int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const ui
         return launch_gemm16<1>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, st,
                                 batch, strideA, strideC, Rf, strideW);
     return launch_gemm16<2>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, st, batch,
-                            strideA, strideC, Rf, strideW);
+                            strideA, strideC, Rf, strideW, /*weights_on_w=*/false);
 }
 
 // ---- elementwise helpers -----------------------------------------------------------------------

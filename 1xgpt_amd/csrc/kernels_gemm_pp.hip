@@ -1,0 +1,415 @@
+// gemm16_pp_kernel: the 16-bit NT GEMM of the GENIE forward, rebuilt around a two-group ("ping-pong") phase schedule.
+//
+//   C[M,N] (+)= epilogue( alpha * A[M,K] . W[N,K]^T + bias )      (nn.Linear; st_transformer.py:16-25, attention.py:27-29)
+//
+//   * 256x256 block tile, 8 waves = 2 (M) x 4 (N), wave tile 128x64 = 4x2 v_mfma_f32_32x32x16 tiles (128 accumulator
+//     registers), two waves per SIMD: waves 0-3 (group 0, rows 0-127) and waves 4-7 (group 1, rows 128-255).
+//   * A K-tile is 128 bytes of every row: 64 bf16/f16 values (NPL = 1) or 32 values x [hi | lo] f16 planes (NPL = 2).
+//     It lives in LDS as FOUR 16 KB half-tiles ordered by WHEN the waves read them, not by row:
+//        A-early = the first 64 rows of each group's 128,  A-late = the other 64,
+//        B-early = the first 32 columns of each wave's 64, B-late = the other 32.
+//     Two K-tiles (128 KB) are resident; the LDS image is lane-linear (LDS-DMA), the 16-byte slot of a row is XOR-swizzled
+//     with (row/2)%8 on the SOURCE address and on the fragment read: conflict-free ds_read_b128.
+//   * Every K-tile is 4 phases, one 64x32 quadrant of the wave tile each: (a0,c0) (a0,c1) (a1,c1) (a1,c0).  A phase is
+//        LOAD: fragment reads for the quadrant (12 / 4 / 8 / 0 ds_read_b128) + 2 LDS-DMA pieces (one half-tile per
+//              phase per workgroup) + a COUNTED s_waitcnt vmcnt   -> s_barrier ->
+//        MFMA: 8 (NPL = 1) or 12 (NPL = 2) matrix instructions   -> s_barrier
+//     Group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA part while the other is in its
+//     LOAD part: the matrix pipe sees back-to-back clusters, the LDS/DMA traffic of one wave hides under the other's.
+//   * Hazard rules used (interval = time between two workgroup barriers; group 0 runs LOAD(p) in interval 2p, group 1
+//     in 2p+1): a half-tile last read in LOAD(p) is re-staged in LOAD(p+2) or later; data waited for in LOAD(p) (vmcnt
+//     before the barrier, by every wave) is read in LOAD(p+1) or later.  Schedule per K-tile t:
+//        q0 stages B-late(t+1)   waits vmcnt(8) -> B-late(t) landed  (read in q1)
+//        q1 stages A-late(t+1)   waits vmcnt(8) -> A-late(t) landed  (read in q2)
+//        q2 stages A-early(t+2)  -
+//        q3 stages B-early(t+2)  waits vmcnt(8) -> A-early(t+1), B-early(t+1) landed (read in q0 of t+1)
+//     i.e. four half-tiles (8 loads per lane) stay in flight across every barrier.
+//   * NPL = 2 ("f16x3"): operands are split pairs a = hi + lo'/2048.  The three products run into ONE accumulator
+//     scaled by 2^11:  acc' += ah.(2048 bh) + ah.bl' + al'.bh  (2048 bh is a packed-f16 multiply on the B fragment in
+//     registers: exact for |w| < 32); the epilogue multiplies by alpha / 2048.  TERMS = 2 drops ah.bl' (weights rounded
+//     to f16), NPL = 1 with F16 reads only the hi plane (plain f16) -- both for the accuracy/speed study of DESIGN.md.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int PP_HT = 16384;    // bytes of one half-tile
+constexpr int PP_BUF = 65536;   // bytes of one K-tile (4 half-tiles: A-early, A-late, B-early, B-late)
+
+template <int N, bool SKIP = false>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (!SKIP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(const s16x8& a, const s16x8& b, const f32x16& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+}  // namespace
+
+// ABL: timing-only ablations for the study in DESIGN.md (results are wrong when ABL != 0): 1 no in-loop LDS-DMA,
+// 2 no in-loop fragment reads, 4 no vmcnt waits, 8 no output stores, 16 no matrix instructions
+template <int NPL, int TERMS, bool F16, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
+                                                            const uint16_t* __restrict__ W, long ldw, long planeW,
+                                                            const float* __restrict__ bias, float* __restrict__ Cf,
+                                                            uint16_t* __restrict__ C16, long plane16, long ldc, int M, int N,
+                                                            int K, int flags, float alpha, long strideA, long strideC,
+                                                            const float* Rf, long strideW) {
+    constexpr int KK = NPL == 1 ? 4 : 2;  // k16 steps per K-tile
+    constexpr int BK = 16 * KK;
+    constexpr int BM = 256, BN = 256;
+    constexpr int OFF_AE = 0, OFF_AL = PP_HT, OFF_BE = 2 * PP_HT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order: the 8 m-tiles of a group go to the 8 XCDs (block b runs on XCD b % 8) and each XCD walks
+    // the n-tiles of ITS m-tile, so an A row panel is fetched into one L2 only
+    const int mt = M / BM, nt_n = N / BN;
+    int bid = blockIdx.x, m_tile, n_tile;
+    const int full = (mt / 8) * 8 * nt_n;
+    if (bid < full) {
+        const int grp = bid / (8 * nt_n), rem = bid - grp * 8 * nt_n;
+        m_tile = grp * 8 + (rem & 7);
+        n_tile = rem >> 3;
+    } else {
+        const int rem = bid - full;
+        m_tile = (mt / 8) * 8 + rem / nt_n;
+        n_tile = rem % nt_n;
+    }
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    A += (size_t)blockIdx.y * strideA + (size_t)m0 * lda;
+    W += (size_t)blockIdx.y * strideW + (size_t)n0 * ldw;
+
+    // ---- staging: LDS-DMA through buffer descriptors (voffset per lane, K / late-half offset in the scalar offset)
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
+    unsigned voffA[2], voffB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rho = (wid * 2 + j) * 8 + (lane >> 3);          // row of the half-tile image this lane fills
+        const int s = (lane & 7) ^ ((rho >> 1) & 7);               // logical 16-byte slot that lands in physical slot lane&7
+        const unsigned ka = NPL == 1 ? s * 16 : (unsigned)((s >> 2) * planeA * 2 + (s & 3) * 16);
+        const unsigned kb = NPL == 1 ? s * 16 : (unsigned)((s >> 2) * planeW * 2 + (s & 3) * 16);
+        voffA[j] = (unsigned)(((rho >> 6) * 128 + (rho & 63)) * lda * 2) + ka;
+        voffB[j] = (unsigned)(((rho >> 5) * 64 + (rho & 31)) * ldw * 2) + kb;
+    }
+    const int lateA = (int)(64 * lda * 2), lateB = (int)(32 * ldw * 2);
+    bool in_loop = false;
+    auto stage = [&](int ht, int buf, int kt) {  // ht: 0 A-early, 1 A-late, 2 B-early, 3 B-late; all arguments wave-uniform
+        if constexpr (ABL & 1) { if (in_loop) return; }
+        const int soff = kt * BK * 2 + (ht == 1 ? lateA : ht == 3 ? lateB : 0);
+        unsigned char* dst = smem + buf * PP_BUF + ht * PP_HT + wid * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ht < 2 ? rsA : rsW, (__attribute__((address_space(3))) void*)(dst + j * 1024),
+                                                     16, ht < 2 ? voffA[j] : voffB[j], soff, 0, 0);
+    };
+
+    // ---- fragment read offsets: lane (r, h) reads 16-byte slot 2c + h of its row, c = plane * KK + k16 step
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned o = r * 128 + (((2 * c + h) ^ ((r >> 1) & 7)) << 4);
+        offA[c] = o + wm * 8192;            // rows wm*64 .. of A-early / A-late
+        offB[c] = o + wn * 4096 + OFF_BE;   // rows wn*32 .. of B-early / B-late
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    s16x8 fa[2][4];      // the current 64-row A sub-tile: [row tile][c]
+    s16x8 fb[2][4];      // both 32-column B sub-tiles:    [sub][c]
+    s16x8 fup[2][2];     // NPL = 2: 2048 * hi plane of the B sub-tiles [sub][kk]
+
+    auto read_a = [&](int buf, int late) {
+        if constexpr (ABL & 2) { if (in_loop) return; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                fa[i][c] = *reinterpret_cast<const s16x8*>(smem + buf * PP_BUF + (late ? OFF_AL : OFF_AE) + i * 4096 + offA[c]);
+    };
+    auto read_b = [&](int buf, int late) {
+        if constexpr (ABL & 2) { if (in_loop) return; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            fb[late][c] = *reinterpret_cast<const s16x8*>(smem + buf * PP_BUF + (late ? PP_HT : 0) + offB[c]);
+    };
+    auto scale_b = [&](int sub) {
+        if constexpr (NPL == 2) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                fup[sub][kk] = __builtin_bit_cast(s16x8, __builtin_bit_cast(f16x8, fb[sub][kk]) * (_Float16)2048.0f);
+        }
+    };
+    auto mma = [&](int asub, int csub) {
+        f32x16& c0 = acc[asub * 2][csub];
+        f32x16& c1 = acc[asub * 2 + 1][csub];
+        if constexpr (ABL & 16) {
+            asm volatile("" : "+v"(c0), "+v"(c1));
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            if constexpr (NPL == 1) {
+                c0 = mma16<F16>(fa[0][kk], fb[csub][kk], c0);
+                c1 = mma16<F16>(fa[1][kk], fb[csub][kk], c1);
+            } else {
+                c0 = mma16<true>(fa[0][kk], fup[csub][kk], c0);
+                c1 = mma16<true>(fa[1][kk], fup[csub][kk], c1);
+                if constexpr (TERMS == 3) {
+                    c0 = mma16<true>(fa[0][kk], fb[csub][KK + kk], c0);
+                    c1 = mma16<true>(fa[1][kk], fb[csub][KK + kk], c1);
+                }
+                c0 = mma16<true>(fa[0][KK + kk], fb[csub][kk], c0);
+                c1 = mma16<true>(fa[1][KK + kk], fb[csub][kk], c1);
+            }
+        }
+    };
+    // MODE 0: steady state, 1: second-to-last K-tile (stages for tile t+1 only), 2: last K-tile (stages nothing)
+    auto ktile = [&](auto bufc, auto modec, int t) {
+        constexpr int BUF = decltype(bufc)::value, MODE = decltype(modec)::value;
+        // q0: quadrant (a0, c0)
+        read_a(BUF, 0);
+        read_b(BUF, 0);
+        if constexpr (MODE < 2) stage(3, BUF ^ 1, t + 1);
+        if constexpr (MODE < 2) wait_vmcnt<8, (ABL & 4) != 0>(); else wait_vmcnt<2>();
+        wg_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        scale_b(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        wg_barrier();
+        // q1: quadrant (a0, c1)
+        read_b(BUF, 1);
+        if constexpr (MODE < 2) stage(1, BUF ^ 1, t + 1);
+        if constexpr (MODE < 2) wait_vmcnt<8, (ABL & 4) != 0>(); else wait_vmcnt<0>();
+        wg_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        scale_b(1);
+        __builtin_amdgcn_s_setprio(1);
+        mma(0, 1);
+        __builtin_amdgcn_s_setprio(0);
+        wg_barrier();
+        // q2: quadrant (a1, c1)
+        read_a(BUF, 1);
+        if constexpr (MODE == 0) stage(0, BUF, t + 2);
+        wg_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        wg_barrier();
+        // q3: quadrant (a1, c0)
+        if constexpr (MODE == 0) stage(2, BUF, t + 2);
+        if constexpr (MODE == 0) wait_vmcnt<8, (ABL & 4) != 0>();
+        if constexpr (MODE == 1) wait_vmcnt<4>();
+        wg_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        mma(1, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (MODE < 2 || wm == 0) wg_barrier();  // group 1 skips the very last barrier (it entered one barrier late)
+    };
+
+    const int nk = K / BK;  // even, >= 2 (launcher)
+    stage(0, 0, 0);
+    stage(2, 0, 0);
+    stage(3, 0, 0);
+    stage(1, 0, 0);
+    stage(0, 1, 1);
+    stage(2, 1, 1);
+    wait_vmcnt<8>();  // A-early(0), B-early(0) of this wave have landed
+    wg_barrier();
+    if (wm == 1) wg_barrier();  // group 1 runs one barrier behind group 0
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if constexpr (ABL & 2) {  // fragments are read once, here
+        wait_vmcnt<0>();
+        wg_barrier();
+        read_a(0, 0); read_b(0, 0); read_b(0, 1);
+        scale_b(0); scale_b(1);
+        wg_barrier();
+    }
+    in_loop = true;
+    for (int t = 0; t + 2 < nk; t += 2) {
+        ktile(I0{}, I0{}, t);
+        ktile(I1{}, I0{}, t + 1);
+    }
+    ktile(I0{}, I1{}, nk - 2);
+    ktile(I1{}, I2{}, nk - 1);
+
+    // ---- epilogue.  The accumulators hold one COLUMN per lane; each wave transposes its tile through its own 16 KB of
+    // the (now idle) ring, 64 rows at a time, and then works on whole rows: 16 lanes x float4 = one 256-byte row segment
+    // per quarter-wave for the residual read, the f32 store and the 16-bit operand store.
+    // (all LDS-DMA has landed and every fragment read has completed before any wave gets here: see the tail waits above)
+    if (Cf) Cf += (size_t)blockIdx.y * strideC;
+    if (C16) C16 += (size_t)blockIdx.y * strideC;
+    const float* Rsrc = Rf ? Rf + (size_t)blockIdx.y * strideC : Cf;
+    float* ct = reinterpret_cast<float*>(smem + wid * 16384);
+    const bool do_gelu = flags & G16X_GELU, do_acc = flags & G16X_ACCUM;
+    const bool out16 = flags & G16X_OUT16, outf = flags & G16X_OUTF32, nts = flags & G16X_NT;
+    const float ascale = NPL == 2 ? alpha * (1.0f / 2048.0f) : alpha;
+    const int c4 = (lane & 15) << 2;
+    const int col = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q * 2 + i][j][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rl = it * 4 + (lane >> 4);
+            const int row = m0 + wm * 128 + q * 64 + rl;
+            float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+            v.x = v.x * ascale + bv.x; v.y = v.y * ascale + bv.y; v.z = v.z * ascale + bv.z; v.w = v.w * ascale + bv.w;
+            if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+            const size_t idx = (size_t)row * ldc + col;
+            if (do_acc) {
+                const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if constexpr (ABL & 8) {
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                continue;
+            }
+            if (outf) {
+                if (nts) {
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    nt4 t = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(t, reinterpret_cast<nt4*>(Cf + idx));
+                } else {
+                    *reinterpret_cast<float4*>(Cf + idx) = v;
+                }
+            }
+            if (out16) {
+                if (flags & G16X_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                auto st2 = [&](uint16_t* p, uint32_t a, uint32_t b) {
+                    u2v t = {a, b};
+                    if (nts) __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(p));
+                    else *reinterpret_cast<u2v*>(p) = t;
+                };
+                if (plane16 == 0) {  // bf16 output
+                    st2(C16 + idx, (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
+                        (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16));
+                } else {             // split f16 planes [hi | lo]
+                    uint16_t h0, l0, h1, l1, h2, l2, h3, l3;
+                    split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3);
+                    st2(C16 + idx, (uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+                    st2(C16 + (size_t)plane16 + idx, (uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next round
+    }
+}
+
+// Returns GENIE_E_UNSUPPORTED when the problem does not fit this kernel's tiling (the caller falls back to the
+// gemm16_v2 / gemm16_nt kernels of kernels_bf16.hip).  npl = 1: bf16 operands (f16 = 0) or the hi plane of split
+// operands (f16 = 1); npl = 2: split-f16 operands, terms = 3 (f32-class) or 2.
+int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw,
+                     long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M,
+                     int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC) {
+    const int bk = npl == 1 ? 64 : 32;
+    if (M < 256 || M % 256 || N % 256 || K % (2 * bk) || K < 2 * bk) return GENIE_E_UNSUPPORTED;
+    if (lda % 8 || ldw % 8 || ldc % 4) return GENIE_E_UNSUPPORTED;
+    // 32-bit byte offsets inside one tile's buffer descriptor
+    if ((double)(npl - 1) * planeA * 2 + 256.0 * lda * 2 + 2.0 * K >= 4.0e9) return GENIE_E_UNSUPPORTED;
+    if ((double)(npl - 1) * planeW * 2 + 256.0 * ldw * 2 + 2.0 * K >= 4.0e9) return GENIE_E_UNSUPPORTED;
+    const long tiles = (long)(M / 256) * (N / 256) * batch;
+    static const long min_tiles = [] { const char* e = getenv("GENIE_GEMM16_PP_MIN_TILES"); return e ? atol(e) : 192L; }();
+    if (tiles < min_tiles) return GENIE_E_UNSUPPORTED;
+    const double mn = (double)M * N * batch;
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
+                   2.0 * npl * ((double)M * K * batch + (double)N * K) +
+                       mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) +
+                             (flags & G16X_OUT16 ? (plane16 ? 4 : 2) : 0)),
+                   st);
+    const dim3 grid((unsigned)((M / 256) * (N / 256)), (unsigned)batch);
+    constexpr size_t lds = 2 * PP_BUF;
+#define PP_LAUNCH(NPL_, TERMS_, F16_)                                                                                     \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, TERMS_, F16_>,                                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+        gemm16_pp_kernel<NPL_, TERMS_, F16_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,       \
+                                                                      plane16, ldc, M, N, K, flags, alpha, strideA,       \
+                                                                      strideC, Rf, strideW);                              \
+    } while (0)
+    static const int abl = [] { const char* e = getenv("GENIE_PP_ABL"); return e ? atoi(e) : 0; }();
+#define PP_LAUNCH_ABL(ABL_)                                                                                               \
+    do {                                                                                                                  \
+        if (npl == 1) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<1, 1, false, ABL_>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            gemm16_pp_kernel<1, 1, false, ABL_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,    \
+                                                                         plane16, ldc, M, N, K, flags, alpha, strideA,    \
+                                                                         strideC, Rf, strideW);                           \
+        } else {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<2, 3, true, ABL_>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            gemm16_pp_kernel<2, 3, true, ABL_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,     \
+                                                                        plane16, ldc, M, N, K, flags, alpha, strideA,     \
+                                                                        strideC, Rf, strideW);                            \
+        }                                                                                                                 \
+    } while (0)
+    if (abl == 1) PP_LAUNCH_ABL(1);
+    else if (abl == 2) PP_LAUNCH_ABL(2);
+    else if (abl == 3) PP_LAUNCH_ABL(3);
+    else if (abl == 4) PP_LAUNCH_ABL(4);
+    else if (abl == 8) PP_LAUNCH_ABL(8);
+    else if (abl == 16) PP_LAUNCH_ABL(16);
+    else if (abl == 19) PP_LAUNCH_ABL(19);
+    else if (abl == 11) PP_LAUNCH_ABL(11);
+    else if (npl == 1 && !f16) PP_LAUNCH(1, 1, false);
+    else if (npl == 1) PP_LAUNCH(1, 1, true);
+    else if (terms == 2) PP_LAUNCH(2, 2, true);
+    else PP_LAUNCH(2, 3, true);
+#undef PP_LAUNCH
+#undef PP_LAUNCH_ABL
+    GENIE_LAUNCH_CHECK("gemm16_pp");
+    return GENIE_OK;
+}
+
+}  // namespace genie

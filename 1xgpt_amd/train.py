@@ -195,6 +195,11 @@ class GenieTrainer:
                 view = self.params[lo:hi].view(named[n].shape)
                 view.copy_(named[n].data)
                 named[n].data = view  # the module now reads (and checkpoints) the flat buffer
+        # every replica starts from rank 0's parameters, as DistributedDataParallel does when it wraps the module
+        # (the reference relies on that broadcast: train.py:441 `accelerator.prepare`); the trainer itself only
+        # all-reduces gradients, so replicas that start apart would stay apart
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.params, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         model.refresh_weights()
         self.p_views = {n: self.params[offs[n][0]:offs[n][1]] for n in self.order}
         self.g_views = {n: self.grads[offs[n][0]:offs[n][1]].view(named[n].shape) for n in self.order}
@@ -239,10 +244,18 @@ class GenieTrainer:
         self._B = 0
 
     def pack_weights(self):
-        """Refresh the 16-bit weight copies from the f32 parameters (no-op in the exact precision)."""
+        """Refresh the 16-bit weight copies from the f32 parameters (no-op in the exact precision).  Call this (or
+        `sync_external_weights`) after ANY weight mutation the trainer did not make itself -- `model.load_state_dict`,
+        `load_numpy_state_dict` -- or the 16-bit GEMM operands keep the old weights until the next optimizer step."""
         if self.precision != "exact":
             _lib.check(self.lib.genie_train_pack_weights(self.cfg, self.w_table, self.w_table, self.wT_table,
                                                          self._stream()), "genie_train_pack_weights")
+
+    def sync_external_weights(self):
+        """After the caller changed the model's parameters in place (they are views of the flat buffer): repack the
+        16-bit operand copies here and the inference-side copies of the module."""
+        self.pack_weights()
+        self.model.refresh_weights()
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, B):
@@ -360,7 +373,16 @@ class GenieTrainer:
                           "gradient_accumulation_steps": self.accum}}
 
     def load_state_dict(self, sd):
-        """Inverse of `state_dict` (moments, step counters); hyper-parameters stay those of this trainer."""
+        """Inverse of `state_dict` (moments, step counters); hyper-parameters stay those of this trainer (a warning
+        names every saved value that differs)."""
+        mine = {"lr": self.base_lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                "max_grad_norm": self.max_grad_norm, "gradient_accumulation_steps": self.accum}
+        diff = {k: (v, mine[k]) for k, v in (sd.get("hyper") or {}).items()
+                if k in mine and (tuple(v) if isinstance(v, (list, tuple)) else v) != mine[k]}
+        if diff:
+            import warnings
+            warnings.warn("GenieTrainer.load_state_dict: resuming with different hyper-parameters (saved, current): "
+                          + ", ".join(f"{k}={a}->{b}" for k, (a, b) in diff.items()))
         for n in self.order:
             lo, hi = self.offsets[n]
             self.exp_avg[lo:hi].copy_(sd["state"][n]["exp_avg"].reshape(-1))

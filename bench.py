@@ -112,6 +112,30 @@ def train_leg(cfg, dev, dist_mod, rank, world, precision, batch, steps):
     return res
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1) as a CHILD process -- this process has not touched the GPU -- and
+    exit with its code.  Rank 0 of the child prints the JSON line."""
+    import subprocess
+    ndev = torch.cuda.device_count()  # does not initialise the GPU
+    if ndev < n and os.environ.get("GENIE_FORCE_DEVICE") is None:
+        sys.exit(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible (set GENIE_FORCE_DEVICE=<i> and "
+                 f"GENIE_DIST_BACKEND=gloo to run all ranks on one device as a plumbing check)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,9 +160,14 @@ def main():
                     help="do not bracket GEMM launches with HIP events (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)  # never returns
     dist_mod = importlib.import_module("1xgpt_amd.distributed")
     rank, world, local_rank = dist_mod.init_distributed()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: launcher started WORLD_SIZE={world} rank(s) but --gpus {args.gpus} was asked for")
+    if world > 1:  # what the collective backend itself reports, not the environment
+        assert torch.distributed.get_world_size() == args.gpus, (torch.distributed.get_world_size(), args.gpus)
     dev_index = dist_mod.local_device_index(local_rank)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -264,6 +293,8 @@ def main():
                    "executed_forward_passes_per_step_per_gpu": passes_per_step,
                    "reference_schedule_forward_passes_per_step_per_gpu": (cfg.T - 1) * args.maskgit_steps * B,
                    "prefix_reuse": reuse, "parallelism": f"dp{world}",
+                   "ranks_reported_by_backend": torch.distributed.get_world_size() if world > 1 else 1,
+                   "collective_backend": torch.distributed.get_backend() if world > 1 else "none",
                    "precision": args.precision, "weights": "synthetic PCG64 seed 0, 'conditioned' law"},
         "ce": m["loss"], "sampled_token_acc": m["acc"],
         "model_tflops_per_gpu": passes_per_step * F * args.steps / seconds / 1e12,

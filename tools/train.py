@@ -70,7 +70,7 @@ def main():
     torch.cuda.set_device(dev)
     if args.seed is not None:
         import random
-        torch.manual_seed(args.seed + rank)
+        torch.manual_seed(args.seed)  # rank-independent while the model is built (the per-rank offset follows below)
         random.seed(args.seed)  # the collator's branch draws are host-side: keep the ranks in step
 
     # ---- data (train.py:421-436)
@@ -98,17 +98,26 @@ def main():
     load_from = args.resume_from_checkpoint or args.warmstart_path
     model = (STMaskGIT.from_pretrained(load_from, precision=args.precision) if load_from
              else STMaskGIT(cfg, precision=args.precision))
-    if not load_from:
+    if not load_from and args.mu_transfer:
+        # reference train.py:420-424: init_weights() only on the muP path; otherwise PyTorch's default initialisation
+        # of nn.Linear / nn.Embedding stays (kept here too, so from-scratch dynamics follow the reference recipe)
         model.init_weights()
     model = model.to(dev)
+    if args.seed is not None:
+        torch.manual_seed(args.seed + rank)  # collator draws differ per rank; the weights above do not
 
     B, accum = args.per_device_train_batch_size, args.gradient_accumulation_steps
     micro_per_epoch = n_train // (B * world)
+    eb_ = args.per_device_eval_batch_size
+    if micro_per_epoch < 1:
+        sys.exit(f"train.py: {n_train} training windows < per_device_train_batch_size {B} x world {world}: no full batch")
+    if n_eval < eb_ * world:
+        sys.exit(f"train.py: {n_eval} eval windows < per_device_eval_batch_size {eb_} x world {world}: no full eval batch")
     updates_per_epoch = max(1, micro_per_epoch // accum)
     max_steps = args.max_train_steps or args.num_train_epochs * updates_per_epoch
     warm = args.num_warmup_steps
     lr_lambda = {"linear": trainmod.lr_factor_linear(warm, max_steps), "constant": lambda s: 1.0,
-                 "custom_cosine": trainmod.lr_factor_custom_cosine(max(warm, 1), max_steps)}[args.lr_scheduler_type]
+                 "custom_cosine": trainmod.lr_factor_custom_cosine(warm, max_steps)}[args.lr_scheduler_type]
     tr = trainmod.GenieTrainer(model, lr=args.learning_rate, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps,
                                weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm,
                                gradient_accumulation_steps=accum, lr_lambda=lr_lambda)
