@@ -115,6 +115,7 @@ SIGNATURES = {
     "genie_conv1x1_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_conv_direct_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          c_ptr]),
+    "genie_group_norm_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "genie_group_norm_swish_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_float, C.c_int, c_ptr]),
     "genie_bits_from_tokens_nhwc_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_int, C.c_int, c_ptr]),

@@ -629,6 +629,10 @@ int genie_conv_direct_bf16(const uint16_t* x, const uint16_t* w_packed, const fl
     GENIE_CHECK_ARG(x && w_packed && y && n >= 0 && (out_mode == 0 || out_mode == 1), "conv_direct: bad argument");
     return launch_conv_direct(x, w_packed, bias, y, n, H, W, Cin, Cout, out_mode, as_stream(stream));
 }
+size_t genie_group_norm_scratch_floats(int n, int HW, int groups) {
+    if (n <= 0 || HW <= 0 || groups <= 0) return 0;
+    return gn_scratch_floats(n, HW, groups);
+}
 int genie_group_norm_swish_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats_ws, int n,
                                 int HW, int C, int groups, float eps, int apply_swish, void* stream) {
     GENIE_CHECK_ARG(x && gamma && beta && y && stats_ws && n >= 0, "group_norm_swish: bad argument");

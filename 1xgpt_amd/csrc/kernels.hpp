@@ -92,6 +92,7 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
                          int stride = 1);
 int launch_frames_to_nhwc(const uint8_t* f, uint16_t* x, long n_img, int HW, int cin, int cpad, hipStream_t st);
 int launch_tokens_from_nhwc(const uint16_t* h, int64_t* ids, long n_pix, int bits, int cpad, hipStream_t st);
+size_t gn_scratch_floats(int n_img, int HW, int groups);
 int launch_gn_swish(const uint16_t* X, const float* gamma, const float* beta, uint16_t* Y, float* stats, int n_img, int HW,
                     int C, int groups, float eps, int apply_swish, hipStream_t st);
 int launch_conv_direct(const uint16_t* X, const uint16_t* Wt, const float* bias, void* Y, int n_img, int H, int Wd, int Cin,

@@ -205,17 +205,17 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
     return GENIE_OK;
 }
 
-// ---- GroupNorm(32) statistics: block = 256 threads over a slab of pixels of one image; thread t owns channel pair
-// columns so that its group is fixed; per-(image, group) f32 sum / sum-of-squares via one atomicAdd pair per block.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X, float* __restrict__ stats, int HW, int C,
+// ---- GroupNorm(32) statistics, order-fixed (bit-reproducible: no atomics anywhere).  block = 256 threads over a slab of
+// pixels of one image; thread t owns a fixed 8-channel slice, so its group(s) are fixed.  Per block: every thread parks its
+// (sum, sumsq) partials in LDS and 2*groups reducer threads add the contributors of their (group, moment) in thread order;
+// the block's partials go to part[(img, block)][groups][2] and gn_finalize adds the blocks of an image in block order (f64).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X, float* __restrict__ part, int HW, int C,
                                                        int groups, int pix_per_block) {
-    extern __shared__ float red[];  // [groups][2]
+    __shared__ float ps[256][4];  // per thread: s0, q0 (first half of its chunk), s1, q1 (second half)
     const int img = blockIdx.y;
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(p0 + pix_per_block, HW);
     const int cpg = C / groups;
-    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
     const int c8 = C >> 3;                  // 16-byte chunks per pixel; 256 % c8 == 0 (checked by the launcher)
     const int chunk = threadIdx.x % c8;     // fixed channel slice of this thread -> fixed group(s)
     const int prow = threadIdx.x / c8, pstep = blockDim.x / c8;
@@ -232,21 +232,36 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
             s1 += c + d; q1 += c * c + d * d;
         }
     }
-    const int g0 = (chunk * 8) / cpg, g1 = (chunk * 8 + 4) / cpg;
-    if (g0 == g1) { atomicAdd(&red[g0 * 2], s0 + s1); atomicAdd(&red[g0 * 2 + 1], q0 + q1); }
-    else { atomicAdd(&red[g0 * 2], s0); atomicAdd(&red[g0 * 2 + 1], q0); atomicAdd(&red[g1 * 2], s1); atomicAdd(&red[g1 * 2 + 1], q1); }
+    ps[threadIdx.x][0] = s0; ps[threadIdx.x][1] = q0; ps[threadIdx.x][2] = s1; ps[threadIdx.x][3] = q1;
     __syncthreads();
-    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) atomicAdd(&stats[(size_t)img * groups * 2 + i], red[i]);
+    if ((int)threadIdx.x < groups * 2) {
+        const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+        float acc = 0.f;
+        for (int t = 0; t < 256; ++t) {
+            const int ch = t % c8;
+            if ((ch * 8) / cpg == g) acc += ps[t][which];
+            if ((ch * 8 + 4) / cpg == g) acc += ps[t][2 + which];
+        }
+        part[(((size_t)img * gridDim.x + blockIdx.x) * groups) * 2 + threadIdx.x] = acc;
+    }
 }
 
-// (sum, sumsq) -> (mean, rstd) in place, one thread per (image, group)
-__global__ void gn_finalize_kernel(float* __restrict__ stats, int n, float cnt, float eps) {
+// per-block (sum, sumsq) partials -> (mean, rstd), one thread per (image, group), blocks added in order
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int n, int groups, int nblk,
+                                   float cnt, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float mean = stats[2 * i] / cnt;
-    const float var = fmaxf(stats[2 * i + 1] / cnt - mean * mean, 0.f);
-    stats[2 * i] = mean;
-    stats[2 * i + 1] = 1.0f / sqrtf(var + eps);
+    const int img = i / groups, g = i - img * groups;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const float* p = part + (((size_t)img * nblk + b) * groups + g) * 2;
+        s += (double)p[0];
+        q += (double)p[1];
+    }
+    const double mean = s / cnt;
+    const double var = fmax(q / cnt - mean * mean, 0.0);
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // y = swish(gn(x)) as bf16 NHWC (apply_swish = 0: GroupNorm only); stats hold (mean, rstd)
@@ -286,19 +301,25 @@ __global__ void gn_swish_kernel(const uint16_t* __restrict__ X, const float* __r
     *reinterpret_cast<uint4*>(Y + idx * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// floats of scratch genie_group_norm_swish_bf16 needs: final (mean, rstd) + the per-block partials
+size_t gn_scratch_floats(int n_img, int HW, int groups) {
+    const int ppb = HW >= 16384 ? 512 : (HW >= 1024 ? 128 : (HW >= 64 ? 64 : HW));
+    const int nblk = (HW + ppb - 1) / ppb;
+    return (size_t)n_img * groups * 2 * (1 + (size_t)nblk);
+}
+
 int launch_gn_swish(const uint16_t* X, const float* gamma, const float* beta, uint16_t* Y, float* stats, int n_img, int HW,
                     int C, int groups, float eps, int apply_swish, hipStream_t st) {
     GENIE_CHECK_SHAPE(C % groups == 0 && (C / groups) % 4 == 0 && C % 8 == 0 && groups <= 64 && 256 % (C / 8) == 0,
                       "group_norm: C=%d groups=%d unsupported", C, groups);
-    if (hipMemsetAsync(stats, 0, (size_t)n_img * groups * 2 * sizeof(float), st) != hipSuccess) {
-        set_error("group_norm: memset failed");
-        return GENIE_E_LAUNCH;
-    }
     const int ppb = HW >= 16384 ? 512 : (HW >= 1024 ? 128 : (HW >= 64 ? 64 : HW));
-    dim3 grid((HW + ppb - 1) / ppb, n_img);
-    gn_stats_kernel<<<grid, 256, groups * 2 * sizeof(float), st>>>(X, stats, HW, C, groups, ppb);
+    const int nblk = (HW + ppb - 1) / ppb;
+    float* part = stats + (size_t)n_img * groups * 2;  // scratch layout: [n][groups][2] (mean, rstd) | [n][nblk][groups][2]
+    dim3 grid(nblk, n_img);
+    gn_stats_kernel<<<grid, 256, 0, st>>>(X, part, HW, C, groups, ppb);
     GENIE_LAUNCH_CHECK("gn_stats");
-    gn_finalize_kernel<<<(n_img * groups + 255) / 256, 256, 0, st>>>(stats, n_img * groups, (float)HW * (C / groups), eps);
+    gn_finalize_kernel<<<(n_img * groups + 255) / 256, 256, 0, st>>>(part, stats, n_img * groups, groups, nblk,
+                                                                      (float)HW * (C / groups), eps);
     GENIE_LAUNCH_CHECK("gn_finalize");
     const long n_chunks = (long)n_img * HW * (C / 8);
     gn_swish_kernel<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>(X, stats, gamma, beta, Y, n_chunks, HW, C, groups,

@@ -28,6 +28,7 @@
 //     scaled by 2^11:  acc' += ah.(2048 bh) + ah.bl' + al'.bh  (2048 bh is a packed-f16 multiply on the B fragment in
 //     registers: exact for |w| < 32); the epilogue multiplies by alpha / 2048.  TERMS = 2 drops ah.bl' (weights rounded
 //     to f16), NPL = 1 with F16 reads only the hi plane (plain f16) -- both for the accuracy/speed study of DESIGN.md.
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -39,6 +40,9 @@ namespace genie {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ABL & 32: wave 0 of every workgroup stamps s_memtime at start / first data / end of main loop / end (debug study)
+__device__ unsigned long long* g_pp_timing = nullptr;
 
 namespace {
 
@@ -69,7 +73,9 @@ __device__ __forceinline__ f32x16 mma16(const s16x8& a, const s16x8& b, const f3
 
 // ABL: timing-only ablations for the study in DESIGN.md (results are wrong when ABL != 0): 1 no in-loop LDS-DMA,
 // 2 no in-loop fragment reads, 4 no vmcnt waits, 8 no output stores, 16 no matrix instructions
-template <int NPL, int TERMS, bool F16, int ABL = 0>
+// EPI >= 0: the epilogue's flag word (G16X_*) is a compile-time constant (the model's four Linear flavours get their own
+// instantiation: straight-line epilogue, loads hoisted, no per-row branches); EPI = -1: flags are read at run time.
+template <int NPL, int TERMS, bool F16, int ABL = 0, int SCHED = 0, int EPI = -1>
 __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
                                                             const uint16_t* __restrict__ W, long ldw, long planeW,
                                                             const float* __restrict__ bias, float* __restrict__ Cf,
@@ -120,14 +126,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     }
     const int lateA = (int)(64 * lda * 2), lateB = (int)(32 * ldw * 2);
     bool in_loop = false;
-    auto stage = [&](int ht, int buf, int kt) {  // ht: 0 A-early, 1 A-late, 2 B-early, 3 B-late; all arguments wave-uniform
+    // one 8 KB piece (j = 0, 1) of a half-tile: ht 0 A-early, 1 A-late, 2 B-early, 3 B-late; all arguments wave-uniform
+    auto piece = [&](int ht, int j, int buf, int kt) {
         if constexpr (ABL & 1) { if (in_loop) return; }
         const int soff = kt * BK * 2 + (ht == 1 ? lateA : ht == 3 ? lateB : 0);
-        unsigned char* dst = smem + buf * PP_BUF + ht * PP_HT + wid * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ht < 2 ? rsA : rsW, (__attribute__((address_space(3))) void*)(dst + j * 1024),
-                                                     16, ht < 2 ? voffA[j] : voffB[j], soff, 0, 0);
+        unsigned char* dst = smem + buf * PP_BUF + ht * PP_HT + wid * 2048 + j * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ht < 2 ? rsA : rsW, (__attribute__((address_space(3))) void*)dst, 16,
+                                                 ht < 2 ? voffA[j] : voffB[j], soff, 0, 0);
+    };
+    auto stage = [&](int ht, int buf, int kt) {
+        piece(ht, 0, buf, kt);
+        piece(ht, 1, buf, kt);
     };
 
     // ---- fragment read offsets: lane (r, h) reads 16-byte slot 2c + h of its row, c = plane * KK + k16 step
@@ -196,56 +205,81 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             }
         }
     };
-    // MODE 0: steady state, 1: second-to-last K-tile (stages for tile t+1 only), 2: last K-tile (stages nothing)
+    auto mfma_part = [&](int asub, int csub, int scale_sub) {
+        wg_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (scale_sub >= 0) scale_b(scale_sub);
+        __builtin_amdgcn_s_setprio(1);
+        mma(asub, csub);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // MODE 0: steady state, 1: second-to-last K-tile (stages for tile t+1 only), 2: last K-tile (stages nothing).
+    // SCHED 0: one half-tile per phase (q0 B-late(t+1), q1 A-late(t+1), q2 A-early(t+2), q3 B-early(t+2)).
+    // SCHED 1: the LDS-DMA issue (the expensive part of a LOAD) is moved away from the phases that carry the fragment
+    //          reads: q0 none (12 reads), q1 B-late(t+1) + half of A-late(t+1) (4 reads), q2 the other half (8 reads),
+    //          q3 A-early(t+2) + B-early(t+2) (no reads).  Same hazard rules; waits: q0 vmcnt(6), q1 (7), q3 (8).
     auto ktile = [&](auto bufc, auto modec, int t) {
         constexpr int BUF = decltype(bufc)::value, MODE = decltype(modec)::value;
+        constexpr bool NOWAIT = (ABL & 4) != 0;
         // q0: quadrant (a0, c0)
         read_a(BUF, 0);
         read_b(BUF, 0);
-        if constexpr (MODE < 2) stage(3, BUF ^ 1, t + 1);
-        if constexpr (MODE < 2) wait_vmcnt<8, (ABL & 4) != 0>(); else wait_vmcnt<2>();
-        wg_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        scale_b(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (SCHED == 0) {
+            if constexpr (MODE < 2) stage(3, BUF ^ 1, t + 1);
+            if constexpr (MODE < 2) wait_vmcnt<8, NOWAIT>(); else wait_vmcnt<2>();
+        } else {
+            if constexpr (MODE < 2) wait_vmcnt<6, NOWAIT>(); else wait_vmcnt<2>();
+        }
+        mfma_part(0, 0, 0);
         wg_barrier();
         // q1: quadrant (a0, c1)
         read_b(BUF, 1);
-        if constexpr (MODE < 2) stage(1, BUF ^ 1, t + 1);
-        if constexpr (MODE < 2) wait_vmcnt<8, (ABL & 4) != 0>(); else wait_vmcnt<0>();
-        wg_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        scale_b(1);
-        __builtin_amdgcn_s_setprio(1);
-        mma(0, 1);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (SCHED == 0) {
+            if constexpr (MODE < 2) stage(1, BUF ^ 1, t + 1);
+            if constexpr (MODE < 2) wait_vmcnt<8, NOWAIT>(); else wait_vmcnt<0>();
+        } else {
+            if constexpr (MODE < 2) { stage(3, BUF ^ 1, t + 1); piece(1, 0, BUF ^ 1, t + 1); }
+            if constexpr (MODE < 2) wait_vmcnt<7, NOWAIT>(); else wait_vmcnt<0>();
+        }
+        mfma_part(0, 1, 1);
         wg_barrier();
         // q2: quadrant (a1, c1)
         read_a(BUF, 1);
-        if constexpr (MODE == 0) stage(0, BUF, t + 2);
-        wg_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(1, 1);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (SCHED == 0) {
+            if constexpr (MODE == 0) stage(0, BUF, t + 2);
+        } else {
+            if constexpr (MODE < 2) piece(1, 1, BUF ^ 1, t + 1);
+        }
+        mfma_part(1, 1, -1);
         wg_barrier();
         // q3: quadrant (a1, c0)
-        if constexpr (MODE == 0) stage(2, BUF, t + 2);
-        if constexpr (MODE == 0) wait_vmcnt<8, (ABL & 4) != 0>();
+        if constexpr (SCHED == 0) {
+            if constexpr (MODE == 0) stage(2, BUF, t + 2);
+        } else {
+            if constexpr (MODE == 0) { stage(0, BUF, t + 2); stage(2, BUF, t + 2); }
+        }
+        if constexpr (MODE == 0) wait_vmcnt<8, NOWAIT>();
         if constexpr (MODE == 1) wait_vmcnt<4>();
-        wg_barrier();
-        __builtin_amdgcn_s_setprio(1);
-        mma(1, 0);
-        __builtin_amdgcn_s_setprio(0);
+        mfma_part(1, 0, -1);
         if (MODE < 2 || wm == 0) wg_barrier();  // group 1 skips the very last barrier (it entered one barrier late)
     };
 
     const int nk = K / BK;  // even, >= 2 (launcher)
+    {   // De-phasing (flags bits 8..11 = number of phase groups G, 0/1 = off): every CU runs its tiles back to back and all
+        // tiles take the same time, so without this all 256 CUs reach their epilogue together and the 256 KB x 256 store
+        // burst runs at the HBM write rate while the matrix pipes idle.  The first workgroup of each CU (block ids < 256, one
+        // workgroup per CU) waits phase/G of a main loop before it starts, phase = CU index within its XCD mod G; the offset
+        // then persists for the whole launch.
+        const int G = (flags >> 8) & 15;
+        if (G > 1 && bid < 256) {
+            const long wait = (long)((bid >> 3) % G) * ((long)nk * 8 * (NPL == 1 ? 288 : 420) / G);
+            const long t0 = (long)__builtin_amdgcn_s_memtime();
+            while ((long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    unsigned long long tstamp[4];
+    if constexpr (ABL & 32) tstamp[0] = __builtin_amdgcn_s_memtime();
     stage(0, 0, 0);
     stage(2, 0, 0);
     stage(3, 0, 0);
@@ -254,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     stage(2, 1, 1);
     wait_vmcnt<8>();  // A-early(0), B-early(0) of this wave have landed
     wg_barrier();
+    if constexpr (ABL & 32) tstamp[1] = __builtin_amdgcn_s_memtime();
     if (wm == 1) wg_barrier();  // group 1 runs one barrier behind group 0
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -277,12 +312,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     // the (now idle) ring, 64 rows at a time, and then works on whole rows: 16 lanes x float4 = one 256-byte row segment
     // per quarter-wave for the residual read, the f32 store and the 16-bit operand store.
     // (all LDS-DMA has landed and every fragment read has completed before any wave gets here: see the tail waits above)
+    if constexpr (ABL & 32) tstamp[2] = __builtin_amdgcn_s_memtime();
     if (Cf) Cf += (size_t)blockIdx.y * strideC;
     if (C16) C16 += (size_t)blockIdx.y * strideC;
     const float* Rsrc = Rf ? Rf + (size_t)blockIdx.y * strideC : Cf;
     float* ct = reinterpret_cast<float*>(smem + wid * 16384);
-    const bool do_gelu = flags & G16X_GELU, do_acc = flags & G16X_ACCUM;
-    const bool out16 = flags & G16X_OUT16, outf = flags & G16X_OUTF32, nts = flags & G16X_NT;
+    const int fl = EPI >= 0 ? EPI : flags;
+    const bool do_gelu = fl & G16X_GELU, do_acc = fl & G16X_ACCUM;
+    const bool out16 = fl & G16X_OUT16, outf = fl & G16X_OUTF32, nts = fl & G16X_NT;
     const float ascale = NPL == 2 ? alpha * (1.0f / 2048.0f) : alpha;
     const int c4 = (lane & 15) << 2;
     const int col = n0 + wn * 64 + c4;
@@ -298,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 for (int e = 0; e < 16; ++e)
                     ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q * 2 + i][j][e];
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int rl = it * 4 + (lane >> 4);
             const int row = m0 + wm * 128 + q * 64 + rl;
@@ -324,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 }
             }
             if (out16) {
-                if (flags & G16X_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+                if (fl & G16X_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
                 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
                 auto st2 = [&](uint16_t* p, uint32_t a, uint32_t b) {
                     u2v t = {a, b};
@@ -343,6 +380,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             }
         }
         __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next round
+    }
+    if constexpr (ABL & 32) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[3] = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && g_pp_timing) {
+            unsigned long long* o = g_pp_timing + 4 * (size_t)blockIdx.x;
+            o[0] = tstamp[0]; o[1] = tstamp[1]; o[2] = tstamp[2]; o[3] = tstamp[3];
+        }
     }
 }
 
@@ -368,46 +413,102 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
                              (flags & G16X_OUT16 ? (plane16 ? 4 : 2) : 0)),
                    st);
     const dim3 grid((unsigned)((M / 256) * (N / 256)), (unsigned)batch);
+    static const int stagger = [] { const char* e = getenv("GENIE_PP_STAGGER"); return e ? atoi(e) : 0; }();
+    static const long stagger_min = [] { const char* e = getenv("GENIE_PP_STAGGER_MIN_TILES"); return e ? atol(e) : 1024L; }();
+    if (stagger > 1 && batch == 1 && tiles >= stagger_min) flags |= (stagger & 15) << 8;
     constexpr size_t lds = 2 * PP_BUF;
-#define PP_LAUNCH(NPL_, TERMS_, F16_)                                                                                     \
+#define PP_LAUNCH(NPL_, TERMS_, F16_, ABL_, SCHED_)                                                                       \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, TERMS_, F16_>,                                      \
+        (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, TERMS_, F16_, ABL_, SCHED_>,                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-        gemm16_pp_kernel<NPL_, TERMS_, F16_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,       \
-                                                                      plane16, ldc, M, N, K, flags, alpha, strideA,       \
-                                                                      strideC, Rf, strideW);                              \
+        gemm16_pp_kernel<NPL_, TERMS_, F16_, ABL_, SCHED_><<<grid, 512, lds, st>>>(                                       \
+            A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,     \
+            strideW);                                                                                                     \
     } while (0)
-    static const int abl = [] { const char* e = getenv("GENIE_PP_ABL"); return e ? atoi(e) : 0; }();
 #define PP_LAUNCH_ABL(ABL_)                                                                                               \
     do {                                                                                                                  \
-        if (npl == 1) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<1, 1, false, ABL_>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            gemm16_pp_kernel<1, 1, false, ABL_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,    \
-                                                                         plane16, ldc, M, N, K, flags, alpha, strideA,    \
-                                                                         strideC, Rf, strideW);                           \
-        } else {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<2, 3, true, ABL_>,                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            gemm16_pp_kernel<2, 3, true, ABL_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,     \
-                                                                        plane16, ldc, M, N, K, flags, alpha, strideA,     \
-                                                                        strideC, Rf, strideW);                            \
-        }                                                                                                                 \
+        if (npl == 1) PP_LAUNCH(1, 1, false, ABL_, 0);                                                                    \
+        else PP_LAUNCH(2, 3, true, ABL_, 0);                                                                              \
     } while (0)
+    static const int abl = [] { const char* e = getenv("GENIE_PP_ABL"); return e ? atoi(e) : 0; }();
+    static const int sched = [] { const char* e = getenv("GENIE_PP_SCHED"); return e ? atoi(e) : 0; }();
+    static unsigned long long* tbuf = nullptr;
+    const size_t n_wg = (size_t)grid.x;
+    if ((abl == 32 || abl == 33) && !tbuf) {
+        (void)hipMalloc(&tbuf, sizeof(unsigned long long) * 4 * 65536);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_timing), &tbuf, sizeof(tbuf));
+    }
     if (abl == 1) PP_LAUNCH_ABL(1);
     else if (abl == 2) PP_LAUNCH_ABL(2);
     else if (abl == 3) PP_LAUNCH_ABL(3);
-    else if (abl == 4) PP_LAUNCH_ABL(4);
     else if (abl == 8) PP_LAUNCH_ABL(8);
     else if (abl == 16) PP_LAUNCH_ABL(16);
-    else if (abl == 19) PP_LAUNCH_ABL(19);
     else if (abl == 11) PP_LAUNCH_ABL(11);
-    else if (npl == 1 && !f16) PP_LAUNCH(1, 1, false);
-    else if (npl == 1) PP_LAUNCH(1, 1, true);
-    else if (terms == 2) PP_LAUNCH(2, 2, true);
-    else PP_LAUNCH(2, 3, true);
+    else if (abl == 32) PP_LAUNCH_ABL(32);
+    else if (abl == 33) {  // stamps with the compile-time OUTF32 | NT epilogue
+        if (npl == 1) { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW); }
+        else { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW); }
+    }
+    else {
+        // compile-time epilogues for the model's Linear flavours (qkv / readout: OUTF32; proj, fc2: ACCUM | OUTF32 [| OUT16];
+        // fc1: GELU | OUT16), each with and without non-temporal stores; anything else takes the run-time-flag kernel
+        const int e = flags & 63;
+#define PP_EPI(NPL_, F16_, E_)                                                                                            \
+        case E_: {                                                                                                        \
+            (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, 0, E_>,           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, 0, E_><<<grid, 512, lds, st>>>(                          \
+                A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,  \
+                strideW);                                                                                                 \
+            done = true;                                                                                                  \
+        } break;
+#define PP_EPI_ALL(NPL_, F16_)                                                                                            \
+        switch (e) {                                                                                                      \
+            PP_EPI(NPL_, F16_, G16X_OUTF32)                                                                               \
+            PP_EPI(NPL_, F16_, G16X_OUTF32 | G16X_NT)                                                                     \
+            PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32)                                                                  \
+            PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32 | G16X_NT)                                                        \
+            PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32 | G16X_OUT16)                                                     \
+            PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32 | G16X_OUT16 | G16X_NT)                                           \
+            PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16)                                                                    \
+            PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16 | G16X_NT)                                                          \
+            default: break;                                                                                               \
+        }
+        bool done = false;
+        static const int epi = [] { const char* e2 = getenv("GENIE_PP_EPI"); return e2 ? atoi(e2) : 1; }();
+        if (epi && sched == 0 && terms == 3) {
+            if (npl == 1 && !f16) { PP_EPI_ALL(1, false) }
+            else if (npl == 2) { PP_EPI_ALL(2, true) }
+        }
+#undef PP_EPI_ALL
+#undef PP_EPI
+        if (done) {
+        } else if (npl == 1 && !f16) { if (sched == 0) PP_LAUNCH(1, 1, false, 0, 0); else PP_LAUNCH(1, 1, false, 0, 1); }
+        else if (npl == 1) PP_LAUNCH(1, 1, true, 0, 0);
+        else if (terms == 2) PP_LAUNCH(2, 2, true, 0, 0);
+        else { if (sched == 0) PP_LAUNCH(2, 3, true, 0, 0); else PP_LAUNCH(2, 3, true, 0, 1); }
+    }
 #undef PP_LAUNCH
 #undef PP_LAUNCH_ABL
+    if ((abl == 32 || abl == 33) && n_wg <= 16384 && batch == 1) {  // debug study: average the stamps of this launch (synchronises!)
+        static unsigned long long host[4 * 16384];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(host, tbuf, sizeof(unsigned long long) * 4 * n_wg, hipMemcpyDeviceToHost);
+        double pro = 0, loop = 0, epi = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < n_wg; ++i) {
+            pro += (double)(host[4 * i + 1] - host[4 * i]);
+            loop += (double)(host[4 * i + 2] - host[4 * i + 1]);
+            epi += (double)(host[4 * i + 3] - host[4 * i + 2]);
+            if (host[4 * i] < t0) t0 = host[4 * i];
+            if (host[4 * i + 3] > t1) t1 = host[4 * i + 3];
+        }
+        fprintf(stderr, "pp_timing npl=%d M=%d N=%d K=%d wgs=%zu: prologue %.0f  main loop %.0f  epilogue+drain %.0f  (s_memtime "
+                        "ticks per workgroup, 100 MHz clock?)  span %.0f\n",
+                npl, M, N, K, n_wg, pro / n_wg, loop / n_wg, epi / n_wg, (double)(t1 - t0));
+    }
     GENIE_LAUNCH_CHECK("gemm16_pp");
     return GENIE_OK;
 }

@@ -5,15 +5,15 @@ Counterpart of the reference's magvit2/ package restricted to what the hot path 
 ``decode_latents_wrapper`` of visualize.py:95-122.  State-dict keys equal the reference's ``encoder.*`` /
 ``decoder.*`` keys, so a Lightning ``magvit2.ckpt`` loads with ``load_tokenizer_ckpt``.
 
-Two executions of the same parameters:
-  * ``HipDecoder`` / ``HipEncoder`` -- the product path: hand-written gfx950 kernels behind the C ABI (NHWC bf16,
-    implicit-GEMM 3x3 convolutions on the bf16 matrix cores with a gathered A operand and fused bias / ResBlock skip /
-    depth-to-space epilogue, fused GroupNorm+swish, bit/byte ends ``genie_bits_from_tokens*``,
-    ``genie_rescale_u8_*``, ``genie_tokens_from_*``).  Tokens and frames never leave HBM (the reference round-trips
-    through numpy and PIL, eval_utils.py:39-41).
-  * the ``nn.Module`` classes below -- parameter holders with the reference's state-dict keys whose ``forward`` is the
-    plain torch (MIOpen) formulation; used to load checkpoints, as the measured library baseline, and for widths the
-    implicit GEMM does not cover (ResBlock widths must be multiples of 64).
+One execution: ``HipDecoder`` / ``HipEncoder`` -- hand-written gfx950 kernels behind the C ABI (NHWC bf16, implicit-GEMM
+3x3 convolutions on the bf16 matrix cores with a gathered A operand and fused bias / ResBlock skip / depth-to-space
+epilogue, fused GroupNorm+swish with order-fixed statistics, bit/byte ends ``genie_bits_from_tokens*``,
+``genie_rescale_u8_*``, ``genie_tokens_from_*``).  Tokens and frames never leave HBM (the reference round-trips through
+numpy and PIL, eval_utils.py:39-41).  The ``nn.Module`` classes below are PARAMETER HOLDERS with the reference's
+state-dict keys (so ``magvit2.ckpt`` loads by name); they have no arithmetic of their own -- calling one raises.  There is
+no second backend: a geometry the kernels do not cover (ResBlock widths must be multiples of 64; the shipped config is
+128/256/512) is an error, not a fallback.  The plain-torch formulation lives in ``oracle/magvit2_oracle.py`` (test
+infrastructure).
 """
 import json
 import math
@@ -23,7 +23,6 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib
 
@@ -53,8 +52,9 @@ class VQConfig:
         return cls(**kw)
 
 
-def swish(x):
-    return x * torch.sigmoid(x)  # improved_model.py:7-9
+def _holder_forward(self, *args, **kwargs):
+    raise RuntimeError(f"{type(self).__name__} is a parameter holder (reference state-dict keys); the arithmetic runs in "
+                       "HipDecoder / HipEncoder (VQModel.decode_tokens / encode_tokens)")
 
 
 class ResBlock(nn.Module):
@@ -71,33 +71,17 @@ class ResBlock(nn.Module):
         if in_filters != out_filters:
             self.nin_shortcut = nn.Conv2d(in_filters, out_filters, kernel_size=(1, 1), padding=0, bias=False)
 
-    def forward(self, x):
-        residual = x
-        x = self.conv1(swish(self.norm1(x)))
-        x = self.conv2(swish(self.norm2(x)))
-        if self.in_filters != self.out_filters:
-            residual = self.nin_shortcut(residual)
-        return x + residual
-
-
-def depth_to_space(x: torch.Tensor, block_size: int) -> torch.Tensor:
-    """DCR depth-to-space: channel (i*bs + j)*C' + c -> pixel (bs*h + i, bs*w + j), channel c (improved_model.py:185-218)."""
-    c, h, w = x.shape[-3:]
-    s = block_size ** 2
-    if c % s != 0:
-        raise ValueError(f"Expecting a channels-first (*CHW) tensor with C divisible by {s}, but got C={c} channels")
-    outer = x.shape[:-3]
-    x = x.reshape(-1, block_size, block_size, c // s, h, w).permute(0, 3, 4, 1, 5, 2)
-    return x.reshape(*outer, c // s, h * block_size, w * block_size)
+    forward = _holder_forward
 
 
 class Upsampler(nn.Module):
+    """conv3x3 C -> 4C (bias) whose output the kernel stores depth-to-space (DCR order, improved_model.py:185-237)."""
+
     def __init__(self, dim):
         super().__init__()
         self.conv1 = nn.Conv2d(dim, dim * 4, (3, 3), padding=1)
 
-    def forward(self, x):
-        return depth_to_space(self.conv1(x), 2)
+    forward = _holder_forward
 
 
 class _Level(nn.Module):
@@ -130,16 +114,7 @@ class Encoder(nn.Module):
         self.norm_out = nn.GroupNorm(32, block_out, eps=1e-6)
         self.conv_out = nn.Conv2d(block_out, config.z_channels, kernel_size=(1, 1))
 
-    def forward(self, x):
-        x = self.conv_in(x)
-        for i_level in range(self.num_blocks):
-            for blk in self.down[i_level].block:
-                x = blk(x)
-            if i_level < self.num_blocks - 1:
-                x = self.down[i_level].downsample(x)
-        for blk in self.mid_block:
-            x = blk(x)
-        return self.conv_out(swish(self.norm_out(x)))
+    forward = _holder_forward
 
 
 class Decoder(nn.Module):
@@ -166,16 +141,7 @@ class Decoder(nn.Module):
         self.norm_out = nn.GroupNorm(32, block_in, eps=1e-6)
         self.conv_out = nn.Conv2d(block_in, config.out_channels, kernel_size=(3, 3), padding=1)
 
-    def forward(self, z):
-        z = self.conv_in(z)
-        for blk in self.mid_block:
-            z = blk(z)
-        for i_level in reversed(range(self.num_blocks)):
-            for blk in self.up[i_level].block:
-                z = blk(z)
-            if i_level > 0:
-                z = self.up[i_level].upsample(z)
-        return self.conv_out(swish(self.norm_out(z)))
+    forward = _holder_forward
 
 
 def _stream():
@@ -226,7 +192,9 @@ def rescale_magvit_output(x: torch.Tensor) -> torch.Tensor:
 
 
 class VQModel(nn.Module):
-    """Encoder + Decoder + LFQ bit packing (inference subset of models/lfqgan.py:21-133)."""
+    """Encoder + Decoder parameters + LFQ bit packing (inference subset of models/lfqgan.py:21-133).  ``decode_tokens`` /
+    ``encode_tokens`` run the hand-written conv stacks (built lazily from the current parameters; call ``refresh()`` after
+    loading new weights or moving the module)."""
 
     def __init__(self, config: VQConfig = None):
         super().__init__()
@@ -235,23 +203,47 @@ class VQModel(nn.Module):
         self.decoder = Decoder(self.config)
         self.codebook_dim = int(math.log2(self.config.codebook_size))
         self.requires_grad_(False)
+        self._hip_dec = self._hip_enc = None
 
-    def decode(self, quant):
-        return self.decoder(quant)
+    def refresh(self):
+        self._hip_dec = self._hip_enc = None
+        return self
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() / .half(): the packed copies are stale
+        self._hip_dec = self._hip_enc = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._hip_dec = self._hip_enc = None
+        return super().load_state_dict(*a, **k)
+
+    def hip_decoder(self):
+        if self._hip_dec is None:
+            self._hip_dec = HipDecoder(self.decoder, self.codebook_dim)
+        return self._hip_dec
+
+    def hip_encoder(self):
+        if self._hip_enc is None:
+            self._hip_enc = HipEncoder(self.encoder, self.codebook_dim)
+        return self._hip_enc
 
     @torch.no_grad()
     def decode_tokens(self, ids_nhw: torch.LongTensor) -> torch.Tensor:
-        """(n, h, w) token ids -> (n, 3, H, W) uint8, in the module's dtype (the reference uses bf16)."""
-        dt = next(self.parameters()).dtype
-        z = bits_from_tokens(ids_nhw, self.codebook_dim).to(dt)
-        return rescale_magvit_output(self.decoder(z))
+        """(n, h, w) token ids -> (n, 3, H, W) uint8 on the device (visualize.py:111-121 without the host round trip)."""
+        return self.hip_decoder().decode_tokens(ids_nhw)
 
     @torch.no_grad()
     def encode_tokens(self, frames_u8: torch.Tensor) -> torch.LongTensor:
         """(n, 3, H, W) uint8 -> (n, h, w) ids with the dataset bit convention."""
-        dt = next(self.parameters()).dtype
-        x = (frames_u8.to(torch.float32) / 127.5 - 1.0).to(dt)
-        return tokens_from_bits(self.encoder(x))
+        return self.hip_encoder().encode_tokens(frames_u8)
+
+
+def _check_widths(module, what):
+    bad = sorted({m.out_filters for m in module.modules() if isinstance(m, ResBlock) and m.out_filters % 64} |
+                 {m.in_filters for m in module.modules() if isinstance(m, ResBlock) and m.in_filters % 64})
+    if bad:
+        raise ValueError(f"{what}: ResBlock widths {bad} are not multiples of 64 -- the implicit-GEMM conv kernels do not "
+                         "cover this geometry and there is no fallback backend")
 
 
 class HipDecoder:
@@ -267,6 +259,7 @@ class HipDecoder:
         dev = next(decoder.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): move the decoder to cuda")
+        _check_widths(decoder, "HipDecoder")
         self.dev, self.bits = dev, codebook_dim
         self.zero = torch.zeros(64, dtype=torch.bfloat16, device=dev)
         self._keep = []
@@ -319,7 +312,7 @@ class HipDecoder:
     def _gn(self, x, gb, swish=True):
         n, H, W, C = x.shape
         y = torch.empty_like(x)
-        stats = torch.empty(n * 32 * 2, dtype=torch.float32, device=self.dev)
+        stats = torch.empty(self.lib.genie_group_norm_scratch_floats(n, H * W, 32), dtype=torch.float32, device=self.dev)
         _lib.check(self.lib.genie_group_norm_swish_bf16(x.data_ptr(), gb[0].data_ptr(), gb[1].data_ptr(), y.data_ptr(),
                                                         stats.data_ptr(), n, H * W, C, 32, 1e-6, int(swish), _stream()),
                    "genie_group_norm_swish_bf16")
@@ -403,6 +396,7 @@ class HipEncoder(HipDecoder):
         dev = next(encoder.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): move the encoder to cuda")
+        _check_widths(encoder, "HipEncoder")
         self.dev, self.bits = dev, codebook_dim
         self.zero = torch.zeros(64, dtype=torch.bfloat16, device=dev)
         self._keep = []
@@ -464,14 +458,13 @@ def load_tokenizer_ckpt(model: VQModel, path: str):
 
 
 def decode_latents_wrapper(batch_size=16, tokenizer_ckpt="data/magvit2.ckpt", max_images=None, model: VQModel = None,
-                           device="cuda", dtype=torch.bfloat16, backend="hip"):
-    """visualize.py:95-122, device-resident: returns ``decode_latents(tokens (b,h,w)) -> uint8 (b,3,H,W)`` tensor.
-    backend "hip": the hand-written conv stack (HipDecoder; needs ResBlock widths %% 64 == 0); "miopen": torch convs."""
+                           device="cuda"):
+    """visualize.py:95-122, device-resident: returns ``decode_latents(tokens (b,h,w)) -> uint8 (b,3,H,W)`` tensor on the
+    hand-written conv stack (bf16 operands like the reference's ``.to(dtype=torch.bfloat16)`` module)."""
     if model is None:
         model = load_tokenizer_ckpt(VQModel(VQConfig()), tokenizer_ckpt)
-    model = model.to(device=device, dtype=dtype).eval()
-    widths_ok = all(c % 64 == 0 for c in [model.config.base_channels * m for m in model.config.ch_mult])
-    hip_dec = HipDecoder(model.decoder, model.codebook_dim) if backend == "hip" and widths_ok else None
+    model = model.to(device=device).eval()
+    hip_dec = model.hip_decoder()
 
     @torch.no_grad()
     def decode_latents(video_data):
@@ -480,8 +473,7 @@ def decode_latents_wrapper(batch_size=16, tokenizer_ckpt="data/magvit2.ckpt", ma
         video_data = video_data.to(device)
         outs = []
         for s in range(0, video_data.shape[0], batch_size):
-            chunk = video_data[s:s + batch_size]
-            outs.append(hip_dec.decode_tokens(chunk) if hip_dec is not None else model.decode_tokens(chunk))
+            outs.append(hip_dec.decode_tokens(video_data[s:s + batch_size]))
             if max_images and len(outs) * batch_size >= max_images:
                 break
         return torch.cat(outs)

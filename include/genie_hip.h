@@ -269,7 +269,9 @@ int genie_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits
  * genie_conv1x1_bf16: the 1x1 nin_shortcut (a plain Linear over pixels).
  * genie_conv_direct_bf16: direct 3x3 conv for the edge layers (C_in = 18 -> 512, 128 -> 3); out_mode 0 = NHWC bf16,
  *   1 = NCHW f32.
- * genie_group_norm_swish_bf16: GroupNorm(groups, eps) [+ x*sigmoid(x)] of an NHWC bf16 image; stats_ws: n*groups*2 f32.
+ * genie_group_norm_swish_bf16: GroupNorm(groups, eps) [+ x*sigmoid(x)] of an NHWC bf16 image (improved_model.py:24-34);
+ *   stats_ws: genie_group_norm_scratch_floats(n, HW, groups) f32 of scratch.  The statistics are reduced in a fixed order
+ *   (no atomics): the same input gives the same bytes on every call.
  * genie_bits_from_tokens_nhwc_bf16: tokens (n_pix) -> (n_pix, cpad) bf16: channel c < bits = +-1 for bit c (a18 in
  *   operand layout), channels >= bits zero (cpad %% 64 == 0 lets conv_in run on the implicit GEMM).
  * genie_rescale_u8_nhwc_bf16: decoder tail: (n, HW, cpad) bf16 -> (n, cout, HW) uint8 with the reference's bf16 rescale. */
@@ -287,6 +289,7 @@ int genie_conv1x1_bf16(const uint16_t* x, const uint16_t* w_packed, const float*
                        int Cout, void* stream);
 int genie_conv_direct_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, void* y, int n, int H, int W,
                            int Cin, int Cout, int out_mode, void* stream);
+size_t genie_group_norm_scratch_floats(int n, int HW, int groups);
 int genie_group_norm_swish_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats_ws, int n,
                                 int HW, int C, int groups, float eps, int apply_swish, void* stream);
 int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_pix, int bits, int cpad, void* stream);

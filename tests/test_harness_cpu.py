@@ -71,23 +71,53 @@ def test_rescale_u8(magvit):
 
 
 def test_magvit_structure_and_weights(magvit):
-    """Same state-dict keys / shapes as the reference stacks and the same f32 function (torch ops, CPU)."""
+    """Same state-dict keys / shapes as the reference stacks; the torch oracle over those parameters reproduces the
+    reference's f32 outputs (pins oracle/magvit2_oracle.py on the small config; mid / full: test_magvit_oracle_mid_and_full)."""
+    from oracle import magvit2_oracle as MO
     mv = pkg("magvit2")
     small = ast.literal_eval(str(magvit["cfg"]))
     m = mv.VQModel(mv.VQConfig(**small))
     sd = mv.make_vq_state_dict(m, seed=int(magvit["weight_seed"]))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     z = torch.from_numpy(O.bits_from_tokens(magvit["dec_tokens"]))
-    y = m.decoder(z).numpy()
+    y = MO.decoder_forward(m.decoder, z).numpy()
     assert np.abs(y - magvit["dec_out_f32"]).max() < 1e-4
     x = torch.from_numpy(magvit["enc_frames"]).float() / 127.5 - 1.0
-    h = m.encoder(x).numpy()
+    h = MO.encoder_forward(m.encoder, x).numpy()
     assert np.abs(h - magvit["enc_h"]).max() < 1e-4
     # the full-size config has the conv inventory of SURVEY.md a19/a20
     full = mv.VQModel(mv.VQConfig())
     n_dec = sum(p.numel() for p in full.decoder.parameters())
     n_enc = sum(p.numel() for p in full.encoder.parameters())
     assert round(n_dec / 1e6, 1) == 40.5 and round(n_enc / 1e6, 1) == 25.0
-    assert mv.depth_to_space(torch.arange(16.).view(1, 4, 2, 2), 2).shape == (1, 1, 4, 4)
+    assert MO.depth_to_space(torch.arange(16.).view(1, 4, 2, 2), 2).shape == (1, 1, 4, 4)
     with pytest.raises(RuntimeError, match="GPU only"):
         mv.bits_from_tokens(torch.zeros(1, 4, 4, dtype=torch.long))
+    # the modules hold parameters only: there is no torch / MIOpen execution in the product package
+    with pytest.raises(RuntimeError, match="parameter holder"):
+        m.decoder(z)
+    with pytest.raises(ValueError, match="multiples of 64"):   # and no fallback for an uncovered geometry (checked before any GPU use
+        mv._check_widths(m.decoder, "HipDecoder")              # would be needed)
+
+
+def test_magvit_oracle_mid_and_full():
+    """oracle/magvit2_oracle.py against the reference's own outputs: the mid config (256/128 widths) and the SHIPPED
+    VQConfig (512..128 channels, one 256x256 frame; improved_model.py:103-182), f32, on the CPU."""
+    from conftest import GOLDEN
+    from oracle import magvit2_oracle as MO
+    mv = pkg("magvit2")
+    torch.set_grad_enabled(False)
+    for name, cfg_kw in (("magvit_mid", None), ("magvit_full", {})):
+        z = np.load(f"{GOLDEN}/{name}.npz")
+        kw = cfg_kw if cfg_kw is not None else ast.literal_eval(str(z["cfg"]))
+        m = mv.VQModel(mv.VQConfig(**kw))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in mv.make_vq_state_dict(m, int(z["weight_seed"])).items()})
+        bits = MO.bits_from_tokens(torch.from_numpy(z["dec_tokens"]))
+        y = MO.decoder_forward(m.decoder, bits)
+        assert np.abs(y.numpy() - z["dec_out_f32"]).max() < 2e-4 * max(1.0, float(np.abs(z["dec_out_f32"]).max()))
+        assert np.array_equal(MO.rescale_u8(y).numpy(), z["dec_u8_f32"]) or \
+            (np.abs(MO.rescale_u8(y).numpy().astype(int) - z["dec_u8_f32"].astype(int)).max() <= 1)
+        x = torch.from_numpy(z["enc_frames"]).float() / 127.5 - 1.0
+        h = MO.encoder_forward(m.encoder, x).numpy()
+        href = z["enc_h_f32"] if "enc_h_f32" in z.files else z["enc_h"]
+        assert np.abs(h - href).max() < 2e-4 * max(1.0, float(np.abs(href).max()))

@@ -1,0 +1,260 @@
+"""GPU (-m gpu): the BASELINE.json configurations that round 1 left without a test.
+
+  config 2  magvit_n32_h8_d256 (C35) bf16 forward + CE at batch 64            -> test_config2_c35_bf16_batch64
+  config 3  GENIE_138M-shape generate.py semantics, maskgit_steps 2 and 8     -> test_config3_generate_c138
+  config 5  MAGVIT2 encode -> GENIE sample -> MAGVIT2 decode, shipped VQConfig -> test_config5_*
+  and the batched (chip-filling) shapes of the 16-bit GEMM, which the single-clip fixtures never reach
+                                                                              -> test_batched_forward_vs_oracle
+References are the committed goldens (outputs of the reference itself, tools/make_goldens.py) and the NumPy oracle."""
+import ast
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pkg
+from oracle import genie_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def _probe(lg, ts, ss):
+    return np.stack([lg[:, :, t, s // 16, s % 16] for t, s in zip(ts, ss)], 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batched shapes: 12 clips x 4096 tokens fill the chip with 256x256 GEMM tiles (kernels_gemm_pp.hip, every epilogue
+# flavour of the block: qkv OUTF32, proj ACCUM|OUTF32|OUT16, fc1 GELU|OUT16, fc2 ACCUM|OUTF32)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,nm,tol", [("f16x3", O.F32, 5e-5), ("bf16", O.BF16_MFMA, None)])
+def test_batched_forward_vs_oracle(precision, nm, tol):
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=8, d_model=512, T=16, S=256, num_factored_vocabs=2,
+                                    qk_norm=False, use_mup=False)
+    synth = pkg("synthetic")
+    sd = synth.make_state_dict(cfg, seed=41, law="conditioned")
+    B = 12
+    ids = synth.make_clips(B, cfg, seed=43)
+    x = ids.reshape(B, 16, 16, 16).copy()
+    x[:, 8:] = cfg.image_vocab_size
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+    lg = m.compute_logits(dev(x)).cpu().numpy()                      # (B, 1024, T, 16, 16): 256x256-tile GEMMs
+    g = np.random.default_rng(3)
+    ts, ss = g.integers(0, 16, 48), g.integers(0, 256, 48)
+    for b in (0, B - 1):                                             # first and last clip against the oracle
+        ref = O.compute_logits(x[b:b + 1], sd, cfg, nm)
+        err = np.abs(_probe(lg[b:b + 1], ts, ss) - _probe(ref, ts, ss))
+        if tol is not None:
+            assert err.max() < tol, (precision, b, err.max())
+        else:  # bf16: same rounding points as the oracle's contract, one-ulp flips propagate (see test_hip_bf16.py)
+            assert np.median(err) < 4e-3 and err.max() < 8e-2, (b, np.median(err), err.max())
+    # batch independence: a clip's logits do not depend on what else is in the batch (other kernels run at B = 1)
+    lg1 = m.compute_logits(dev(x[5:6])).cpu().numpy()
+    d = np.abs(lg1 - lg[5:6]).max()
+    assert d < (2e-5 if precision == "f16x3" else 8e-2), d
+
+
+def test_split_gemm_range_edges():
+    """f16x3 operands near both ends of the f16 range: activations up to 3e4, down to 1e-6 (hi is
+    flushed below 6.1e-5 and lo alone carries the value), weights up to 16 (the in-register 2^11 scaling of the weight's hi
+    plane needs |w| < 32).  The result must stay f32-class against an f64 product of the same split operands."""
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    M, N, K = 16384, 1536, 512                      # 384 tiles: the 256x256 kernel
+    mag = torch.exp(torch.empty(M, K, device="cuda").uniform_(np.log(1e-6), np.log(3e4), generator=g))
+    x = mag * torch.sign(torch.randn(M, K, device="cuda", generator=g))
+    W = (torch.randn(N, K, device="cuda", generator=g) * torch.exp(torch.empty(N, K, device="cuda").uniform_(-9.0, 2.7, generator=g))).clamp(-31.0, 31.0)
+    assert W.abs().max() < 32
+    st = torch.cuda.current_stream().cuda_stream
+    x16 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+    W16 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+    _lib.check(lib.genie_pack_split_f16(x.data_ptr(), x16.data_ptr(), x.numel(), st), "pack")
+    _lib.check(lib.genie_pack_split_f16(W.data_ptr(), W16.data_ptr(), W.numel(), st), "pack")
+    y = torch.empty(M, N, device="cuda")
+    _lib.check(lib.genie_linear_lowp(_lib.PREC_F16X3, x16.data_ptr(), W16.data_ptr(), 0, y.data_ptr(), M, N, K, 0, 0, st), "lin")
+    rows = torch.randint(0, M, (48,), device="cuda", generator=g)
+    xs = x16[0, rows].double() + x16[1, rows].double() / 2048
+    Ws = W16[0].double() + W16[1].double() / 2048
+    ref = xs @ Ws.T
+    scale = (xs.abs() @ Ws.abs().T)                 # sum |a||b|: the natural error scale of a dot product
+    rel = ((y[rows].double() - ref).abs() / scale).max().item()
+    assert torch.isfinite(y).all()
+    assert rel < 3e-6, rel                          # f32 accumulation + the dropped lo.lo term (2^-22)
+    # and the split itself: 22 bits across the normal range
+    back = x16[0].double() + x16[1].double() / 2048
+    big = x.abs() > 1e-3
+    assert ((back - x.double()).abs()[big] / x.abs().double()[big]).max().item() < 2.0 ** -21
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 2: the shipped 35M config, bf16, forward + CE on 64 clips
+# ---------------------------------------------------------------------------------------------------------------
+def test_config2_c35_bf16_batch64(golden):
+    z, cfg, sd = golden("anchor_c35")
+    synth = pkg("synthetic")
+    B = 64
+    ids = np.concatenate([z["ids"], synth.make_clips(B - 1, cfg, seed=4040)], 0)      # clip 0 = the reference's clip
+    x = ids.reshape(B, 16, 16, 16).copy()
+    x[:, 8:] = cfg.image_vocab_size
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision="bf16").load_numpy_state_dict(sd).to("cuda")
+    out = m(dev(x.reshape(B, -1)), dev(ids))
+    assert np.isfinite(out.loss.item()) and 0.0 <= out.acc.item() <= 1.0
+    # per-clip CE from the batched logits with the reference's own metric (eval_utils.compute_loss semantics)
+    lg = out.logits                                                                    # (B, 1024, 16, 16, 16)
+    fl = lg[:, :, 1:].reshape(B, 2, 512, 15, 16, 16).permute(0, 2, 1, 3, 4, 5)
+    eu = pkg("eval_utils")
+    ce = [eu.compute_loss(dev(ids[b:b + 1]), fl[b:b + 1].contiguous()) for b in range(B)]
+    # clip 0 against the f32 reference golden (bf16 noise over 32 layers) ...
+    assert abs(ce[0] - float(z["fwd_compute_loss_allframes"])) < 0.1
+    # ... clips 0 and 63 against the bf16-contract oracle (same rounding points: tight) ...
+    for b in (0, B - 1):
+        lo = O.compute_logits(x[b:b + 1], sd, cfg, O.BF16_MFMA)
+        flo = lo[:, :, 1:].reshape(1, 2, 512, 15, 16, 16).transpose(0, 2, 1, 3, 4, 5)
+        ce_o = O.compute_loss(ids[b:b + 1], flo, cfg)
+        assert abs(ce[b] - ce_o) < 3e-3, (b, ce[b], ce_o)
+    # ... and every clip against itself run alone or in a small batch (batch independence of the whole stack)
+    for lo_, hi_ in ((0, 1), (17, 19), (62, 64)):
+        small = m(dev(x[lo_:hi_].reshape(hi_ - lo_, -1)), dev(ids[lo_:hi_])).logits
+        fs = small[:, :, 1:].reshape(hi_ - lo_, 2, 512, 15, 16, 16).permute(0, 2, 1, 3, 4, 5)
+        for k, b in enumerate(range(lo_, hi_)):
+            assert abs(eu.compute_loss(dev(ids[b:b + 1]), fs[k:k + 1].contiguous()) - ce[b]) < 2e-3
+    # the batch loss is the masked mean over ALL clips (st_mask_git.py:231-253): frames >= 8 of every clip
+    fl8 = lg[:, :, 8:].reshape(B, 2, 512, 8, 16, 16).permute(0, 2, 1, 3, 4, 5)
+    tgt = dev(ids).view(B, 16, 256)[:, 8:].reshape(B, 8, 16, 16)
+    lp = torch.log_softmax(fl8.float(), dim=1)
+    nll = -(lp[:, :, 0].gather(1, (tgt % 512)[:, None]) + lp[:, :, 1].gather(1, (tgt // 512)[:, None]))
+    assert abs(out.loss.item() - nll.mean().item()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3: generate.py semantics at the GENIE_138M shape, maskgit_steps 2 and 8 (generate.py:77-103)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "exact"])
+def test_config3_generate_c138(precision):
+    z = np.load(f"{GOLDEN}/gen_c138.npz")
+    cfg = pkg("config").GenieConfig(**ast.literal_eval(str(z["cfg"])))
+    sd = pkg("synthetic").make_state_dict(cfg, seed=int(z["weight_seed"]), law="conditioned")
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+    G = pkg("generate")
+    ex = dev(z["ids"]).view(1, 16, 16, 16)
+    ROBUST = 6e-5   # top-2 logit gap of the reference run below which f32 accumulation order may flip an argmax
+    for steps in (2, 8):
+        ref = z[f"gen_s{steps}_outputs"].astype(np.int64)           # (1, 24, 16, 16): [prompt | generated | gt]
+        gaps = z[f"gen_s{steps}_frame_gap"]
+        noise = dev(z[f"gen_s{steps}_noise"])                        # (8, steps-1, 1, S)
+        # (1) every generated frame on its own, prompted by the REFERENCE's earlier frames (no error propagation)
+        for k, t in enumerate(range(8, 16)):
+            prompt = torch.full((1, 16, 16, 16), cfg.image_vocab_size, dtype=torch.int64, device="cuda")
+            prompt[:, :8] = ex[:, :8]
+            prompt[:, 8:t] = dev(ref[:, 8:t])
+            s, _ = m.maskgit_generate(prompt, t, maskgit_steps=steps, temperature=0.0, noise=noise[k])
+            same = (s.cpu().numpy() == ref[:, t])
+            assert prompt[:, t].equal(s)                              # in-place write-back (st_mask_git.py:223)
+            if gaps[k] > ROBUST:
+                assert same.all(), (steps, t, int((~same).sum()), gaps[k])
+            else:
+                assert same.mean() > 0.97, (steps, t, same.mean(), gaps[k])
+        # (2) the generate.py loop itself: identical up to the first fragile frame, output layout always
+        out = G.generate_frames(m, ex, num_prompt_frames=8, maskgit_steps=steps, temperature=0.0, noise=noise).cpu().numpy()
+        assert out.shape == (1, 24, 16, 16)
+        assert np.array_equal(out[:, :8], ref[:, :8]) and np.array_equal(out[:, 16:], ref[:, 16:])
+        n_ok = 0
+        while n_ok < 8 and gaps[n_ok] > ROBUST:
+            n_ok += 1
+        assert np.array_equal(out[:, 8:8 + n_ok], ref[:, 8:8 + n_ok]), (steps, n_ok)
+        assert (out[:, 8:16] == ref[:, 8:16]).mean() > (0.9 if n_ok < 8 else 0.9999)
+        if precision == "f16x3" and steps == 2:
+            # the temporal-KV-cache schedule produces the same frames (genie_frame_pass)
+            outc = G.generate_frames_cached(m, ex, 8, steps, 0.0, False, noise=noise).cpu().numpy()
+            assert np.array_equal(outc[:, 8:8 + n_ok], ref[:, 8:8 + n_ok])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 5: shipped-size MAGVIT2 ends and the encode -> sample -> decode chain
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def vq_full():
+    mv = pkg("magvit2")
+    z = np.load(f"{GOLDEN}/magvit_full.npz")
+    m = mv.VQModel(mv.VQConfig())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in mv.make_vq_state_dict(m, int(z["weight_seed"])).items()})
+    return z, m.to("cuda"), mv
+
+
+def test_config5_decoder_shipped_size(vq_full):
+    """One 16x16-token frame -> 256x256 RGB through the hand-written conv stack (512..128 channels, 16^2..256^2), against
+    the reference Decoder (improved_model.py:162-182).  The bar is the reference's OWN bf16-vs-f32 error on the same
+    input (the reference runs this module in bf16, visualize.py:97-101)."""
+    z, m, mv = vq_full
+    hd = mv.HipDecoder(m.decoder)
+    tok = dev(z["dec_tokens"])
+    ref32 = z["dec_u8_f32"].astype(np.int32)
+    ref16 = z["dec_u8_bf16"].astype(np.int32)
+    own = np.abs(ref16 - ref32)                                       # reference bf16 module vs reference f32 module
+    u8 = hd.decode_tokens(tok).cpu().numpy().astype(np.int32)
+    assert u8.shape == ref32.shape == (1, 3, 256, 256)
+    d = np.abs(u8 - ref32)
+    print("decoder u8 |hip - ref f32| mean/max", d.mean(), d.max(), " reference's own bf16-vs-f32", own.mean(), own.max())
+    assert d.mean() <= 1.1 * own.mean() + 0.05 and d.max() <= own.max() + 2
+    y = hd.decode_tokens(tok, return_float=True).cpu().numpy()
+    yref = z["dec_out_f32"]
+    y16 = (z["dec_out_bf16_bits"].view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+    e_own = np.abs(y16 - yref)
+    e = np.abs(y - yref)
+    assert np.median(e) <= 1.25 * np.median(e_own) + 1e-4 and e.max() <= 1.5 * e_own.max()
+
+
+def test_config5_encoder_shipped_size(vq_full):
+    """One 256x256 RGB frame -> 256 tokens (improved_model.py:103-121 + the dataset bit convention)."""
+    z, m, mv = vq_full
+    he = mv.HipEncoder(m.encoder)
+    ids = he.encode_tokens(dev(z["enc_frames"])).cpu().numpy()
+    h32, h16 = z["enc_h_f32"], z["enc_h_bf16_as_f32"]
+    assert ids.shape == (1, 16, 16)
+    bits = (ids[:, None] >> np.arange(18)[None, :, None, None]) & 1
+    ref_bits = (h32 > 0).astype(np.int64)
+    own_flips = int(((h16 > 0) != (h32 > 0)).sum())                   # the reference's own bf16 module vs its f32 module
+    flips = int((bits != ref_bits).sum())
+    print("encoder bit flips vs reference f32:", flips, "reference bf16 module's own:", own_flips, "of", bits.size)
+    assert flips <= 2 * own_flips + 8
+    robust = np.abs(h32) > 6 * np.abs(h16 - h32).std()                # codes far from zero relative to bf16 noise
+    assert np.array_equal(bits[robust], ref_bits[robust])
+
+
+def test_config5_encode_sample_decode_chain(vq_full):
+    """encode -> GENIE sample -> decode with tokens and frames resident in HBM (visualize.py:95-122, eval_utils.py:28-41
+    round-trip them through NumPy / PIL): the chain equals the composition of its separately verified stages."""
+    z, m, mv = vq_full
+    G = pkg("generate")
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=2, d_model=128, T=16, S=256, num_factored_vocabs=2,
+                                    qk_norm=False, use_mup=False)
+    sd = pkg("synthetic").make_state_dict(cfg, seed=51, law="conditioned")
+    model = pkg("st_mask_git").STMaskGIT(cfg, precision="f16x3").load_numpy_state_dict(sd).to("cuda")
+    he, hd = mv.HipEncoder(m.encoder), mv.HipDecoder(m.decoder)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = dev(z["enc_frames"]).float()
+    frames = (base + torch.randn(16, 3, 256, 256, device="cuda", generator=g) * 20).clamp(0, 255).to(torch.uint8)
+    tokens = he.encode_tokens(frames)                                 # (16, 16, 16) int64 on the device
+    assert tokens.is_cuda and tokens.dtype == torch.int64 and int(tokens.max()) < 2 ** 18
+    clip = tokens.view(1, 16, 16, 16)
+    noise = torch.rand(8, 1, 1, 256, device="cuda", generator=g)
+    out = G.generate_frames(model, clip, num_prompt_frames=8, maskgit_steps=2, temperature=0.0, noise=noise)
+    gen = out[:, 8:16].reshape(8, 16, 16)
+    rgb = hd.decode_tokens(gen)
+    assert rgb.is_cuda and rgb.dtype == torch.uint8 and tuple(rgb.shape) == (8, 3, 256, 256)
+    # stage 2 against the oracle on the SAME tokens (first generated frame: no propagation)
+    p = clip.cpu().numpy().copy()
+    p[:, 8:] = cfg.image_vocab_size
+    s_o, _ = O.maskgit_generate(p, 8, sd, cfg, 2, 0.0, "random", noise=noise[0].cpu().numpy())
+    assert (gen[0].cpu().numpy() == s_o[0]).mean() > 0.995
+    # stage 3 is bit-reproducible (order-fixed GroupNorm statistics), and the reference-shaped wrapper
+    # (visualize.py:95-122) is the same conv stack, batched differently
+    assert torch.equal(hd.decode_tokens(gen), rgb)
+    w = mv.decode_latents_wrapper(batch_size=4, model=m)(gen)
+    assert w.is_cuda and w.dtype == torch.uint8 and torch.equal(w, rgb)
+    # round trip of the tokenizer ends on device: re-encoding decoded frames yields valid tokens
+    assert int(he.encode_tokens(rgb).max()) < 2 ** 18

@@ -61,26 +61,18 @@ def test_tokenizer_byte_and_bit_kernels(magvit):
     assert mv.rescale_magvit_output(e).cpu().tolist() == [0, 0, 0, 127, 254, 255, 255]
 
 
-def test_decode_encode_on_device(magvit):
+def test_single_backend(magvit):
+    """The product package executes MAGVIT2 only on the hand-written conv stack: the nn.Modules are parameter holders and an
+    uncovered geometry (the 32/64-wide toy config) is an error, not a silent torch/MIOpen fallback."""
     mv = pkg("magvit2")
     small = ast.literal_eval(str(magvit["cfg"]))
-    m = mv.VQModel(mv.VQConfig(**small))
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in mv.make_vq_state_dict(m, int(magvit["weight_seed"])).items()})
-    m = m.to("cuda")
-    tok = dev(magvit["dec_tokens"])
-    u8 = m.decode_tokens(tok).cpu().numpy().astype(np.int32)  # f32 decoder on the GPU
-    ref = magvit["dec_u8_f32"].astype(np.int32)
-    assert np.abs(u8 - ref).max() <= 1 and (u8 != ref).mean() < 0.01  # conv accumulation order: <= 1 level
-    y = m.decoder(mv.bits_from_tokens(tok)).cpu().numpy()
-    assert np.abs(y - magvit["dec_out_f32"]).max() < 2e-4
-    ids = m.encode_tokens(dev(magvit["enc_frames"])).cpu().numpy()
-    assert np.array_equal(ids, O.tokens_from_bits(magvit["enc_h"]))  # |h| >= 3e-3 in the fixture: sign is robust
-    # bf16 module like the reference's decode_latents_wrapper; tokens and frames stay on the device
-    dl = mv.decode_latents_wrapper(batch_size=1, model=m)
-    frames = dl(tok)
-    assert frames.is_cuda and frames.dtype == torch.uint8 and tuple(frames.shape) == (2, 3, 8, 8)
-    d = np.abs(frames.cpu().numpy().astype(np.int32) - magvit["dec_u8_bf16"].astype(np.int32))
-    assert np.median(d) <= 2 and d.mean() < 4  # bf16 conv stack vs the reference's bf16 CPU run
+    m = mv.VQModel(mv.VQConfig(**small)).to("cuda")
+    with pytest.raises(RuntimeError, match="parameter holder"):
+        m.decoder(torch.zeros(1, 18, 4, 4, device="cuda"))
+    with pytest.raises(ValueError, match="multiples of 64"):
+        m.decode_tokens(dev(magvit["dec_tokens"]))
+    with pytest.raises(ValueError, match="multiples of 64"):
+        mv.decode_latents_wrapper(batch_size=1, model=m)
 
 
 def test_hip_decoder_conv_stack(magvit):
@@ -104,10 +96,16 @@ def test_hip_decoder_conv_stack(magvit):
     u8 = hd.decode_tokens(tok).cpu().numpy().astype(np.int32)
     d = np.abs(u8 - z["dec_u8_f32"].astype(np.int32))
     assert np.median(d) <= 2 and d.mean() < 3
-    # agrees with the MIOpen bf16 run of the same module at the same level
-    mb = m.to(torch.bfloat16)
-    ym = mb.decoder(mv.bits_from_tokens(tok).to(torch.bfloat16)).float().cpu().numpy()
+    # the torch formulation (oracle, MIOpen bf16 convs on this GPU) of the same parameters sits at the same distance
+    from oracle import magvit2_oracle as MO
+    import copy
+    mb = copy.deepcopy(m).to(torch.bfloat16)
+    ym = MO.decoder_forward(mb.decoder, mv.bits_from_tokens(tok).to(torch.bfloat16)).float().cpu().numpy()
     assert np.abs(ym - ref).max() < 0.08 * scale
+    # VQModel.decode_tokens and the reference-shaped wrapper are this same stack, device-resident
+    assert torch.equal(m.decode_tokens(tok), hd.decode_tokens(tok))
+    frames = mv.decode_latents_wrapper(batch_size=2, model=m)(tok)
+    assert frames.is_cuda and frames.dtype == torch.uint8 and torch.equal(frames, hd.decode_tokens(tok))
 
 
 def test_hip_encoder_conv_stack(magvit):

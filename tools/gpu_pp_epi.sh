@@ -1,0 +1,9 @@
+#!/bin/bash
+B=${1:-48}; TAG=${2:-pp}
+mkdir -p gpurun_out
+{
+for e in 1 0 1 0; do
+  echo "== GENIE_PP_EPI=$e"; GENIE_PP_EPI=$e python tools/bench_gemm.py --batch $B --prec f16x3 bf16 2>/dev/null
+done
+echo "== stamps, compile-time epilogue (ABL 33)"; GENIE_PP_ABL=33 python tools/bench_gemm.py --batch $B --prec f16x3 bf16 2>&1 | grep -E "pp_timing" | awk '{print $2,$3,$4,$5,$6,$8,$11,$13}' | sort | uniq -c | sort -k2 | awk 'NR%7==1'
+} > gpurun_out/${TAG}_epi.log 2>&1

@@ -424,9 +424,99 @@ def magvit_fixture():
     print("magvit_small: dec out range", float(y32.min()), float(y32.max()), "enc |h| min", out["enc_min_abs_h"])
 
 
+def magvit_full_fixture():
+    """The SHIPPED tokenizer geometry (magvit2/config.py:9-43: base 128, ch_mult (1,1,2,2,4), 2 ResBlocks, 18-bit
+    codebook): one 16x16-token frame through the reference Decoder (improved_model.py:162-182) and one 256x256 RGB
+    frame through the reference Encoder (:103-121), each in f32 and as the bf16 module the reference actually runs
+    (visualize.py:97-101), so that the GPU test can hold the hand-written conv stack to the reference's own
+    bf16-vs-f32 error."""
+    from magvit2.config import VQConfig as RefVQ
+    from magvit2.modules.diffusionmodules.improved_model import Encoder as RefEnc, Decoder as RefDec
+    from magvit2.modules.vqvae.lookup_free_quantize import LFQ
+    import visualize as ref_vis
+    mv = importlib.import_module("1xgpt_amd.magvit2")
+    rcfg = RefVQ()
+    mine = mv.VQModel(mv.VQConfig())
+    sd = mv.make_vq_state_dict(mine, seed=3)
+    enc, dec = RefEnc(rcfg), RefDec(rcfg)
+    enc.load_state_dict({k[len("encoder."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("encoder.")})
+    dec.load_state_dict({k[len("decoder."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("decoder.")})
+    enc.eval(), dec.eval()
+    g = np.random.default_rng(31)
+    lfq = LFQ(rcfg)
+    tok = g.integers(0, 262144, size=(1, 16, 16)).astype(np.int64)
+    z = lfq.get_codebook_entry(torch.from_numpy(tok.reshape(1, 256)), bhwc=(1, 16, 16, 18)).flip(1).float()
+    y32 = dec(z)
+    dec16 = RefDec(rcfg)
+    dec16.load_state_dict(dec.state_dict())
+    dec16 = dec16.to(torch.bfloat16).eval()
+    y16 = dec16(z.to(torch.bfloat16))
+    out = {"weight_seed": 3, "dec_tokens": tok, "dec_out_f32": y32.numpy(),
+           "dec_out_bf16_bits": y16.view(torch.int16).numpy(),
+           "dec_u8_f32": ref_vis.rescale_magvit_output(y32).numpy(),
+           "dec_u8_bf16": ref_vis.rescale_magvit_output(y16).numpy()}
+    # a smooth-ish synthetic frame (low-pass noise) so that the encoder sees image-like statistics, plus white noise
+    base = g.standard_normal((1, 3, 32, 32)).astype(np.float32)
+    up = torch.nn.functional.interpolate(torch.from_numpy(base), size=(256, 256), mode="bicubic", align_corners=False)
+    img = (up * 60 + 128 + torch.from_numpy(g.standard_normal((1, 3, 256, 256)).astype(np.float32)) * 12).clamp(0, 255)
+    frames = img.to(torch.uint8).numpy()
+    xin = torch.from_numpy(frames).float() / 127.5 - 1.0
+    h32 = enc(xin)
+    enc16 = RefEnc(rcfg)
+    enc16.load_state_dict(enc.state_dict())
+    enc16 = enc16.to(torch.bfloat16).eval()
+    h16 = enc16(xin.to(torch.bfloat16))
+    out.update({"enc_frames": frames, "enc_h_f32": h32.numpy(), "enc_h_bf16_as_f32": h16.float().numpy()})
+    np.savez_compressed(os.path.join(OUT, "magvit_full.npz"), **out)
+    d = (out["dec_u8_bf16"].astype(np.int32) - out["dec_u8_f32"].astype(np.int32))
+    print("magvit_full: dec range", float(y32.min()), float(y32.max()), "ref bf16-vs-f32 u8 |d| mean", np.abs(d).mean(),
+          "max", np.abs(d).max(), "| enc h std", float(h32.std()), "bit flips bf16 vs f32",
+          int(((h32 > 0) != (h16.float() > 0)).sum()), "of", h32.numel())
+
+
+def generate_fixture(name, cfg_kwargs, wseed, clip_seed=300):
+    """BASELINE config 3 at full size: generate.py semantics (generate.py:77-103: prompt 8 frames, sample frames 8..15
+    autoregressively, each with `maskgit_steps` MaskGIT steps at temperature 0) for steps 2 and 8 (schedule
+    st_mask_git.py:199).  Over 8 frames x steps forwards x 512 argmax decisions SOME top-2 logit gap is always within
+    f32 accumulation noise, so the smallest gap is recorded PER FRAME: a test holds frames with a robust gap to
+    bit-exact ids (with the reference's own earlier frames as the prompt) and the fragile ones to near-equality."""
+    model, cfg = build_ref_model(cfg_kwargs, wseed)
+    H = W = math.isqrt(cfg.S)
+    ids = synthetic.make_clips(1, cfg, seed=clip_seed)
+    example = torch.from_numpy(ids).reshape(1, cfg.T, H, W)
+    out = {"clip_seed": clip_seed, "weight_seed": wseed, "ids": ids}
+    for steps in (2, 8):
+        frame_gaps, noises, samples = [], [], []
+        prompt = example.clone()
+        prompt[:, 8:] = model.mask_token_id
+        torch.manual_seed(9000 + steps)
+        for t in range(8, cfg.T):
+            with Recorder(model) as rec:
+                rec.out_t = t
+                s_hw, _ = model.maskgit_generate(prompt, out_t=t, maskgit_steps=steps, temperature=0)
+            samples.append(s_hw)
+            prompt[:, t] = s_hw
+            frame_gaps.append(rec.min_gap if conf_gap(np.stack(rec.noise)) > 0 else 0.0)
+            noises.append(np.stack(rec.noise).reshape(steps - 1, 1, cfg.S))
+            print(f"  {name}: steps={steps} frame {t} min top-2 gap {frame_gaps[-1]:.3e}", flush=True)
+        outs = torch.cat([example[:, :8], torch.stack(samples, 1), example[:, 8:]], 1)
+        out[f"gen_s{steps}_outputs"] = outs.numpy().astype(np.int32)   # [prompt | generated | ground truth], 24 frames
+        out[f"gen_s{steps}_noise"] = np.stack(noises)                    # (8 frames, steps-1, 1, S)
+        out[f"gen_s{steps}_frame_gap"] = np.array(frame_gaps, np.float64)
+    out["mup_pinned"] = np.int64(1)
+    out["cfg"] = np.array(repr(cfg_kwargs))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: frame gaps s2 {out['gen_s2_frame_gap']} s8 {out['gen_s8_frame_gap']}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "shape", "c35", "c138", "harness", "magvit"]
+    which = sys.argv[1:] or ["tiny", "shape", "c35", "c138", "harness", "magvit", "magvit_full", "c138_gen"]
+    if "magvit_full" in which:
+        magvit_full_fixture()
+    if "c138_gen" in which:
+        generate_fixture("gen_c138", dict(num_layers=32, num_heads=8, d_model=512, T=16, S=256,
+                                          num_factored_vocabs=2, qk_norm=False, use_mup=False), 0)
     if "harness" in which:
         harness_fixture()
     if "magvit" in which:
