@@ -42,30 +42,50 @@ def pass_flops(cfg):
     return T * S * (L * (32 * d * d + 4 * S * d + 4 * T * d) + 2 * d * V)
 
 
-def cpu_baseline(cfg, sd, clips, maskgit_steps, timesteps=(8,), max_threads=32):
-    """Oracle (NumPy port of the reference path) on the host cores: a bounded sample of the same workload.
-    BLAS threads are capped at `max_threads`: on a 128-core host the 4096x512 GEMMs of one clip do not scale
-    further and oversubscription makes the run slower."""
+def cpu_baseline(cfg, sd, clips, maskgit_steps, budget_s=20.0):
+    """The CPU path beside the GPU number: the torch-CPU restatement of the reference forward (oracle/genie_torch_port.py:
+    the ops genie/evaluate.py executes with device="cpu") driving the oracle's MaskGIT loop, on this host's cores.
+    Bounded sample of the same workload: clip 0, as many of the 15 timesteps as fit in ~`budget_s` seconds (each =
+    `maskgit_steps` full forwards), after picking the fastest intra-op thread count among a few candidates (one forward
+    each).  frames/s of a full clip = this rate (every timestep costs the same: a full 16-frame forward per step)."""
     O = importlib.import_module("oracle.genie_oracle")
+    TP = importlib.import_module("oracle.genie_torch_port")
     synth = importlib.import_module("1xgpt_amd.synthetic")
-    from threadpoolctl import threadpool_info, threadpool_limits
-    ids = clips[:1]
     H = W = int(round(cfg.S ** 0.5))
-    x = ids.reshape(1, cfg.T, H, W)
-    noise = synth.make_noise((len(timesteps), max(maskgit_steps - 1, 1), 1, cfg.S), seed=42)
-    cores = min(max_threads, os.cpu_count() or 1)
-    with threadpool_limits(limits=cores):
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    x = clips[:1].reshape(1, cfg.T, H, W)
+    sdt = TP.to_torch(sd)
+    ncpu = os.cpu_count() or 1
+    prev_threads = torch.get_num_threads()
+    cands = sorted({c for c in (16, 32, 64, ncpu // 2) if 1 <= c <= ncpu}) or [1]
+    probe = {}
+    for c in cands:  # one forward per candidate thread count
+        torch.set_num_threads(c)
         t0 = time.perf_counter()
-        for k, t in enumerate(timesteps):
-            p = x.copy()
-            p[:, t:] = cfg.image_vocab_size
-            O.maskgit_generate(p, t, sd, cfg, maskgit_steps, 0.0, "random", noise=noise[k])
-        dt = time.perf_counter() - t0
-    return {"value": len(timesteps) / dt, "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "sample": f"NumPy/OpenBLAS f32 oracle, 1 clip, timesteps {list(timesteps)} of 1..15, "
-                      f"{maskgit_steps} MaskGIT steps ({len(timesteps) * maskgit_steps} full forwards), "
-                      f"{dt:.1f} s on {os.cpu_count()} logical CPUs"}
+        TP.compute_logits(x, sdt, cfg)
+        probe[c] = time.perf_counter() - t0
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    order = [8, 1, 15, 4, 12, 2, 6, 10, 14, 3, 5, 7, 9, 11, 13]
+    noise = synth.make_noise((len(order), max(maskgit_steps - 1, 1), 1, cfg.S), seed=42)
+    done, t0 = [], time.perf_counter()
+    for k, t in enumerate(order):
+        p = x.copy()
+        p[:, t:] = cfg.image_vocab_size
+        O.maskgit_generate(p, t, sd, cfg, maskgit_steps, 0.0, "random", noise=noise[k],
+                           logits_fn=lambda q: TP.compute_logits(q, sdt, cfg))
+        done.append(t)
+        if time.perf_counter() - t0 + (time.perf_counter() - t0) / len(done) > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(prev_threads)
+    return {"value": len(done) / dt, "unit": "frames/s", "cores": int(best), "kind": "port",
+            "sample": f"torch-CPU f32 port of the reference forward + oracle MaskGIT loop, clip 0, timesteps {done} of 1..15 "
+                      f"x {maskgit_steps} MaskGIT steps = {len(done) * maskgit_steps} full 16-frame forwards in {dt:.1f} s "
+                      f"({dt / (len(done) * maskgit_steps):.2f} s/forward); a full clip (15 timesteps) extrapolates to "
+                      f"{15 * dt / len(done):.0f} s; {ncpu} logical CPUs, intra-op threads {best} picked from "
+                      + ", ".join(f"{c}: {v:.2f} s/forward" for c, v in sorted(probe.items())),
+            "reference_cpu_anchor": "SURVEY.md 8(d): the reference itself (genie/evaluate.py path, torch 2.10 CPU) in the build "
+                                    "container, 8 threads of a 2.1 GHz Xeon: 2.81 s per C138-shape forward = 0.19 frames/s"}
 
 
 def train_leg(cfg, dev, dist_mod, rank, world, precision, batch, steps):
@@ -203,7 +223,8 @@ def main():
         step()
     # timed region: exactly K steps, GEMM launches bracketed by HIP events on the launch stream
     if not args.no_events:
-        _lib.check(lib.genie_profile_enable(1 << _lib.KC_GEMM), "profile_enable")
+        _lib.check(lib.genie_profile_enable((1 << _lib.KC_GEMM) | (1 << _lib.KC_ATTN_SPATIAL) |
+                                            (1 << _lib.KC_ATTN_TEMPORAL) | (1 << _lib.KC_LAYERNORM)), "profile_enable")
         lib.genie_profile_reset()
     dist_mod.barrier()
     torch.cuda.synchronize()
@@ -220,8 +241,18 @@ def main():
     seconds = float(tt.item())
     prof = (ctypes.c_double * 4)()
     _lib.check(lib.genie_profile_read(_lib.KC_GEMM, prof), "profile_read")
-    lib.genie_profile_enable(0)
     gemm_launches, gemm_ms, gemm_flops, gemm_bytes = list(prof)
+    other_classes = {}
+    for name, kc in (("attention_spatial", _lib.KC_ATTN_SPATIAL), ("attention_temporal", _lib.KC_ATTN_TEMPORAL),
+                     ("layernorm", _lib.KC_LAYERNORM)):
+        _lib.check(lib.genie_profile_read(kc, prof), "profile_read")
+        n, ms, fl, by = list(prof)
+        if n:
+            other_classes[name] = {"launches": int(n), "avg_launch_ms": ms / n, "achieved_GBps": by / ms / 1e6,
+                                   "achieved_TFLOPs": fl / ms / 1e9, "algorithmic_bytes_per_launch": by / n,
+                                   "share_of_step_time": ms / 1e3 / seconds,
+                                   "frac_of_hbm_peak_8TBps": by / ms / 1e6 / 8000.0}
+    lib.genie_profile_enable(0)
 
     # secondary leg (N=1 only): the same batch through the reference's full-forward schedule, 1 timed step
     full_forward = None
@@ -301,22 +332,41 @@ def main():
         "model_frac_of_mfma_peak": passes_per_step * F * args.steps / seconds / 1e12 / peak,
         "roofline": {
             "kernel": {"exact": "gemm_f32_nt_kernel (v_mfma_f32_32x32x2_f32)",
-                       "f16x3": "gemm16_v2_kernel<2,32,4> (3x v_mfma_f32_32x32x16_f16 per K-step)",
-                       "bf16": "gemm16_v2_kernel<1,64,2> (v_mfma_f32_32x32x16_bf16)"}[args.precision],
+                       "f16x3": "gemm16_pp_kernel<2,3,true,...> (256x256 tile, two-group phase schedule, 3x "
+                                "v_mfma_f32_32x32x16_f16 per algorithmic MFMA into one accumulator)",
+                       "bf16": "gemm16_pp_kernel<1,1,false,...> (256x256 tile, two-group phase schedule, "
+                               "v_mfma_f32_32x32x16_bf16)"}[args.precision],
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "launches": int(gemm_launches), "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
             "flops_per_launch": gemm_flops / max(gemm_launches, 1),
-            "gemm_share_of_step_time": gemm_ms / 1e3 / seconds, "traffic": None},
+            "algorithmic_bytes_per_launch": gemm_bytes / max(gemm_launches, 1),
+            "gemm_share_of_step_time": gemm_ms / 1e3 / seconds, "traffic": None,
+            "timing": "HIP events around every GEMM launch of the timed region, on the launch stream (genie_profile_*)"},
     }
-    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    # Counter-derived figures cannot be collected inside this run (rocprofv3 --pmc serialises kernels and needs its own
+    # passes): they come from the committed PMC summary of this same command and say so.
+    pmc = os.path.join(REPO, "profiles", "pmc_bench.json")
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
-                per_clip = json.load(f).get("per_clip", {}).get(args.precision)
-            out["roofline"]["traffic"] = None if per_clip is None else per_clip * B
-            out["roofline"]["algorithmic_bytes_per_launch"] = gemm_bytes / max(gemm_launches, 1)
-        except Exception:
-            pass
+                pj = json.load(f)
+            pe = pj.get(args.precision, {})
+            g = pe.get("gemm")
+            if g:
+                out["roofline"]["traffic"] = g["hbm_bytes_per_launch_per_clip"] * B
+                out["roofline"]["traffic_source"] = (f"profiles/pmc_bench.json ({pj.get('_source', '')}): FETCH_SIZE x2 "
+                                                     f"(gfx950 correction) + WRITE_SIZE per GEMM launch at {g['clips']} "
+                                                     f"clips, scaled linearly to {B} clips; not measured in this run")
+                out["roofline"]["mfma_busy_frac_pmc"] = g.get("mfma_busy_frac")
+                out["roofline"]["sclk_ghz_pmc"] = g.get("sclk_ghz")
+                out["roofline"]["mfma_note"] = g.get("note")
+            for k in ("attention_spatial", "attention_temporal"):
+                if k in pe and k in other_classes:
+                    other_classes[k]["hbm_bytes_per_launch_pmc"] = pe[k]["hbm_bytes_per_launch_per_clip"] * B
+                    other_classes[k]["mfma_busy_frac_pmc"] = pe[k].get("mfma_busy_frac")
+        except Exception as e:
+            out["roofline"]["traffic_source"] = f"profiles/pmc_bench.json unreadable: {e}"
+    out["kernel_classes"] = other_classes
     if full_forward:
         out["full_forward_schedule"] = full_forward
     if args.precision == "f16x3":

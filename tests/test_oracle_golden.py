@@ -2,6 +2,8 @@
 made by tools/make_goldens.py from the imported reference).  CPU only."""
 import math
 
+import importlib
+
 import numpy as np
 import pytest
 
@@ -163,3 +165,16 @@ def test_full_size_anchor(golden, name):
     assert np.abs(probe - z["probe_logits"]).max() < 2e-4
     s, _ = O.maskgit_generate(x.copy(), 8, sd, cfg, 2, noise=z["mg_s2_noise"])
     assert np.array_equal(s, z["mg_s2_samples"])
+
+
+def test_torch_port_matches_oracle(golden):
+    """oracle/genie_torch_port.py (the torch-CPU restatement timed by bench.py's cpu_baseline) against the reference's
+    golden logits and the NumPy oracle, on every tiny config (LN / qk-norm / muP)."""
+    TP = importlib.import_module("oracle.genie_torch_port")
+    for name in ("tiny_ln", "tiny_qknorm", "tiny_mup", "tiny_qknorm_mup"):
+        z, cfg, sd = golden(name)
+        H = W = int(round(cfg.S ** 0.5))
+        x = z["ids"].reshape(-1, cfg.T, H, W)
+        lg = TP.compute_logits(x, TP.to_torch(sd), cfg)
+        assert np.abs(lg - z["logits"]).max() < 2e-5 * max(1.0, float(np.abs(z["logits"]).max()) / 8)
+        assert np.abs(lg - O.compute_logits(x, sd, cfg)).max() < 2e-5 * max(1.0, float(np.abs(z["logits"]).max()) / 8)
