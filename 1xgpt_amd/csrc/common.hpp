@@ -77,6 +77,27 @@ __device__ __forceinline__ float gelu_erf_fast(float z) {
     return 0.5f * z * (x >= 0.f ? 2.0f - q : q);                                       // 1 + erf(x)
 }
 
+// Two GELUs at once in the packed-f32 form the GEMM epilogues want (v_pk_fma_f32 / v_pk_mul_f32: 2 lanes of math per issue
+// slot).  Same approximation as gelu_erf_fast; the sign handling is folded away:  with q = erfc(|x|), x = z/sqrt(2),
+//   z >= 0: 0.5 z (2 - q) = z - 0.5 |z| q       z < 0: 0.5 z q = -0.5 |z| q        =>  gelu(z) = max(z, 0) - (|x| / sqrt(2)) q
+typedef float genie_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ genie_f2 gelu_erf_fast2(genie_f2 z) {
+    const genie_f2 x = z * 0.70710678118654752440f;
+    const genie_f2 ax = {fabsf(x[0]), fabsf(x[1])};
+    auto splat = [](float c) { return genie_f2{c, c}; };
+    const genie_f2 u = __builtin_elementwise_fma(ax, splat(0.3275911f), splat(1.0f));
+    const genie_f2 t = {__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+    genie_f2 p = __builtin_elementwise_fma(t, splat(1.061405429f), splat(-1.453152027f));
+    p = __builtin_elementwise_fma(p, t, splat(1.421413741f));
+    p = __builtin_elementwise_fma(p, t, splat(-0.284496736f));
+    p = __builtin_elementwise_fma(p, t, splat(0.254829592f));
+    const genie_f2 a2 = ax * ax * -1.4426950408889634f;
+    const genie_f2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+    const genie_f2 w = (p * t) * (e * (ax * 0.70710678118654752440f));
+    const genie_f2 zp = {fmaxf(z[0], 0.f), fmaxf(z[1], 0.f)};
+    return zp - w;
+}
+
 // round-to-nearest-even f32 -> bf16 bits
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     uint32_t u = __float_as_uint(f);
@@ -94,6 +115,22 @@ __device__ __forceinline__ void split_f16(float a, uint16_t& hi, uint16_t& lo) {
     _Float16 l = (_Float16)((a - hf) * 2048.0f);
     hi = __builtin_bit_cast(uint16_t, h);
     lo = __builtin_bit_cast(uint16_t, l);
+}
+
+// The same split for four values at once, on packed conversions (v_cvt_pk_f16_f32: 3 VALU instructions per element instead of
+// ~10) and WITHOUT the flush of a subnormal hi: gfx950's f16 matrix instructions take subnormal inputs exactly (probed on
+// MI355X: A- and B-side subnormals down to 2^-24 give exact sums, tools/_subnormal_probe.py), so hi + lo/2048 is the same
+// 22-bit value either way.  Returns hi pairs in h01 / h23 and lo pairs in l01 / l23 (element 0 in the low half).
+__device__ __forceinline__ void split_f16_x4(float a0, float a1, float a2, float a3, uint32_t& h01, uint32_t& h23,
+                                             uint32_t& l01, uint32_t& l23) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v x = {a0, a1}, y = {a2, a3};
+    const h2v hx = __builtin_convertvector(x, h2v), hy = __builtin_convertvector(y, h2v);
+    const f2v rx = (x - __builtin_convertvector(hx, f2v)) * 2048.0f, ry = (y - __builtin_convertvector(hy, f2v)) * 2048.0f;
+    const h2v lx = __builtin_convertvector(rx, h2v), ly = __builtin_convertvector(ry, h2v);
+    h01 = __builtin_bit_cast(uint32_t, hx); h23 = __builtin_bit_cast(uint32_t, hy);
+    l01 = __builtin_bit_cast(uint32_t, lx); l23 = __builtin_bit_cast(uint32_t, ly);
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -341,7 +341,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             const int row = m0 + wm * 128 + q * 64 + rl;
             float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
             v.x = v.x * ascale + bv.x; v.y = v.y * ascale + bv.y; v.z = v.z * ascale + bv.z; v.w = v.w * ascale + bv.w;
-            if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+            if (do_gelu) {
+                const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+                v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+            }
             const size_t idx = (size_t)row * ldc + col;
             if (do_acc) {
                 const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
@@ -361,21 +364,25 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 }
             }
             if (out16) {
-                if (fl & G16X_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+                if (fl & G16X_GELU16) {
+                    const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+                    v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+                }
                 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
                 auto st2 = [&](uint16_t* p, uint32_t a, uint32_t b) {
                     u2v t = {a, b};
                     if (nts) __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(p));
                     else *reinterpret_cast<u2v*>(p) = t;
                 };
-                if (plane16 == 0) {  // bf16 output
+                const bool split_out = EPI >= 0 ? (NPL == 2) : (plane16 != 0);  // compile-time in the EPI instantiations
+                if (!split_out) {  // bf16 output
                     st2(C16 + idx, (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
                         (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16));
                 } else {             // split f16 planes [hi | lo]
-                    uint16_t h0, l0, h1, l1, h2, l2, h3, l3;
-                    split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3);
-                    st2(C16 + idx, (uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
-                    st2(C16 + (size_t)plane16 + idx, (uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+                    uint32_t h01, h23, l01, l23;
+                    split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
+                    st2(C16 + idx, h01, h23);
+                    st2(C16 + (size_t)plane16 + idx, l01, l23);
                 }
             }
         }
@@ -478,7 +485,8 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
         }
         bool done = false;
         static const int epi = [] { const char* e2 = getenv("GENIE_PP_EPI"); return e2 ? atoi(e2) : 1; }();
-        if (epi && sched == 0 && terms == 3) {
+        const bool out_kind_ok = !(flags & G16X_OUT16) || (npl == 2 ? plane16 != 0 : plane16 == 0);
+        if (epi && sched == 0 && terms == 3 && out_kind_ok) {
             if (npl == 1 && !f16) { PP_EPI_ALL(1, false) }
             else if (npl == 2) { PP_EPI_ALL(2, true) }
         }
