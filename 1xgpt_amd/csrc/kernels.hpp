@@ -141,14 +141,19 @@ int launch_cast_transpose16(int npl, float* in, long ld, const float* z, uint16_
                             int cols, hipStream_t st, float* colpart = nullptr);
 int launch_transpose16(int npl, const uint16_t* in, uint16_t* outT, int rows, int cols, hipStream_t st);
 int launch_cast16(int npl, const float* src, uint16_t* dst, size_t n, hipStream_t st);
-enum { G16X_GELU = 1, G16X_ACCUM = 2, G16X_OUT16 = 4, G16X_OUTF32 = 8, G16X_GELU16 = 16, G16X_NT = 32 };  // = the G16_* flags of kernels_bf16.hip
+enum { G16X_GELU = 1, G16X_ACCUM = 2, G16X_OUT16 = 4, G16X_OUTF32 = 8, G16X_GELU16 = 16, G16X_NT = 32,
+       G16X_QKV = 64 /* gemm16_pp only: the spatial-attention operand layout, see launch_gemm16_pp */ };  // = the G16_* flags of kernels_bf16.hip
 int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                      const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N,
                      int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC);
 // kernels_gemm_pp.hip: the 256x256 two-group phase-scheduled GEMM; GENIE_E_UNSUPPORTED when the shape does not fit it
 int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw,
                      long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M,
-                     int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC);
+                     int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC,
+                     float qscale = 1.0f, int head_dim = 0);
+// kernels_attn_dma.hip: spatial attention over the operand planes written by launch_gemm16_pp(G16X_OUT16 | G16X_QKV)
+int launch_attn_spatial_dma(int npl, const uint16_t* qkv16, long n_seq, int d, int H, int Dh, uint16_t* out16, size_t out_plane,
+                            hipStream_t st);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, float grad_mult, const double* sumsq, float max_norm, hipStream_t st);
 

@@ -649,6 +649,28 @@ __global__ void cast16_kernel(const float* __restrict__ src, uint16_t* __restric
     if (i < n) dst[i] = f32_to_bf16(src[i]);
 }
 
+
+// Spatial attention on the fused operand path: the QKV GEMM writes [Q * scale * log2e | K | V^T] as 16-bit planes in the
+// attention kernel's own layout (kernels_gemm_pp.hip, G16X_QKV) and kernels_attn_dma.hip streams them through LDS -- no f32
+// qkv round trip, no operand split / transpose inside the attention kernel.  Covers the shipped geometry (S = 256, head_dim
+// 32 / 64, d % 256 == 0, LayerNorm blocks, chip-filling batches); anything else returns GENIE_E_UNSUPPORTED and the caller
+// runs the f32-qkv path below.
+static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_layer_weights& lw, const uint16_t* u, size_t planeA,
+                                   size_t planeW, Workspace& w, int B, uint16_t* out16, size_t out_plane, hipStream_t st) {
+    static const int on = [] { const char* e = getenv("GENIE_ATTN_DMA"); return e ? atoi(e) : 1; }();
+    const int d = c.d_model;
+    if (!on || c.S != 256 || c.qk_norm || (c.head_dim != 64 && c.head_dim != 32) || d % 256 || d != c.num_heads * c.head_dim)
+        return GENIE_E_UNSUPPORTED;
+    const long n_seq = (long)B * c.T;
+    const int M = (int)(n_seq * c.S);
+    uint16_t* qkv16 = (uint16_t*)w.big;  // 3 * npl planes of M * d 16-bit values <= the (M, 3d) f32 buffer
+    const int rc = launch_gemm16_pp(npl, 3, npl == 2, u, d, (long)planeA, lw.spatial.qkv_w16, d, (long)planeW,
+                                    c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, nullptr, qkv16, (long)M * d, d, M, 3 * d, d,
+                                    G16X_OUT16 | G16X_QKV, 1.0f, st, 1, 0, 0, 0, c.attn_scale * 1.4426950408889634f, c.head_dim);
+    if (rc != GENIE_OK) return rc;
+    return launch_attn_spatial_dma(npl, qkv16, n_seq, d, c.num_heads, c.head_dim, out16, out_plane, st);
+}
+
 // bf16 precision contract (mirrored by oracle.genie_oracle.BF16_MFMA):
 //   * every nn.Linear operand is bf16 (weights packed once; activations rounded by their producer)
 //   * accumulation, bias, GELU, LayerNorm and the residual stream are f32
@@ -673,14 +695,17 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
         GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
         u = xn16;
     }
+    int rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st);
+    if (rc == GENIE_E_UNSUPPORTED) {
     GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.spatial.qkv_w16, d, 0, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv, nullptr,
                                0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
-    int rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
-                                       nbs, st, xn16, 0);
+    rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
+                                   nbs, st, xn16, 0);
     if (rc == GENIE_E_UNSUPPORTED) {
         GENIE_TRY(launch_attn_generic(qkv, w.logits, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
                                       c.attn_scale, 0, nws, nbs, st));
         rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
+    }
     }
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.spatial.proj_w16, d, 0, c.proj_bias ? lw.spatial.proj_b : nullptr, x, x16,
@@ -783,15 +808,18 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
         GENIE_TRY(launch_layer_norm_split(x, lw.norm1_w, lw.norm1_b, as, pd, M, d, 1e-5f, st));
         u = as;
     }
+    int rc = spatial_attention_fused(2, c, lw, u, pd, pw_qkv, w, B, as, pd, st);
+    if (rc == GENIE_E_UNSUPPORTED) {
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.spatial.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
-    int rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
-                                       nbs, st, as, pd);
+    rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
+                                   nbs, st, as, pd);
     if (rc == GENIE_E_UNSUPPORTED) {  // generic kernel writes f32 into x-sized scratch (logits region), then split
         float* tmp = w.logits;
         GENIE_TRY(launch_attn_generic(qkv, tmp, c.S, (long)B * c.T, 1, c.S, 0, 1, d, c.num_heads, c.head_dim,
                                       c.attn_scale, 0, nws, nbs, st));
         rc = launch_split_f16(tmp, as, pd, pd, st);
+    }
     }
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.spatial.proj_w16, d, pw_proj, c.proj_bias ? lw.spatial.proj_b : nullptr, x,

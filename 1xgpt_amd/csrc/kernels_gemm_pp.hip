@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                                                             const float* __restrict__ bias, float* __restrict__ Cf,
                                                             uint16_t* __restrict__ C16, long plane16, long ldc, int M, int N,
                                                             int K, int flags, float alpha, long strideA, long strideC,
-                                                            const float* Rf, long strideW) {
+                                                            const float* Rf, long strideW, float qscale, int head_dim) {
     constexpr int KK = NPL == 1 ? 4 : 2;  // k16 steps per K-tile
     constexpr int BK = 16 * KK;
     constexpr int BM = 256, BN = 256;
@@ -325,6 +325,104 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     const int col = n0 + wn * 64 + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+    if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0) {
+        // ---- spatial-attention operand layout (N = 3d, d % 256 == 0, so a 256-column tile is all-Q, all-K or all-V; the 256
+        // rows of a tile are exactly one (clip, frame) sequence).  C16 holds 3*NPL planes of M*d 16-bit values:
+        //   [Q planes | K planes | V^T planes], Q and K row-major (M, d) with Q multiplied by qscale (= scale * log2 e),
+        //   V^T as [(sequence, head)][feature][256 keys]: what kernels_attn_dma.hip streams straight into LDS.
+        const int dm = N / 3;
+        const int which = n0 / dm;                       // 0 Q, 1 K, 2 V  (block-uniform)
+        const size_t P = (size_t)plane16;               // = M * d
+        uint16_t* base = C16 + (size_t)which * NPL * P;
+        const float4 bvq = bv;
+        if (which < 2) {
+            const float qs = which == 0 ? qscale : 1.0f;
+            const int colq = n0 - which * dm + wn * 64 + c4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q * 2 + i][j][e];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int rl = it * 4 + (lane >> 4);
+                    const size_t idx = (size_t)(m0 + wm * 128 + q * 64 + rl) * dm + colq;
+                    float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+                    v.x = (v.x * ascale + bvq.x) * qs; v.y = (v.y * ascale + bvq.y) * qs;
+                    v.z = (v.z * ascale + bvq.z) * qs; v.w = (v.w * ascale + bvq.w) * qs;
+                    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                    if constexpr (NPL == 1) {
+                        const u2v t = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
+                                       (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16)};
+                        __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(base + idx));
+                    } else {
+                        uint32_t h01, h23, l01, l23;
+                        split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
+                        const u2v th = {h01, h23}, tl = {l01, l23};
+                        __builtin_nontemporal_store(th, reinterpret_cast<u2v*>(base + idx));
+                        __builtin_nontemporal_store(tl, reinterpret_cast<u2v*>(base + P + idx));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            // V tiles: the accumulators already hold one COLUMN (feature) per lane with 4 consecutive rows (keys) per register
+            // group, so they go to LDS as [feature][key] with float4 writes (16-byte slot XOR (feature & 15): conflict-free on
+            // both sides) and come back as 8 consecutive keys of one feature per lane = one 16-byte store per 16-bit plane.
+            const int seq = m0 >> 8;
+            const int Hn = dm / head_dim;
+            const int fl8 = lane >> 3, kq = lane & 7;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int c = j * 32 + r, ks = i * 8 + 2 * g + h;
+                            *reinterpret_cast<float4*>(ct + c * 64 + ((ks ^ (c & 15)) << 2)) =
+                                make_float4(acc[q * 2 + i][j][4 * g], acc[q * 2 + i][j][4 * g + 1], acc[q * 2 + i][j][4 * g + 2],
+                                            acc[q * 2 + i][j][4 * g + 3]);
+                        }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int c = it * 8 + fl8;                                  // feature column inside the wave's 64
+                    const int cv = n0 - 2 * dm + wn * 64 + c;                    // feature column inside d
+                    const float4 a = *reinterpret_cast<const float4*>(ct + c * 64 + (((2 * kq) ^ (c & 15)) << 2));
+                    const float4 b = *reinterpret_cast<const float4*>(ct + c * 64 + (((2 * kq + 1) ^ (c & 15)) << 2));
+                    const float bb = bias ? bias[n0 + wn * 64 + c] : 0.f;
+                    const int head = cv / head_dim, f = cv - head * head_dim;
+                    const size_t idx = (((size_t)seq * Hn + head) * head_dim + f) * 256 + wm * 128 + q * 64 + kq * 8;
+                    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                    const float v0 = a.x * ascale + bb, v1 = a.y * ascale + bb, v2 = a.z * ascale + bb, v3 = a.w * ascale + bb;
+                    const float v4 = b.x * ascale + bb, v5 = b.y * ascale + bb, v6 = b.z * ascale + bb, v7 = b.w * ascale + bb;
+                    if constexpr (NPL == 1) {
+                        const u4v t = {(uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16),
+                                       (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16),
+                                       (uint32_t)f32_to_bf16(v4) | ((uint32_t)f32_to_bf16(v5) << 16),
+                                       (uint32_t)f32_to_bf16(v6) | ((uint32_t)f32_to_bf16(v7) << 16)};
+                        __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(base + idx));
+                    } else {
+                        uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
+                        split_f16_x4(v0, v1, v2, v3, h01, h23, l01, l23);
+                        split_f16_x4(v4, v5, v6, v7, h45, h67, l45, l67);
+                        const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
+                        __builtin_nontemporal_store(th, reinterpret_cast<u4v*>(base + idx));
+                        __builtin_nontemporal_store(tl, reinterpret_cast<u4v*>(base + P + idx));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
@@ -403,8 +501,20 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
 // operands (f16 = 1); npl = 2: split-f16 operands, terms = 3 (f32-class) or 2.
 int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw,
                      long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M,
-                     int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC) {
+                     int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC,
+                     float qscale, int head_dim) {
     const int bk = npl == 1 ? 64 : 32;
+    if (flags & G16X_QKV) {  // C16 = [Q | K | V^T] operand planes of the spatial attention (plane16 = M * d, ldc unused)
+        if (N % 3 || (N / 3) % 256 || M % 256 || batch != 1 || head_dim <= 0 || (N / 3) % head_dim || 64 % head_dim ||
+            !(flags & G16X_OUT16) || (flags & (G16X_ACCUM | G16X_GELU | G16X_OUTF32 | G16X_GELU16)) || f16 != (npl == 2) ||
+            terms != 3)
+            return GENIE_E_UNSUPPORTED;
+        const char* e1 = getenv("GENIE_PP_ABL");
+        const char* e2 = getenv("GENIE_PP_EPI");
+        const char* e3 = getenv("GENIE_PP_SCHED");
+        if ((e1 && atoi(e1)) || (e2 && !atoi(e2)) || (e3 && atoi(e3))) return GENIE_E_UNSUPPORTED;  // study knobs: no QKV variant
+        flags |= G16X_NT;
+    }
     if (M < 256 || M % 256 || N % 256 || K % (2 * bk) || K < 2 * bk) return GENIE_E_UNSUPPORTED;
     if (lda % 8 || ldw % 8 || ldc % 4) return GENIE_E_UNSUPPORTED;
     // 32-bit byte offsets inside one tile's buffer descriptor
@@ -430,7 +540,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
         gemm16_pp_kernel<NPL_, TERMS_, F16_, ABL_, SCHED_><<<grid, 512, lds, st>>>(                                       \
             A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,     \
-            strideW);                                                                                                     \
+            strideW, qscale, head_dim);                                                                                                     \
     } while (0)
 #define PP_LAUNCH_ABL(ABL_)                                                                                               \
     do {                                                                                                                  \
@@ -454,21 +564,21 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     else if (abl == 32) PP_LAUNCH_ABL(32);
     else if (abl == 33) {  // stamps with the compile-time OUTF32 | NT epilogue
         if (npl == 1) { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW); }
+            gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim); }
         else { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW); }
+            gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim); }
     }
     else {
         // compile-time epilogues for the model's Linear flavours (qkv / readout: OUTF32; proj, fc2: ACCUM | OUTF32 [| OUT16];
         // fc1: GELU | OUT16), each with and without non-temporal stores; anything else takes the run-time-flag kernel
-        const int e = flags & 63;
+        const int e = flags & 127;
 #define PP_EPI(NPL_, F16_, E_)                                                                                            \
         case E_: {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, 0, E_>,           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, 0, E_><<<grid, 512, lds, st>>>(                          \
                 A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,  \
-                strideW);                                                                                                 \
+                strideW, qscale, head_dim);                                                                                                 \
             done = true;                                                                                                  \
         } break;
 #define PP_EPI_ALL(NPL_, F16_)                                                                                            \
@@ -481,11 +591,12 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
             PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32 | G16X_OUT16 | G16X_NT)                                           \
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16)                                                                    \
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16 | G16X_NT)                                                          \
+            PP_EPI(NPL_, F16_, G16X_OUT16 | G16X_QKV | G16X_NT)                                                           \
             default: break;                                                                                               \
         }
         bool done = false;
         static const int epi = [] { const char* e2 = getenv("GENIE_PP_EPI"); return e2 ? atoi(e2) : 1; }();
-        const bool out_kind_ok = !(flags & G16X_OUT16) || (npl == 2 ? plane16 != 0 : plane16 == 0);
+        const bool out_kind_ok = !(flags & G16X_OUT16) || (flags & G16X_QKV) || (npl == 2 ? plane16 != 0 : plane16 == 0);
         if (epi && sched == 0 && terms == 3 && out_kind_ok) {
             if (npl == 1 && !f16) { PP_EPI_ALL(1, false) }
             else if (npl == 2) { PP_EPI_ALL(2, true) }

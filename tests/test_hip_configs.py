@@ -30,9 +30,12 @@ def _probe(lg, ts, ss):
 # batched shapes: 12 clips x 4096 tokens fill the chip with 256x256 GEMM tiles (kernels_gemm_pp.hip, every epilogue
 # flavour of the block: qkv OUTF32, proj ACCUM|OUTF32|OUT16, fc1 GELU|OUT16, fc2 ACCUM|OUTF32)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision,nm,tol", [("f16x3", O.F32, 5e-5), ("bf16", O.BF16_MFMA, None)])
-def test_batched_forward_vs_oracle(precision, nm, tol):
-    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=8, d_model=512, T=16, S=256, num_factored_vocabs=2,
+@pytest.mark.parametrize("precision,nm,tol,width", [("f16x3", O.F32, 5e-5, 512), ("bf16", O.BF16_MFMA, None, 512),
+                                                    ("f16x3", O.F32, 5e-5, 256)])
+def test_batched_forward_vs_oracle(precision, nm, tol, width):
+    """width 512 = 8 heads of 64 (GENIE_138M shape), width 256 = 8 heads of 32 (the shipped 35M config): both geometries of
+    the fused spatial-attention path (QKV GEMM writing [Q | K | V^T] operand planes -> kernels_attn_dma.hip)."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=8, d_model=width, T=16, S=256, num_factored_vocabs=2,
                                     qk_norm=False, use_mup=False)
     synth = pkg("synthetic")
     sd = synth.make_state_dict(cfg, seed=41, law="conditioned")
