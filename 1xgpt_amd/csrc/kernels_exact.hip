@@ -1113,11 +1113,12 @@ __device__ __forceinline__ void store_row_chunk(float* out, uint16_t* out16, siz
 template <int DH>
 __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float* __restrict__ qkv,
                                                                      float* __restrict__ out, long n_bs, int S,
-                                                                     int d, int H, float scale,
+                                                                     int d, int H, int T, float scale,
                                                                      const float* __restrict__ nw,
                                                                      const float* __restrict__ nb,
                                                                      uint16_t* __restrict__ out16, size_t plane) {
-    constexpr int T = 16, PER = DH / 4;  // floats per lane per row
+    constexpr int PER = DH / 4;  // floats per lane per row; T <= 16 frames fill a 16x16 tile (rows >= T are padding:
+                                 // they repeat frame T-1 on the load side and are never stored)
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1127,7 +1128,7 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     const long b = bs / S, s = bs - b * S;
     const long tok_stride = (long)S * 3 * d;                       // frame t -> t+1
     const float* base = qkv + ((size_t)(b * T) * S + s) * 3 * d + head * DH;
-    const float* qp = base + (size_t)r * tok_stride + g * PER;     // row t = r
+    const float* qp = base + (size_t)(r < T ? r : T - 1) * tok_stride + g * PER;     // row t = r
     float q[PER], k[PER];
 #pragma unroll
     for (int c = 0; c < PER / 4; ++c) {
@@ -1177,15 +1178,15 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     // O = P V.  Feature permutation: MFMA column r of "d-tile" c is feature NV*r + c, so a lane fetches NV
     // CONTIGUOUS features of V[4g+e] (16 lanes = one 4*DH-byte row segment) and later stores NV contiguous outputs.
     constexpr int NV = DH / 16;
-    const float* vp = base + 2 * d + (size_t)(4 * g) * tok_stride + NV * r;
+    const float* vp = base + 2 * d + NV * r;
     float vv[4][NV];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if constexpr (NV == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(vp + (size_t)e * tok_stride);
+            const float4 t = *reinterpret_cast<const float4*>(vp + (size_t)(4 * g + e < T ? 4 * g + e : T - 1) * tok_stride);
             vv[e][0] = t.x; vv[e][1] = t.y; vv[e][2] = t.z; vv[e][3] = t.w;
         } else {
-            const float2 t = *reinterpret_cast<const float2*>(vp + (size_t)e * tok_stride);
+            const float2 t = *reinterpret_cast<const float2*>(vp + (size_t)(4 * g + e < T ? 4 * g + e : T - 1) * tok_stride);
             vv[e][0] = t.x; vv[e][1] = t.y;
         }
     }
@@ -1200,6 +1201,7 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + NV * r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        if (4 * g + e >= T) continue;
         const size_t oi = obase + (size_t)(4 * g + e) * S * d;
         float ov[NV];
 #pragma unroll
@@ -1208,15 +1210,15 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     }
 }
 
-// Temporal attention over T = 16 frames on a (B,T,S,3d) buffer; GENIE_E_UNSUPPORTED for other geometries.
+// Temporal attention over 8 <= T <= 16 frames on a (B,T,S,3d) buffer; GENIE_E_UNSUPPORTED for other geometries.
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
                                   const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
-    if (T != 16 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
+    if (T > 16 || T < 8 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
     const long n_bs = (long)B * S, waves = n_bs * H;
     ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 16.0, st);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb, out16, plane);
-    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, scale, nw, nb, out16, plane);
+    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, scale, nw, nb, out16, plane);
+    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, scale, nw, nb, out16, plane);
     GENIE_LAUNCH_CHECK("attn_temporal_f32_mfma");
     return GENIE_OK;
 }

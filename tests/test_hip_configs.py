@@ -60,6 +60,24 @@ def test_batched_forward_vs_oracle(precision, nm, tol, width):
     assert d < (2e-5 if precision == "f16x3" else 8e-2), d
 
 
+@pytest.mark.parametrize("T,heads,width", [(8, 2, 128), (12, 4, 128), (9, 2, 64)])
+def test_short_window_temporal_mfma(T, heads, width):
+    """Windows shorter than 16 frames (generate.py / RawTokenDataset window_size < 16) run the 16x16 MFMA temporal kernel
+    with padded rows (kernels_exact.hip attn_temporal_f32_mfma_kernel, 8 <= T <= 16): logits against the f64-accumulating oracle."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=heads, d_model=width, T=T, S=16, num_factored_vocabs=2,
+                                    qk_norm=(T == 12), use_mup=False)
+    synth = pkg("synthetic")
+    sd = synth.make_state_dict(cfg, seed=T, law="conditioned")
+    ids = synth.make_clips(3, cfg, seed=T + 1)
+    x = ids.reshape(3, T, 4, 4).copy()
+    x[:, T // 2:] = cfg.image_vocab_size
+    for precision, tol in (("exact", 3e-5), ("f16x3", 5e-5)):
+        m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+        lg = m.compute_logits(dev(x)).cpu().numpy()
+        ref = O.compute_logits(x, sd, cfg, O.F32)
+        assert np.abs(lg - ref).max() < tol, (precision, T, np.abs(lg - ref).max())
+
+
 def test_split_gemm_range_edges():
     """f16x3 operands near both ends of the f16 range: activations up to 3e4, down to 1e-6 (hi is
     flushed below 6.1e-5 and lo alone carries the value), weights up to 16 (the in-register 2^11 scaling of the weight's hi
