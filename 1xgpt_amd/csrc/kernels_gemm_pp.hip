@@ -93,27 +93,34 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     const int wm = wid >> 2, wn = wid & 3;
     const int r = lane & 31, h = lane >> 5;
 
-    // XCD-aware tile order: the 8 m-tiles of a group go to the 8 XCDs (block b runs on XCD b % 8) and each XCD walks
-    // the n-tiles of ITS m-tile, so an A row panel is fetched into one L2 only
+    // PERSISTENT: one workgroup per CU walks tiles bid, bid + gridDim.x, ... (the hardware hands block b to XCD b % 8, so the
+    // walk stays on one XCD).  XCD-aware tile order: the 8 m-tiles of a group go to the 8 XCDs and each XCD walks the n-tiles
+    // of ITS m-tile, so an A row panel is fetched into one L2 only.
     const int mt = M / BM, nt_n = N / BN;
-    int bid = blockIdx.x, m_tile, n_tile;
+    const int ntiles = mt * nt_n;
     const int full = (mt / 8) * 8 * nt_n;
-    if (bid < full) {
-        const int grp = bid / (8 * nt_n), rem = bid - grp * 8 * nt_n;
-        m_tile = grp * 8 + (rem & 7);
-        n_tile = rem >> 3;
-    } else {
-        const int rem = bid - full;
-        m_tile = (mt / 8) * 8 + rem / nt_n;
-        n_tile = rem % nt_n;
-    }
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
-    A += (size_t)blockIdx.y * strideA + (size_t)m0 * lda;
-    W += (size_t)blockIdx.y * strideW + (size_t)n0 * ldw;
+    auto tile_origin = [&](int bid, int& m0_, int& n0_) {
+        int m_tile, n_tile;
+        if (bid < full) {
+            const int grp = bid / (8 * nt_n), rem = bid - grp * 8 * nt_n;
+            m_tile = grp * 8 + (rem & 7);
+            n_tile = rem >> 3;
+        } else {
+            const int rem = bid - full;
+            m_tile = (mt / 8) * 8 + rem / nt_n;
+            n_tile = rem % nt_n;
+        }
+        m0_ = m_tile * BM;
+        n0_ = n_tile * BN;
+    };
+    A += (size_t)blockIdx.y * strideA;
+    W += (size_t)blockIdx.y * strideW;
 
     // ---- staging: LDS-DMA through buffer descriptors (voffset per lane, K / late-half offset in the scalar offset)
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
+    int bid = blockIdx.x, m0, n0;
+    tile_origin(bid, m0, n0);
+    auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, -1, 0x00020000);
+    auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, -1, 0x00020000);
     unsigned voffA[2], voffB[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -149,12 +156,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     }
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     s16x8 fa[2][4];      // the current 64-row A sub-tile: [row tile][c]
     s16x8 fb[2][4];      // both 32-column B sub-tiles:    [sub][c]
@@ -279,220 +280,247 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
         }
     }
     unsigned long long tstamp[4];
-    if constexpr (ABL & 32) tstamp[0] = __builtin_amdgcn_s_memtime();
-    stage(0, 0, 0);
-    stage(2, 0, 0);
-    stage(3, 0, 0);
-    stage(1, 0, 0);
-    stage(0, 1, 1);
-    stage(2, 1, 1);
-    wait_vmcnt<8>();  // A-early(0), B-early(0) of this wave have landed
-    wg_barrier();
-    if constexpr (ABL & 32) tstamp[1] = __builtin_amdgcn_s_memtime();
-    if (wm == 1) wg_barrier();  // group 1 runs one barrier behind group 0
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    if constexpr (ABL & 2) {  // fragments are read once, here
-        wait_vmcnt<0>();
-        wg_barrier();
-        read_a(0, 0); read_b(0, 0); read_b(0, 1);
-        scale_b(0); scale_b(1);
-        wg_barrier();
-    }
-    in_loop = true;
-    for (int t = 0; t + 2 < nk; t += 2) {
-        ktile(I0{}, I0{}, t);
-        ktile(I1{}, I0{}, t + 1);
-    }
-    ktile(I0{}, I1{}, nk - 2);
-    ktile(I1{}, I2{}, nk - 1);
-
-    // ---- epilogue.  The accumulators hold one COLUMN per lane; each wave transposes its tile through its own 16 KB of
-    // the (now idle) ring, 64 rows at a time, and then works on whole rows: 16 lanes x float4 = one 256-byte row segment
-    // per quarter-wave for the residual read, the f32 store and the 16-bit operand store.
-    // (all LDS-DMA has landed and every fragment read has completed before any wave gets here: see the tail waits above)
-    if constexpr (ABL & 32) tstamp[2] = __builtin_amdgcn_s_memtime();
     if (Cf) Cf += (size_t)blockIdx.y * strideC;
     if (C16) C16 += (size_t)blockIdx.y * strideC;
     const float* Rsrc = Rf ? Rf + (size_t)blockIdx.y * strideC : Cf;
-    float* ct = reinterpret_cast<float*>(smem + wid * 16384);
+    // the epilogue's transpose scratch: 8 KB per wave in the SECOND K-tile buffer (the first one receives the next tile's
+    // K-tile 0 while the epilogue runs)
+    float* ct = reinterpret_cast<float*>(smem + PP_BUF + wid * 8192);
     const int fl = EPI >= 0 ? EPI : flags;
     const bool do_gelu = fl & G16X_GELU, do_acc = fl & G16X_ACCUM;
     const bool out16 = fl & G16X_OUT16, outf = fl & G16X_OUTF32, nts = fl & G16X_NT;
     const float ascale = NPL == 2 ? alpha * (1.0f / 2048.0f) : alpha;
     const int c4 = (lane & 15) << 2;
-    const int col = n0 + wn * 64 + c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
-    if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0) {
-        // ---- spatial-attention operand layout (N = 3d, d % 256 == 0, so a 256-column tile is all-Q, all-K or all-V; the 256
-        // rows of a tile are exactly one (clip, frame) sequence).  C16 holds 3*NPL planes of M*d 16-bit values:
-        //   [Q planes | K planes | V^T planes], Q and K row-major (M, d) with Q multiplied by qscale (= scale * log2 e),
-        //   V^T as [(sequence, head)][feature][256 keys]: what kernels_attn_dma.hip streams straight into LDS.
-        const int dm = N / 3;
-        const int which = n0 / dm;                       // 0 Q, 1 K, 2 V  (block-uniform)
-        const size_t P = (size_t)plane16;               // = M * d
-        uint16_t* base = C16 + (size_t)which * NPL * P;
-        const float4 bvq = bv;
-        if (which < 2) {
-            const float qs = which == 0 ? qscale : 1.0f;
-            const int colq = n0 - which * dm + wn * 64 + c4;
+
+    // K-tile 0 of the first tile; every later tile's K-tile 0 is staged BEFORE the previous tile's epilogue, so that its
+    // loads run ahead of the 256 KB of output stores instead of queueing behind them
+    stage(0, 0, 0);
+    stage(2, 0, 0);
+    stage(3, 0, 0);
+    stage(1, 0, 0);
+    for (;;) {
+        if constexpr (ABL & 32) tstamp[0] = __builtin_amdgcn_s_memtime();
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        in_loop = false;
+        stage(0, 1, 1);
+        stage(2, 1, 1);
+        wait_vmcnt<8>();  // A-early(0), B-early(0) of this wave have landed (outstanding output stores of the previous tile only
+                          // make a counted wait stricter: loads retire in order among loads)
+        wg_barrier();
+        if constexpr (ABL & 32) tstamp[1] = __builtin_amdgcn_s_memtime();
+        if (wm == 1) wg_barrier();  // group 1 runs one barrier behind group 0
+        if constexpr (ABL & 2) {  // fragments are read once, here
+            wait_vmcnt<0>();
+            wg_barrier();
+            read_a(0, 0); read_b(0, 0); read_b(0, 1);
+            scale_b(0); scale_b(1);
+            wg_barrier();
+        }
+        in_loop = true;
+        for (int t = 0; t + 2 < nk; t += 2) {
+            ktile(I0{}, I0{}, t);
+            ktile(I1{}, I0{}, t + 1);
+        }
+        ktile(I0{}, I1{}, nk - 2);
+        ktile(I1{}, I2{}, nk - 1);
+        in_loop = false;
+
+        // ---- all LDS-DMA has landed and every fragment read has completed before any wave gets here (tail waits above)
+        if constexpr (ABL & 32) tstamp[2] = __builtin_amdgcn_s_memtime();
+        const int m0e = m0, n0e = n0;            // this tile's origin, for the epilogue
+        const int tile_id = bid;
+        bid += gridDim.x;
+        const bool more = bid < ntiles;
+        if (more) {
+            tile_origin(bid, m0, n0);
+            rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, -1, 0x00020000);
+            rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, -1, 0x00020000);
+            stage(0, 0, 0);
+            stage(2, 0, 0);
+            stage(3, 0, 0);
+            stage(1, 0, 0);
+        }
+
+        // ---- epilogue.  The accumulators hold one COLUMN per lane; each wave transposes its tile through its own 8 KB of
+        // the ring's second buffer, 32 rows at a time, and then works on whole rows: 16 lanes x float4 = one 256-byte row
+        // segment per quarter-wave for the residual read, the f32 store and the 16-bit operand store.
+        const int col = n0e + wn * 64 + c4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+        if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0) {
+            // ---- spatial-attention operand layout (N = 3d, d % 256 == 0, so a 256-column tile is all-Q, all-K or all-V; the
+            // 256 rows of a tile are exactly one (clip, frame) sequence).  C16 holds 3*NPL planes of M*d 16-bit values:
+            //   [Q planes | K planes | V^T planes], Q and K row-major (M, d) with Q multiplied by qscale (= scale * log2 e),
+            //   V^T as [(sequence, head)][feature][256 keys]: what kernels_attn_dma.hip streams straight into LDS.
+            const int dm = N / 3;
+            const int which = n0e / dm;                      // 0 Q, 1 K, 2 V  (block-uniform)
+            const size_t P = (size_t)plane16;               // = M * d
+            uint16_t* base = C16 + (size_t)which * NPL * P;
+            const float4 bvq = bv;
+            if (which < 2) {
+                const float qs = which == 0 ? qscale : 1.0f;
+                const int colq = n0e - which * dm + wn * 64 + c4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
-                            ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q * 2 + i][j][e];
-                __builtin_amdgcn_wave_barrier();
+                            ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q][j][e];
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int it = 0; it < 16; ++it) {
-                    const int rl = it * 4 + (lane >> 4);
-                    const size_t idx = (size_t)(m0 + wm * 128 + q * 64 + rl) * dm + colq;
-                    float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
-                    v.x = (v.x * ascale + bvq.x) * qs; v.y = (v.y * ascale + bvq.y) * qs;
-                    v.z = (v.z * ascale + bvq.z) * qs; v.w = (v.w * ascale + bvq.w) * qs;
-                    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-                    if constexpr (NPL == 1) {
-                        const u2v t = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
-                                       (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16)};
-                        __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(base + idx));
-                    } else {
-                        uint32_t h01, h23, l01, l23;
-                        split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
-                        const u2v th = {h01, h23}, tl = {l01, l23};
-                        __builtin_nontemporal_store(th, reinterpret_cast<u2v*>(base + idx));
-                        __builtin_nontemporal_store(tl, reinterpret_cast<u2v*>(base + P + idx));
+                    for (int it = 0; it < 8; ++it) {
+                        const int rl = it * 4 + (lane >> 4);
+                        const size_t idx = (size_t)(m0e + wm * 128 + q * 32 + rl) * dm + colq;
+                        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+                        v.x = (v.x * ascale + bvq.x) * qs; v.y = (v.y * ascale + bvq.y) * qs;
+                        v.z = (v.z * ascale + bvq.z) * qs; v.w = (v.w * ascale + bvq.w) * qs;
+                        typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                        if constexpr (NPL == 1) {
+                            const u2v t = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
+                                           (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16)};
+                            __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(base + idx));
+                        } else {
+                            uint32_t h01, h23, l01, l23;
+                            split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
+                            const u2v th = {h01, h23}, tl = {l01, l23};
+                            __builtin_nontemporal_store(th, reinterpret_cast<u2v*>(base + idx));
+                            __builtin_nontemporal_store(tl, reinterpret_cast<u2v*>(base + P + idx));
+                        }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
-            // V tiles: the accumulators already hold one COLUMN (feature) per lane with 4 consecutive rows (keys) per register
-            // group, so they go to LDS as [feature][key] with float4 writes (16-byte slot XOR (feature & 15): conflict-free on
-            // both sides) and come back as 8 consecutive keys of one feature per lane = one 16-byte store per 16-bit plane.
-            const int seq = m0 >> 8;
-            const int Hn = dm / head_dim;
-            const int fl8 = lane >> 3, kq = lane & 7;
+            } else {
+                // V tiles: the accumulators already hold one COLUMN (feature) per lane with 4 consecutive rows (keys) per
+                // register group, so they go to LDS as [feature][32 keys] with float4 writes (16-byte slot XOR (feature & 7):
+                // conflict-free on both sides) and come back as 8 consecutive keys of one feature per lane = one 16-byte
+                // store per 16-bit plane.
+                const int seq = m0e >> 8;
+                const int Hn = dm / head_dim;
+                const int fl4 = lane >> 2, kq = lane & 3;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int q = 0; q < 4; ++q) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int c = j * 32 + r, ks = i * 8 + 2 * g + h;
-                            *reinterpret_cast<float4*>(ct + c * 64 + ((ks ^ (c & 15)) << 2)) =
-                                make_float4(acc[q * 2 + i][j][4 * g], acc[q * 2 + i][j][4 * g + 1], acc[q * 2 + i][j][4 * g + 2],
-                                            acc[q * 2 + i][j][4 * g + 3]);
+                            const int c = j * 32 + r, ks = 2 * g + h;
+                            *reinterpret_cast<float4*>(ct + c * 32 + ((ks ^ (c & 7)) << 2)) =
+                                make_float4(acc[q][j][4 * g], acc[q][j][4 * g + 1], acc[q][j][4 * g + 2], acc[q][j][4 * g + 3]);
                         }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int c = it * 16 + fl4;                                 // feature column inside the wave's 64
+                        const int cv = n0e - 2 * dm + wn * 64 + c;                   // feature column inside d
+                        const float4 a = *reinterpret_cast<const float4*>(ct + c * 32 + (((2 * kq) ^ (c & 7)) << 2));
+                        const float4 b = *reinterpret_cast<const float4*>(ct + c * 32 + (((2 * kq + 1) ^ (c & 7)) << 2));
+                        const float bb = bias ? bias[n0e + wn * 64 + c] : 0.f;
+                        const int head = cv / head_dim, f = cv - head * head_dim;
+                        const size_t idx = (((size_t)seq * Hn + head) * head_dim + f) * 256 + wm * 128 + q * 32 + kq * 8;
+                        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                        const float v0 = a.x * ascale + bb, v1 = a.y * ascale + bb, v2 = a.z * ascale + bb, v3 = a.w * ascale + bb;
+                        const float v4 = b.x * ascale + bb, v5 = b.y * ascale + bb, v6 = b.z * ascale + bb, v7 = b.w * ascale + bb;
+                        if constexpr (NPL == 1) {
+                            const u4v t = {(uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16),
+                                           (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16),
+                                           (uint32_t)f32_to_bf16(v4) | ((uint32_t)f32_to_bf16(v5) << 16),
+                                           (uint32_t)f32_to_bf16(v6) | ((uint32_t)f32_to_bf16(v7) << 16)};
+                            __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(base + idx));
+                        } else {
+                            uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
+                            split_f16_x4(v0, v1, v2, v3, h01, h23, l01, l23);
+                            split_f16_x4(v4, v5, v6, v7, h45, h67, l45, l67);
+                            const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
+                            __builtin_nontemporal_store(th, reinterpret_cast<u4v*>(base + idx));
+                            __builtin_nontemporal_store(tl, reinterpret_cast<u4v*>(base + P + idx));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q][j][e];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const int c = it * 8 + fl8;                                  // feature column inside the wave's 64
-                    const int cv = n0 - 2 * dm + wn * 64 + c;                    // feature column inside d
-                    const float4 a = *reinterpret_cast<const float4*>(ct + c * 64 + (((2 * kq) ^ (c & 15)) << 2));
-                    const float4 b = *reinterpret_cast<const float4*>(ct + c * 64 + (((2 * kq + 1) ^ (c & 15)) << 2));
-                    const float bb = bias ? bias[n0 + wn * 64 + c] : 0.f;
-                    const int head = cv / head_dim, f = cv - head * head_dim;
-                    const size_t idx = (((size_t)seq * Hn + head) * head_dim + f) * 256 + wm * 128 + q * 64 + kq * 8;
-                    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-                    const float v0 = a.x * ascale + bb, v1 = a.y * ascale + bb, v2 = a.z * ascale + bb, v3 = a.w * ascale + bb;
-                    const float v4 = b.x * ascale + bb, v5 = b.y * ascale + bb, v6 = b.z * ascale + bb, v7 = b.w * ascale + bb;
-                    if constexpr (NPL == 1) {
-                        const u4v t = {(uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16),
-                                       (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16),
-                                       (uint32_t)f32_to_bf16(v4) | ((uint32_t)f32_to_bf16(v5) << 16),
-                                       (uint32_t)f32_to_bf16(v6) | ((uint32_t)f32_to_bf16(v7) << 16)};
-                        __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(base + idx));
-                    } else {
-                        uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
-                        split_f16_x4(v0, v1, v2, v3, h01, h23, l01, l23);
-                        split_f16_x4(v4, v5, v6, v7, h45, h67, l45, l67);
-                        const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
-                        __builtin_nontemporal_store(th, reinterpret_cast<u4v*>(base + idx));
-                        __builtin_nontemporal_store(tl, reinterpret_cast<u4v*>(base + P + idx));
+                    const int rl = it * 4 + (lane >> 4);
+                    const int row = m0e + wm * 128 + q * 32 + rl;
+                    float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+                    v.x = v.x * ascale + bv.x; v.y = v.y * ascale + bv.y; v.z = v.z * ascale + bv.z; v.w = v.w * ascale + bv.w;
+                    if (do_gelu) {
+                        const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+                        v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+                    }
+                    const size_t idx = (size_t)row * ldc + col;
+                    if (do_acc) {
+                        const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    if constexpr (ABL & 8) {
+                        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                        continue;
+                    }
+                    if (outf) {
+                        if (nts) {
+                            typedef float nt4 __attribute__((ext_vector_type(4)));
+                            nt4 t = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(t, reinterpret_cast<nt4*>(Cf + idx));
+                        } else {
+                            *reinterpret_cast<float4*>(Cf + idx) = v;
+                        }
+                    }
+                    if (out16) {
+                        if (fl & G16X_GELU16) {
+                            const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+                            v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+                        }
+                        typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                        auto st2 = [&](uint16_t* p_, uint32_t a, uint32_t b) {
+                            u2v t = {a, b};
+                            if (nts) __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(p_));
+                            else *reinterpret_cast<u2v*>(p_) = t;
+                        };
+                        const bool split_out = EPI >= 0 ? (NPL == 2) : (plane16 != 0);  // compile-time in the EPI instantiations
+                        if (!split_out) {  // bf16 output
+                            st2(C16 + idx, (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
+                                (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16));
+                        } else {             // split f16 planes [hi | lo]
+                            uint32_t h01, h23, l01, l23;
+                            split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
+                            st2(C16 + idx, h01, h23);
+                            st2(C16 + (size_t)plane16 + idx, l01, l23);
+                        }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next round
             }
         }
-        return;
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q * 2 + i][j][e];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int rl = it * 4 + (lane >> 4);
-            const int row = m0 + wm * 128 + q * 64 + rl;
-            float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
-            v.x = v.x * ascale + bv.x; v.y = v.y * ascale + bv.y; v.z = v.z * ascale + bv.z; v.w = v.w * ascale + bv.w;
-            if (do_gelu) {
-                const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
-                v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
-            }
-            const size_t idx = (size_t)row * ldc + col;
-            if (do_acc) {
-                const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-            }
-            if constexpr (ABL & 8) {
-                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                continue;
-            }
-            if (outf) {
-                if (nts) {
-                    typedef float nt4 __attribute__((ext_vector_type(4)));
-                    nt4 t = {v.x, v.y, v.z, v.w};
-                    __builtin_nontemporal_store(t, reinterpret_cast<nt4*>(Cf + idx));
-                } else {
-                    *reinterpret_cast<float4*>(Cf + idx) = v;
-                }
-            }
-            if (out16) {
-                if (fl & G16X_GELU16) {
-                    const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
-                    v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
-                }
-                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-                auto st2 = [&](uint16_t* p, uint32_t a, uint32_t b) {
-                    u2v t = {a, b};
-                    if (nts) __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(p));
-                    else *reinterpret_cast<u2v*>(p) = t;
-                };
-                const bool split_out = EPI >= 0 ? (NPL == 2) : (plane16 != 0);  // compile-time in the EPI instantiations
-                if (!split_out) {  // bf16 output
-                    st2(C16 + idx, (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
-                        (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16));
-                } else {             // split f16 planes [hi | lo]
-                    uint32_t h01, h23, l01, l23;
-                    split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
-                    st2(C16 + idx, h01, h23);
-                    st2(C16 + (size_t)plane16 + idx, l01, l23);
-                }
+        if constexpr (ABL & 32) {
+            tstamp[3] = __builtin_amdgcn_s_memtime();
+            if (tid == 0 && g_pp_timing) {
+                unsigned long long* o = g_pp_timing + 4 * (size_t)tile_id;
+                o[0] = tstamp[0]; o[1] = tstamp[1]; o[2] = tstamp[2]; o[3] = tstamp[3];
             }
         }
-        __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next round
-    }
-    if constexpr (ABL & 32) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tstamp[3] = __builtin_amdgcn_s_memtime();
-        if (tid == 0 && g_pp_timing) {
-            unsigned long long* o = g_pp_timing + 4 * (size_t)blockIdx.x;
-            o[0] = tstamp[0]; o[1] = tstamp[1]; o[2] = tstamp[2]; o[3] = tstamp[3];
-        }
+        if (!more) break;
+        // every wave is done with its transpose scratch before K-tile 1 of the next tile is staged over it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_barrier();
     }
 }
 
@@ -529,7 +557,17 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
                        mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) +
                              (flags & G16X_OUT16 ? (plane16 ? 4 : 2) : 0)),
                    st);
-    const dim3 grid((unsigned)((M / 256) * (N / 256)), (unsigned)batch);
+    // persistent: one workgroup per CU (128 KB of LDS: one fits), each walking tiles bid, bid + grid.x, ...
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("GENIE_PP_PERSIST");   // 0: one workgroup per tile (the non-persistent launch, for A/B runs)
+        if (e && !atoi(e)) return 1 << 30;
+        return n > 0 ? n : 256;
+    }();
+    const long tiles_x = (long)(M / 256) * (N / 256);
+    const dim3 grid((unsigned)(tiles_x < n_cu ? tiles_x : n_cu), (unsigned)batch);
     static const int stagger = [] { const char* e = getenv("GENIE_PP_STAGGER"); return e ? atoi(e) : 0; }();
     static const long stagger_min = [] { const char* e = getenv("GENIE_PP_STAGGER_MIN_TILES"); return e ? atol(e) : 1024L; }();
     if (stagger > 1 && batch == 1 && tiles >= stagger_min) flags |= (stagger & 15) << 8;
@@ -550,7 +588,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     static const int abl = [] { const char* e = getenv("GENIE_PP_ABL"); return e ? atoi(e) : 0; }();
     static const int sched = [] { const char* e = getenv("GENIE_PP_SCHED"); return e ? atoi(e) : 0; }();
     static unsigned long long* tbuf = nullptr;
-    const size_t n_wg = (size_t)grid.x;
+    const size_t n_wg = (size_t)tiles_x;
     if ((abl == 32 || abl == 33) && !tbuf) {
         (void)hipMalloc(&tbuf, sizeof(unsigned long long) * 4 * 65536);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_timing), &tbuf, sizeof(tbuf));

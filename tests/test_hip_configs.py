@@ -60,12 +60,12 @@ def test_batched_forward_vs_oracle(precision, nm, tol, width):
     assert d < (2e-5 if precision == "f16x3" else 8e-2), d
 
 
-@pytest.mark.parametrize("T,heads,width", [(8, 2, 128), (12, 4, 128), (9, 2, 64)])
-def test_short_window_temporal_mfma(T, heads, width):
-    """Windows shorter than 16 frames (generate.py / RawTokenDataset window_size < 16) run the 16x16 MFMA temporal kernel
+@pytest.mark.parametrize("T,heads,width,qkn", [(8, 2, 128, False), (8, 4, 128, True), (8, 2, 64, False)])
+def test_short_window_temporal_mfma(T, heads, width, qkn):
+    """Windows shorter than 16 frames (generate.py / RawTokenDataset window_size = 8; T must be a power of two) run the 16x16 MFMA temporal kernel
     with padded rows (kernels_exact.hip attn_temporal_f32_mfma_kernel, 8 <= T <= 16): logits against the f64-accumulating oracle."""
     cfg = pkg("config").GenieConfig(num_layers=2, num_heads=heads, d_model=width, T=T, S=16, num_factored_vocabs=2,
-                                    qk_norm=(T == 12), use_mup=False)
+                                    qk_norm=qkn, use_mup=False)
     synth = pkg("synthetic")
     sd = synth.make_state_dict(cfg, seed=T, law="conditioned")
     ids = synth.make_clips(3, cfg, seed=T + 1)
