@@ -131,7 +131,7 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
         GENIE_TRY(rc);
     } else if (w.tcache) {
         GENIE_TRY(launch_attn_temporal_prefix(qkv, w.tcache, ao, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
-                                              nw, nb, st));
+                                              nw, nb, st, nullptr, 0, w.tshift));
     } else {
         int rc = launch_attn_temporal_f32_mfma(qkv, ao, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nw, nb,
                                                st);
@@ -370,45 +370,66 @@ size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B) {
 }
 
 static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int64_t* ids, int B, float* cache,
-                          bool clean, Workspace& w, hipStream_t st) {
+                          bool clean, int tshift, Workspace& w, hipStream_t st) {
     const size_t per_layer = (size_t)B * c.T * c.S * 3 * c.d_model;
     GENIE_TRY(launch_embed(c, wt, ids, B, w.x, st));
     if (c.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c, w.x, w, B, st));
     if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, w.x, w, B, st));
     for (int i = 0; i < c.num_layers; ++i) {
         if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; }
-        else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; }
+        else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; w.tshift = tshift; }
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
         int rc = st_block(c, wt.layers_host[i], w.x, w, B, st);
         w.skip_shadow_mlp = false;
         w.tqkv = nullptr;
         w.tcache = nullptr;
+        w.tshift = 0;
         GENIE_TRY(rc);
     }
     return GENIE_OK;
 }
 
-int genie_clean_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, float* cache,
+// The prefix passes run on `nframes` <= T frame slots per clip: a private copy of the config with T = nframes (dense
+// (B, nframes, S, *) buffers) and the positional table advanced to clip frame `frame0`.
+static int prefix_view(const genie_cfg* cfg, const genie_weights* wt, int B, int frame0, int nframes, size_t cache_bytes,
+                       genie_cfg& c2, genie_weights& w2) {
+    GENIE_CHECK_ARG(nframes >= 1 && frame0 >= 0 && frame0 + nframes <= cfg->T, "prefix pass: frames [%d, %d) outside the clip (T=%d)",
+                    frame0, frame0 + nframes, cfg->T);
+    c2 = *cfg;
+    c2.T = nframes;
+    w2 = *wt;
+    w2.pos_embed = wt->pos_embed + (size_t)frame0 * cfg->S * cfg->d_model;  // pos_embed_TSC[0, frame0 + i]
+    const size_t need = (size_t)cfg->num_layers * B * nframes * cfg->S * 3 * cfg->d_model * sizeof(float);
+    GENIE_CHECK_ARG(cache_bytes >= need, "prefix pass: cache too small (%zu < %zu bytes)", cache_bytes, need);
+    return GENIE_OK;
+}
+
+int genie_clean_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int nframes, float* cache,
                      size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream) {
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(wt && wt->layers_host && ids && cache, "clean_pass: NULL pointer");
-    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "clean_pass: cache too small");
     GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
-    Workspace w = carve(*cfg, B, workspace);
-    return prefix_forward(*cfg, *wt, ids, B, cache, true, w, as_stream(stream));
+    genie_cfg c2;
+    genie_weights w2;
+    GENIE_TRY(prefix_view(cfg, wt, B, 0, nframes, cache_bytes, c2, w2));
+    Workspace w = carve(c2, B, workspace);
+    return prefix_forward(c2, w2, ids, B, cache, true, 0, w, as_stream(stream));
 }
 
-int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frames, int B,
-                               const float* cache, size_t cache_bytes, float* logits, void* workspace,
+int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frames, int B, int frame0,
+                               int nframes, const float* cache, size_t cache_bytes, float* logits, void* workspace,
                                size_t workspace_bytes, void* stream) {
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(wt && wt->layers_host && frames && cache && logits, "masked_frames_logits: NULL pointer");
-    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "masked_frames_logits: cache too small");
+    GENIE_CHECK_ARG(frame0 == 0 || frame0 == 1, "masked_frames_logits: frame0 = %d (0 or 1)", frame0);
     GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
-    Workspace w = carve(*cfg, B, workspace);
+    genie_cfg c2;
+    genie_weights w2;
+    GENIE_TRY(prefix_view(cfg, wt, B, frame0, nframes, cache_bytes, c2, w2));
+    Workspace w = carve(c2, B, workspace);
     hipStream_t st = as_stream(stream);
-    GENIE_TRY(prefix_forward(*cfg, *wt, frames, B, const_cast<float*>(cache), false, w, st));
-    return readout(*cfg, *wt, w.x, w, B, 0, cfg->T, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
+    GENIE_TRY(prefix_forward(c2, w2, frames, B, const_cast<float*>(cache), false, frame0, w, st));
+    return readout(c2, w2, w.x, w, B, 0, nframes, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
 }
 
 int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frame_ids, int B, int t, float* cache,

@@ -20,7 +20,8 @@ struct Workspace {
     size_t total;
     // teacher-forced prefix reuse (set per layer by the prefix entry points, NULL otherwise):
     float* tqkv;         // where the temporal qkv GEMM writes (clean pass: this layer's slice of the cache)
-    const float* tcache; // non-NULL: temporal attention takes keys j < i from this cached qkv (masked-frames pass)
+    const float* tcache; // non-NULL: temporal attention takes keys j < i + tshift from this cached qkv (masked-frames pass)
+    int tshift = 0;      // clip-frame offset of the masked-frames buffers against the cache (0 or 1)
     // single-frame decode (generate with a temporal KV cache): the block runs on ONE frame (cfg.T == 1, dense
     // (B,S,*) buffers); its temporal qkv is written into slot `frame_t` of this layer's cache slice and the
     // attention reads slots 0..frame_t.
@@ -71,7 +72,7 @@ int launch_attn_temporal_single(const float* cache, float* out, int B, int T, in
                                 uint16_t* out16 = nullptr, size_t plane = 0);
 int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
                                 int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
-                                uint16_t* out16 = nullptr, size_t plane = 0);
+                                uint16_t* out16 = nullptr, size_t plane = 0, int sh = 0);
 int launch_layer_norm_split(const float* x, const float* g, const float* b, uint16_t* y, size_t plane, long rows, int C,
                             float eps, hipStream_t st);
 int launch_split_f16(const float* src, uint16_t* dst, size_t plane, size_t n, hipStream_t st);

@@ -724,10 +724,10 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     if (w.tcache) {
         rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
-                                         nwt, nbt, st, xn16, 0);
+                                         nwt, nbt, st, xn16, 0, w.tshift);
         if (rc == GENIE_E_UNSUPPORTED) {
             GENIE_TRY(launch_attn_temporal_prefix(tq, w.tcache, w.logits, B, c.T, c.S, d, c.num_heads, c.head_dim,
-                                                  c.attn_scale, nwt, nbt, st));
+                                                  c.attn_scale, nwt, nbt, st, nullptr, 0, w.tshift));
             rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
         }
     } else {
@@ -838,10 +838,10 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     if (w.tcache) {
         rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
-                                         nwt, nbt, st, as, pd);
+                                         nwt, nbt, st, as, pd, w.tshift);
         if (rc == GENIE_E_UNSUPPORTED) {
             GENIE_TRY(launch_attn_temporal_prefix(tq, w.tcache, w.logits, B, c.T, c.S, d, c.num_heads, c.head_dim,
-                                                  c.attn_scale, nwt, nbt, st));
+                                                  c.attn_scale, nwt, nbt, st, nullptr, 0, w.tshift));
             rc = launch_split_f16(w.logits, as, pd, pd, st);
         }
     } else {

@@ -1279,9 +1279,12 @@ int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bit
 template <int DH>
 __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     const float* __restrict__ cur, const float* __restrict__ cache, float* __restrict__ out, long n_bs, int S, int d,
-    int H, float scale, const float* __restrict__ nw, const float* __restrict__ nb, uint16_t* __restrict__ out16,
-    size_t plane) {
-    constexpr int T = 16, PER = DH / 4;
+    int H, int T, int sh, float scale, const float* __restrict__ nw, const float* __restrict__ nb,
+    uint16_t* __restrict__ out16, size_t plane) {
+    // T <= 16 frame slots in `cur` and in `cache` (tile rows / columns >= T are padding: loads repeat slot T-1, nothing is
+    // stored); query slot i sees cached slots j < i + sh (sh = 0: cur and cache hold the same frames; sh = 1: cur holds
+    // clip frames 1..T, cache clip frames 0..T-1)
+    constexpr int PER = DH / 4;
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1291,8 +1294,9 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     const long b = bs / S, s = bs - b * S;
     const long tok_stride = (long)S * 3 * d;
     const size_t off0 = ((size_t)(b * T) * S + s) * 3 * d + head * DH;
-    const float* qp = cur + off0 + (size_t)r * tok_stride + g * PER;
-    const float* kcp = cache + off0 + (size_t)r * tok_stride + d + g * PER;
+    const int rr = r < T ? r : T - 1;
+    const float* qp = cur + off0 + (size_t)rr * tok_stride + g * PER;
+    const float* kcp = cache + off0 + (size_t)rr * tok_stride + d + g * PER;
     float q[PER], k[PER], kc[PER];
 #pragma unroll
     for (int c = 0; c < PER / 4; ++c) {
@@ -1343,7 +1347,7 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     float mx = dg;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if (4 * g + e >= r) st[e] = -INFINITY;  // strictly earlier frames only
+        if (4 * g + e >= r + sh || 4 * g + e >= T) st[e] = -INFINITY;  // strictly earlier clip frames only
         mx = fmaxf(mx, st[e]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -1357,19 +1361,20 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     const float inv = 1.0f / (sum + pd);
     const float pdn = pd * inv;  // weight of the query's own (current) frame, held by every lane with r == i
     constexpr int NV = DH / 16;  // feature permutation as in attn_temporal_f32_mfma_kernel
-    const float* vcp = cache + off0 + 2 * d + (size_t)(4 * g) * tok_stride + NV * r;
-    const float* vp = cur + off0 + 2 * d + (size_t)(4 * g) * tok_stride + NV * r;
+    const float* vcp = cache + off0 + 2 * d + NV * r;
+    const float* vp = cur + off0 + 2 * d + NV * r;
     float vc[4][NV], vs[4][NV];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        const size_t fo = (size_t)(4 * g + e < T ? 4 * g + e : T - 1) * tok_stride;
         if constexpr (NV == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(vcp + (size_t)e * tok_stride);
-            const float4 u = *reinterpret_cast<const float4*>(vp + (size_t)e * tok_stride);
+            const float4 t = *reinterpret_cast<const float4*>(vcp + fo);
+            const float4 u = *reinterpret_cast<const float4*>(vp + fo);
             vc[e][0] = t.x; vc[e][1] = t.y; vc[e][2] = t.z; vc[e][3] = t.w;
             vs[e][0] = u.x; vs[e][1] = u.y; vs[e][2] = u.z; vs[e][3] = u.w;
         } else {
-            const float2 t = *reinterpret_cast<const float2*>(vcp + (size_t)e * tok_stride);
-            const float2 u = *reinterpret_cast<const float2*>(vp + (size_t)e * tok_stride);
+            const float2 t = *reinterpret_cast<const float2*>(vcp + fo);
+            const float2 u = *reinterpret_cast<const float2*>(vp + fo);
             vc[e][0] = t.x; vc[e][1] = t.y; vs[e][0] = u.x; vs[e][1] = u.y;
         }
     }
@@ -1386,6 +1391,7 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     const size_t obase = ((size_t)(b * T) * S + s) * d + head * DH + NV * r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        if (4 * g + e >= T) continue;
         const size_t oi = obase + (size_t)(4 * g + e) * S * d;
         float ov[NV];
 #pragma unroll
@@ -1397,7 +1403,7 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
 // generic geometry (any T <= 64, Dh in {8,16,32,64}): one thread per (b, s, head, frame)
 template <int DH>
 __global__ void attn_temporal_prefix_generic_kernel(const float* __restrict__ cur, const float* __restrict__ cache,
-                                                    float* __restrict__ out, long n, int T, int S, int d, int H,
+                                                    float* __restrict__ out, long n, int T, int sh, int S, int d, int H,
                                                     float scale, const float* __restrict__ nw,
                                                     const float* __restrict__ nb) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1427,10 +1433,11 @@ __global__ void attn_temporal_prefix_generic_kernel(const float* __restrict__ cu
     load_norm(cur + off0 + (size_t)i * tok_stride, q);
 #pragma unroll
     for (int c = 0; c < DH; ++c) { q[c] *= scale; o[c] = 0.f; }
-    float sc[64];
+    float sc[65];
     float mx = -INFINITY;
-    for (int j = 0; j <= i; ++j) {
-        const float* src = (j < i ? cache : cur) + off0 + (size_t)j * tok_stride + d;
+    const int nc = i + sh;  // cached slots 0..nc-1, then the query's own (current) slot
+    for (int j = 0; j <= nc; ++j) {
+        const float* src = (j < nc ? cache + off0 + (size_t)j * tok_stride : cur + off0 + (size_t)i * tok_stride) + d;
         load_norm(src, kk);
         float a = 0.f;
 #pragma unroll
@@ -1439,10 +1446,10 @@ __global__ void attn_temporal_prefix_generic_kernel(const float* __restrict__ cu
         mx = fmaxf(mx, a);
     }
     float sum = 0.f;
-    for (int j = 0; j <= i; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+    for (int j = 0; j <= nc; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
     const float inv = 1.0f / sum;
-    for (int j = 0; j <= i; ++j) {
-        const float* vsrc = (j < i ? cache : cur) + off0 + (size_t)j * tok_stride + 2 * d;
+    for (int j = 0; j <= nc; ++j) {
+        const float* vsrc = (j < nc ? cache + off0 + (size_t)j * tok_stride : cur + off0 + (size_t)i * tok_stride) + 2 * d;
         const float p = sc[j] * inv;
 #pragma unroll
         for (int c = 0; c < DH; ++c) o[c] = fmaf(p, vsrc[c], o[c]);
@@ -1456,17 +1463,19 @@ __global__ void attn_temporal_prefix_generic_kernel(const float* __restrict__ cu
 // (returns GENIE_E_UNSUPPORTED if a 16-bit output is requested for a geometry without an MFMA instantiation).
 int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
                                 int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
-                                uint16_t* out16, size_t plane) {
+                                uint16_t* out16, size_t plane, int sh) {
+    // T frame slots in both buffers; query slot i sees cached slots j < i + sh and itself (sh in {0, 1})
+    GENIE_CHECK_SHAPE(sh == 0 || sh == 1, "prefix attention: shift %d", sh);
     const long n_bs = (long)B * S, waves = n_bs * H;
     ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 28.0, st);
-    if (T == 16 && (Dh == 32 || Dh == 64)) {
+    if (T <= 16 && T >= 8 && (Dh == 32 || Dh == 64)) {
         const unsigned blocks = (unsigned)((waves + 3) / 4);
         if (Dh == 64)
-            attn_temporal_prefix_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, scale, nw, nb,
-                                                                             out16, plane);
+            attn_temporal_prefix_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, T, sh, scale, nw,
+                                                                             nb, out16, plane);
         else
-            attn_temporal_prefix_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, scale, nw, nb,
-                                                                             out16, plane);
+            attn_temporal_prefix_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, T, sh, scale, nw,
+                                                                             nb, out16, plane);
         GENIE_LAUNCH_CHECK("attn_temporal_prefix_mfma");
         return GENIE_OK;
     }
@@ -1475,10 +1484,10 @@ int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out
     const long n = waves * T;
     const unsigned blocks = (unsigned)((n + 127) / 128);
     switch (Dh) {
-        case 8: attn_temporal_prefix_generic_kernel<8><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
-        case 16: attn_temporal_prefix_generic_kernel<16><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
-        case 32: attn_temporal_prefix_generic_kernel<32><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
-        case 64: attn_temporal_prefix_generic_kernel<64><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, S, d, H, scale, nw, nb); break;
+        case 8: attn_temporal_prefix_generic_kernel<8><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, sh, S, d, H, scale, nw, nb); break;
+        case 16: attn_temporal_prefix_generic_kernel<16><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, sh, S, d, H, scale, nw, nb); break;
+        case 32: attn_temporal_prefix_generic_kernel<32><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, sh, S, d, H, scale, nw, nb); break;
+        case 64: attn_temporal_prefix_generic_kernel<64><<<blocks, 128, 0, st>>>(cur, cache, out, n, T, sh, S, d, H, scale, nw, nb); break;
         default: set_error("prefix attention: head_dim %d unsupported", Dh); return GENIE_E_SHAPE;
     }
     GENIE_LAUNCH_CHECK("attn_temporal_prefix_generic");

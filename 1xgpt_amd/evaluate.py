@@ -65,19 +65,21 @@ class GenieEvaluator:
     @torch.no_grad()
     def predict_zframe_logits_reuse(self, input_ids: torch.LongTensor, noise=None, return_logits=True,
                                     unmask_mode="random"):
-        """Same contract and same per-row arithmetic as ``predict_zframe_logits`` in ~(1 + steps) forward passes
-        instead of 15 * steps: the ground-truth frames < t of every timeline t are identical to one clean pass
-        (temporal attention is causal, everything else per-frame), so they are computed once and their temporal
-        keys/values cached; "frame t of timeline t" is then decoded for all t together
-        (genie_clean_pass / genie_masked_frames_logits).  Returns (samples (B,T-1,H,W), logits (B,512,2,T-1,H,W))."""
+        """Same contract and same per-row arithmetic as ``predict_zframe_logits`` in (1 + steps) passes over T-1 frames
+        instead of 15 * steps forwards over T: the ground-truth frames < t of every timeline t are identical to one clean
+        pass (temporal attention is causal, everything else per-frame), so they are computed once (frames 0..T-2: no
+        timeline has the last frame as context) and their temporal keys/values cached; "frame t of timeline t" is then
+        decoded for t = 1..T-1 together (genie_clean_pass / genie_masked_frames_logits with frame0 = 1).
+        Returns (samples (B,T-1,H,W), logits (B,512,2,T-1,H,W))."""
         import math
         lib = _lib.load()
         m = self.model
         cfg, w = m._weights()[:2]
         T, S = m.config.T, m.config.S
+        n = T - 1                                           # timelines 1..T-1 = frame slots 0..n-1 of the masked passes
         V = m.config.factored_vocab_size * m.config.num_factored_vocabs
         steps, temperature = self.args.maskgit_steps, float(self.args.temperature)
-        ids = input_ids.to(self.device).to(torch.int64).view(-1, T, S).contiguous()
+        ids = input_ids.to(self.device).to(torch.int64).view(-1, T, S)
         B = ids.shape[0]
         dev = ids.device
         ws = m._workspace(B)
@@ -87,48 +89,46 @@ class GenieEvaluator:
             self._cache = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         cache = self._cache
         st = torch.cuda.current_stream().cuda_stream
-        _lib.check(lib.genie_clean_pass(cfg, w, ids.data_ptr(), B, cache.data_ptr(), nbytes, ws.data_ptr(), ws.numel(),
+        ctx = ids[:, :n].contiguous()                       # ground-truth context frames 0..T-2
+        _lib.check(lib.genie_clean_pass(cfg, w, ctx.data_ptr(), B, n, cache.data_ptr(), nbytes, ws.data_ptr(), ws.numel(),
                                         st), "genie_clean_pass")
-        cur = torch.full((B, T, S), m.mask_token_id, dtype=torch.int64, device=dev)
-        unmasked = torch.zeros(B * T, S, dtype=torch.uint8, device=dev)
-        samples = torch.empty(B * T, S, dtype=torch.int64, device=dev)
-        conf = torch.empty(B * T, S, dtype=torch.float32, device=dev)
-        logits = torch.empty(B, T, S, V, dtype=torch.float32, device=dev)
+        cur = torch.full((B, n, S), m.mask_token_id, dtype=torch.int64, device=dev)
+        unmasked = torch.zeros(B * n, S, dtype=torch.uint8, device=dev)
+        samples = torch.empty(B * n, S, dtype=torch.int64, device=dev)
+        conf = torch.empty(B * n, S, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, n, S, V, dtype=torch.float32, device=dev)
         logits0 = None
         for step in range(steps):
-            _lib.check(lib.genie_masked_frames_logits(cfg, w, cur.data_ptr(), B, cache.data_ptr(), nbytes,
+            _lib.check(lib.genie_masked_frames_logits(cfg, w, cur.data_ptr(), B, 1, n, cache.data_ptr(), nbytes,
                                                       logits.data_ptr(), ws.data_ptr(), ws.numel(), st),
                        "genie_masked_frames_logits")
             if step == 0:
                 logits0 = logits.clone() if steps > 1 else logits
             uni = None
             if temperature > 1e-8:
-                uni = torch.rand(m.config.num_factored_vocabs, B * T, S, device=dev)
-            _lib.check(lib.genie_sample(cfg, logits.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, B * T, temperature,
+                uni = torch.rand(m.config.num_factored_vocabs, B * n, S, device=dev)
+            _lib.check(lib.genie_sample(cfg, logits.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, B * n, temperature,
                                         0 if uni is None else uni.data_ptr(), samples.data_ptr(), conf.data_ptr(), st),
                        "genie_sample")
             last = step == steps - 1
-            keys, n = None, 0
+            keys, k_unmask = None, 0
             if not last:
-                n = math.ceil(math.cos((step + 1) / steps * math.pi / 2) * S)
+                k_unmask = math.ceil(math.cos((step + 1) / steps * math.pi / 2) * S)
                 if unmask_mode == "greedy":
                     keys = conf
-                else:
-                    keys = torch.zeros(B, T, S, dtype=torch.float32, device=dev)
-                    if noise is None:
-                        keys[:, 1:] = torch.rand(B, T - 1, S, device=dev)
-                    else:  # reference draw order: one (B,S) tensor per timeline t and step
-                        keys[:, 1:] = noise[:, step].to(dev).reshape(T - 1, B, S).permute(1, 0, 2)
-                    keys = keys.contiguous()
-            _lib.check(lib.genie_mask_step(0 if keys is None else keys.data_ptr(), n, int(last), m.mask_token_id,
-                                           unmasked.data_ptr(), samples.data_ptr(), cur.data_ptr(), S, B * T, S, st),
+                elif noise is None:
+                    keys = torch.rand(B, n, S, device=dev)
+                else:  # reference draw order: one (B,S) tensor per timeline t and step
+                    keys = noise[:, step].to(dev).reshape(n, B, S).permute(1, 0, 2).contiguous()
+            _lib.check(lib.genie_mask_step(0 if keys is None else keys.data_ptr(), k_unmask, int(last), m.mask_token_id,
+                                           unmasked.data_ptr(), samples.data_ptr(), cur.data_ptr(), S, B * n, S, st),
                        "genie_mask_step")
-        samples_THW = samples.view(B, T, m.h, m.w)[:, 1:]
+        samples_THW = samples.view(B, n, m.h, m.w)
         self._last_token_major_logits0 = logits0
         if not return_logits:
             return samples_THW, None
         nv, vf = m.config.num_factored_vocabs, m.config.factored_vocab_size
-        fl = logits0[:, 1:].reshape(B, T - 1, m.h, m.w, nv, vf).permute(0, 5, 4, 1, 2, 3)  # B Vf nv T-1 H W
+        fl = logits0.reshape(B, n, m.h, m.w, nv, vf).permute(0, 5, 4, 1, 2, 3)  # B Vf nv T-1 H W
         return samples_THW, fl
 
     @torch.no_grad()
@@ -137,19 +137,18 @@ class GenieEvaluator:
         lib = _lib.load()
         m = self.model
         T, S = m.config.T, m.config.S
-        cfg = m._weights()[0]
-        ids = input_ids.to(self.device).to(torch.int64).view(-1, T, S).contiguous()
-        lab = ids if labels is None else labels.to(self.device).to(torch.int64).view(-1, T, S).contiguous()
+        ids = input_ids.to(self.device).to(torch.int64).view(-1, T, S)
+        lab = ids if labels is None else labels.to(self.device).to(torch.int64).view(-1, T, S)
         B = ids.shape[0]
         samples, _ = self.predict_zframe_logits_reuse(ids, noise=noise, return_logits=False)
-        lg0 = self._last_token_major_logits0  # (B,T,S,V) token-major, frame 0 is a dummy
-        wid = torch.full((B, T, S), m.mask_token_id, dtype=torch.int64, device=ids.device)
-        wid[:, 0] = 0  # count frames 1..T-1 only
-        ce = torch.zeros(3, dtype=torch.float64, device=ids.device)
-        _lib.check(lib.genie_factored_ce(cfg, lg0.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, lab.data_ptr(), wid.data_ptr(), B,
-                                         0, T, ce.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                   "genie_factored_ce")
+        lg0 = self._last_token_major_logits0  # (B,T-1,S,V) token-major: clip frames 1..T-1
+        lab = lab.contiguous()
         hits = (ids.view(B, T, m.h, m.w)[:, 1:] == samples).sum().double()
+        ce = torch.zeros(3, dtype=torch.float64, device=ids.device)
+        cfg = m._weights()[0]
+        # logits hold frames [1, T) of the clip; targets are indexed in the full (B,T,S) clip
+        _lib.check(lib.genie_factored_ce(cfg, lg0.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, lab.data_ptr(), 0, B, 1, T,
+                                         ce.data_ptr(), torch.cuda.current_stream().cuda_stream), "genie_factored_ce")
         f64 = lambda v: torch.tensor(float(v), dtype=torch.float64, device=ids.device)  # noqa: E731
         return torch.stack([ce[0], ce[2], hits, f64(B * (T - 1) * S), f64(B * (T - 1)), f64(B)])
 

@@ -35,9 +35,10 @@ DTYPE = {"exact": "f32", "f16x3": "f16x3 (split-f16 operands, f32-class results)
 PUBLISHED_FRAMES_PER_SEC = {"c138": 1.0 / 0.075, "c35": 1.0 / 0.030}  # BASELINE.md section 1 (1x RTX 4090, fp32)
 
 
-def pass_flops(cfg):
-    """Algorithmic FLOPs of one forward pass of one clip."""
-    d, L, S, T = cfg.d_model, cfg.num_layers, cfg.S, cfg.T
+def pass_flops(cfg, frames=None):
+    """Algorithmic FLOPs of one forward pass of one clip over `frames` frames (default: all T)."""
+    d, L, S = cfg.d_model, cfg.num_layers, cfg.S
+    T = cfg.T if frames is None else frames
     V = cfg.factored_vocab_size * cfg.num_factored_vocabs
     return T * S * (L * (32 * d * d + 4 * S * d + 4 * T * d) + 2 * d * V)
 
@@ -304,8 +305,9 @@ def main():
     frames_per_step = (cfg.T - 1) * B * world
     value = frames_per_step * args.steps / seconds
     # executed full-pass equivalents per step per GPU (never credit skipped FLOPs as utilisation)
+    # (prefix reuse: every pass covers T-1 frames -- context frames 0..T-2, then timelines 1..T-1)
     passes_per_step = ((1 + args.maskgit_steps) if reuse else (cfg.T - 1) * args.maskgit_steps) * B
-    F = pass_flops(cfg)
+    F = pass_flops(cfg, cfg.T - 1) if reuse else pass_flops(cfg)
     peak = PEAK_TFLOPS[args.precision]
     achieved = gemm_flops / max(gemm_ms, 1e-9) / 1e9  # TFLOP/s over all timed GEMM launches
     out = {
@@ -318,10 +320,11 @@ def main():
         "dtype": DTYPE[args.precision], "data": "synthetic",
         "config": {"workload": f"teacher-forced evaluate (predict_zframe_logits semantics): 15 timesteps x "
                                f"{args.maskgit_steps} MaskGIT steps, temperature 0, {B} clips/GPU/step, "
-                               f"{'teacher-forced prefix reuse (1 clean pass + ' + str(args.maskgit_steps) + ' masked-frame passes, outputs identical to the full schedule)' if reuse else 'full-forward schedule'}, "
+                               f"{'teacher-forced prefix reuse (1 clean pass + ' + str(args.maskgit_steps) + ' masked-frame passes of 15 frames each, outputs identical to the full schedule)' if reuse else 'full-forward schedule'}, "
                                f"{'GENIE_138M-shape L=32 H=8 d=512 (shape inferred: config.json is hub-only)' if args.model == 'c138' else 'GENIE_35M magvit_n32_h8_d256'}",
                    "clips_per_gpu": B, "global_clips": B * world, "maskgit_steps": args.maskgit_steps,
                    "executed_forward_passes_per_step_per_gpu": passes_per_step,
+                   "frames_per_executed_pass": (cfg.T - 1) if reuse else cfg.T,
                    "reference_schedule_forward_passes_per_step_per_gpu": (cfg.T - 1) * args.maskgit_steps * B,
                    "prefix_reuse": reuse, "parallelism": f"dp{world}",
                    "ranks_reported_by_backend": torch.distributed.get_world_size() if world > 1 else 1,

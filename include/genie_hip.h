@@ -170,16 +170,22 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int
 /* ---- teacher-forced prefix reuse (evaluate.py:107-116 recomputes frames < t in every timeline) -----------------
  * Temporal attention is causal and every other op is per-frame, so in the evaluator's timeline t the activations of
  * the ground-truth frames < t equal those of ONE forward over the ground-truth clip ("clean pass"), and frame t
- * itself only needs their temporal keys/values.  genie_clean_pass runs that forward and stores every layer's
- * temporal qkv (L, B, T, S, 3d) f32 in `cache`; genie_masked_frames_logits then evaluates "frame t in timeline t"
- * for ALL t at once: `frames` (B,T,S) holds, at frame t, the current tokens of timeline t's frame t (all-mask at
- * MaskGIT step 0); frame i attends cached keys j < i and its own key.  logits: token-major (B,T,S,V).
- * Same per-row arithmetic as the full forwards: (1 + steps*T/(T-1)... ) ~ 3 passes instead of 15*steps. */
+ * itself only needs their temporal keys/values.
+ *   genie_clean_pass: `ids` (B, nframes, S) = clip frames 0..nframes-1; runs that forward and stores every layer's
+ *     temporal qkv (L, B, nframes, S, 3d) f32 in `cache`.  The evaluator needs nframes = T-1 (no timeline has the
+ *     last frame as context).
+ *   genie_masked_frames_logits: evaluates "frame t in timeline t" for nframes timelines at once: slot i of `frames`
+ *     (B, nframes, S) holds the current tokens of clip frame frame0 + i in its own timeline (all-mask at MaskGIT step 0);
+ *     it attends the cached keys of clip frames < frame0 + i and its own key.  `cache` comes from a clean pass with the
+ *     same nframes; frame0 is 1 (slots = clip frames 1..nframes, the evaluator's case) or 0 (slot 0 = frame 0 seeing
+ *     only itself).  logits: token-major (B, nframes, S, V).
+ * Same per-row arithmetic as the full forwards: (1 + steps) passes over T-1 frames instead of 15*steps over T.
+ * genie_prefix_cache_bytes is the size for nframes = T (an upper bound). */
 size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B);
-int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, float* cache,
+int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int nframes, float* cache,
                      size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);
-int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* w, const int64_t* frames, int B,
-                               const float* cache, size_t cache_bytes, float* logits, void* workspace,
+int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* w, const int64_t* frames, int B, int frame0,
+                               int nframes, const float* cache, size_t cache_bytes, float* logits, void* workspace,
                                size_t workspace_bytes, void* stream);
 
 /* Temporal KV cache for autoregressive generation (generate.py:81-95 re-runs the full 16-frame forward for every
