@@ -115,6 +115,11 @@ SIGNATURES = {
     "genie_conv1x1_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_conv_direct_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          c_ptr]),
+    "genie_conv_gn_part_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "genie_conv3x3_gn_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, c_ptr, C.c_int, c_ptr]),
+    "genie_group_norm_swish_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int,
+                                                    C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_ptr]),
     "genie_group_norm_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "genie_group_norm_swish_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_float, C.c_int, c_ptr]),

@@ -122,6 +122,7 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
     }
     GENIE_TRY(launch_gemm_f32(u, d, 0, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, qkv, 3 * d, 0, M, 3 * d, d, 1,
                               0, 1.0f, st));
+    if (temporal && w.stop_after_tqkv) return GENIE_OK;
     if (!temporal) {
         int rc = launch_attn_spatial_f32_mfma(qkv, ao, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale,
                                               nw, nb, st);
@@ -157,6 +158,7 @@ int st_block_exact(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     GENIE_TRY(attention_block(c, lw.spatial, u, x, w, B, false, st));
     // temporal: x += TmpAttn(x, causal), no pre-norm  (st_transformer.py:77-78)
     GENIE_TRY(attention_block(c, lw.temporal, x, x, w, B, true, st));
+    if (w.stop_after_tqkv) return GENIE_OK;
     // MLP: x += fc2(gelu(fc1(norm2(x))))  (st_transformer.py:81, 16-25)
     u = x;
     if (!c.qk_norm) {
@@ -379,8 +381,10 @@ static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int
         if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; }
         else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; w.tshift = tshift; }
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
+        w.stop_after_tqkv = clean && i + 1 == c.num_layers;  // nothing reads the clean pass's final hidden state
         int rc = st_block(c, wt.layers_host[i], w.x, w, B, st);
         w.skip_shadow_mlp = false;
+        w.stop_after_tqkv = false;
         w.tqkv = nullptr;
         w.tcache = nullptr;
         w.tshift = 0;
@@ -659,6 +663,25 @@ int genie_group_norm_swish_bf16(const uint16_t* x, const float* gamma, const flo
     GENIE_CHECK_ARG(x && gamma && beta && y && stats_ws && n >= 0, "group_norm_swish: bad argument");
     if (n == 0) return GENIE_OK;
     return launch_gn_swish(x, gamma, beta, y, stats_ws, n, HW, C, groups, eps, apply_swish, as_stream(stream));
+}
+size_t genie_conv_gn_part_floats(int n, int H, int W, int Cout) {
+    if (n <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    return conv_gn_part_floats(n, H, W, Cout);
+}
+int genie_conv3x3_gn_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, const uint16_t* residual, uint16_t* y,
+                          const uint16_t* zero_page, int n, int H, int W, int Cin, int Cout, int depth_to_space, int stride,
+                          float* gn_part, int groups, void* stream) {
+    GENIE_CHECK_ARG(x && w_packed && y && zero_page && gn_part && n >= 0 && H >= 1 && W >= 1, "conv3x3_gn: bad argument");
+    return launch_conv3x3_igemm(x, w_packed, bias, residual, y, zero_page, n, H, W, Cin, Cout, depth_to_space,
+                                as_stream(stream), stride, gn_part, groups);
+}
+int genie_group_norm_swish_fused_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y,
+                                      const float* gn_part, float* stats_ws, int n, int H, int W, int Cout, int depth_to_space,
+                                      int groups, float eps, int apply_swish, void* stream) {
+    GENIE_CHECK_ARG(x && gamma && beta && y && gn_part && stats_ws && n >= 0 && groups >= 1, "group_norm_swish_fused: bad argument");
+    if (n == 0) return GENIE_OK;
+    return launch_gn_swish_tiles(x, gamma, beta, y, gn_part, stats_ws, n, H, W, Cout, depth_to_space, groups, eps, apply_swish,
+                                 as_stream(stream));
 }
 int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_pix, int bits, int cpad, void* stream) {
     GENIE_CHECK_ARG(ids && z && n_pix >= 0 && bits >= 1 && bits <= 62 && cpad >= bits, "bits_nhwc: bad argument");

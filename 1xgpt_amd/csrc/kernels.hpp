@@ -31,6 +31,8 @@ struct Workspace {
     // 16-bit precisions: the block's last GEMM need not refresh the 16-bit shadow of x when the next consumer is a
     // LayerNorm (set by the layer loops for every layer but the last when the block has pre-norms)
     bool skip_shadow_mlp = false;
+    // clean pass, last layer: only the temporal qkv (the cache entry) is needed -- the block returns right after that GEMM
+    bool stop_after_tqkv = false;
 };
 
 // Brackets one launch with HIP events when profiling of `cls` is enabled (see genie_profile_* in the ABI).
@@ -90,7 +92,10 @@ int launch_rescale_u8(const void* x, int is_bf16, uint8_t* out, size_t n, hipStr
 int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits, hipStream_t st);
 int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bias, const uint16_t* residual, uint16_t* Y,
                          const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st,
-                         int stride = 1);
+                         int stride = 1, float* gn_part = nullptr, int gn_groups = 0);
+size_t conv_gn_part_floats(int n_img, int H, int Wd, int Cout);
+int launch_gn_swish_tiles(const uint16_t* X, const float* gamma, const float* beta, uint16_t* Y, const float* part, float* stats,
+                          int n_img, int H, int Wd, int Cout, int d2s, int groups, float eps, int apply_swish, hipStream_t st);
 int launch_frames_to_nhwc(const uint8_t* f, uint16_t* x, long n_img, int HW, int cin, int cpad, hipStream_t st);
 int launch_tokens_from_nhwc(const uint16_t* h, int64_t* ids, long n_pix, int bits, int cpad, hipStream_t st);
 size_t gn_scratch_floats(int n_img, int HW, int groups);

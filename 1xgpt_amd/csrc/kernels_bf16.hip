@@ -722,6 +722,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     } else {
     GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+    if (w.stop_after_tqkv) return GENIE_OK;
     if (w.tcache) {
         rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
                                          nwt, nbt, st, xn16, 0, w.tshift);
@@ -836,6 +837,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     } else {
     GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+    if (w.stop_after_tqkv) return GENIE_OK;
     if (w.tcache) {
         rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
                                          nwt, nbt, st, as, pd, w.tshift);

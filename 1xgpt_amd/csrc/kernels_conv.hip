@@ -28,7 +28,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
                                                               const uint16_t* __restrict__ residual,
                                                               uint16_t* __restrict__ Y, const uint16_t* __restrict__ zero,
                                                               int n_img, int H, int Wd, int Cin, int Cout, int flags,
-                                                              int stride) {
+                                                              int stride, float* __restrict__ gn_part, int gn_cpg) {
     constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
     constexpr int ROWB = 128, SPR = 8, RPB = 2;
     constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB, STAGE_B = A_TILE + W_TILE;  // 48 KB
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
     if (bias && col < Cout) bv = *reinterpret_cast<const float4*>(bias + col);
     const bool d2s = flags & CONV_D2S;
     const int Cq = Cout >> 2;  // channels after depth-to-space
+    float gs = 0.f, gq = 0.f;  // GroupNorm partials of this lane's 4 channels (one group: cpg % 4 == 0) over its 16 rows
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
         const int rl = it * 4 + (lane >> 4);
@@ -178,16 +179,71 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
             v.x += bf16_to_f32((uint16_t)(rr.x & 0xFFFF)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
             v.z += bf16_to_f32((uint16_t)(rr.y & 0xFFFF)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
         }
+        const uint16_t b0 = f32_to_bf16(v.x), b1 = f32_to_bf16(v.y), b2 = f32_to_bf16(v.z), b3 = f32_to_bf16(v.w);
         uint2 pk;
-        pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-        pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        pk.x = (uint32_t)b0 | ((uint32_t)b1 << 16);
+        pk.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
         *reinterpret_cast<uint2*>(Y + oidx) = pk;
+        if (gn_part) {  // statistics of the STORED (bf16-rounded) tensor, like a separate pass over Y would see
+            const float r0 = bf16_to_f32(b0), r1 = bf16_to_f32(b1), r2 = bf16_to_f32(b2), r3 = bf16_to_f32(b3);
+            gs += (r0 + r1) + (r2 + r3);
+            gq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        }
+    }
+    if (gn_part) {
+        // ---- fixed-order reduction of the tile's GroupNorm partials: every lane parks (sum, sumsq) behind the transpose
+        // scratch, then one thread per (local group, moment) adds its contributors in (wave row, lane) order.  The tile's 128
+        // columns hold 128 / cpg whole groups (launcher: 128 % cpg == 0; with depth-to-space the 128 columns lie inside one
+        // sub-pixel block, so col - n0 indexes the GroupNorm channel relative to the tile as well).
+        float* ps = reinterpret_cast<float*>(smem + 8 * 64 * 64 * 4);  // [8 waves][64 lanes][2]
+        ps[(wid * 64 + lane) * 2] = gs;
+        ps[(wid * 64 + lane) * 2 + 1] = gq;
+        __syncthreads();
+        const int ngrp = BN / gn_cpg;
+        if (tid < ngrp * 2) {
+            const int g = tid >> 1, which = tid & 1;
+            const int c_lo = g * gn_cpg;                 // first tile column of the group
+            const int wn_g = c_lo >> 6;                  // the wave column that owns it
+            const int l_lo = (c_lo & 63) >> 2, l_n = gn_cpg >> 2;  // lanes (lane & 15) in [l_lo, l_lo + l_n)
+            float a = 0.f;
+            for (int wmi = 0; wmi < 4; ++wmi)
+                for (int rg = 0; rg < 4; ++rg)
+                    for (int l = 0; l < l_n; ++l)
+                        a += ps[(((wmi * 2 + wn_g) * 64) + rg * 16 + l_lo + l) * 2 + which];
+            gn_part[((size_t)m_tile * nt + n_tile) * 64 + tid] = a;
+        }
     }
 }
 
+// per-tile (sum, sumsq) partials written by conv3x3_igemm_kernel -> (mean, rstd) per (image, group): tiles added in order (f64)
+__global__ void gn_finalize_tiles_kernel(const float* __restrict__ part, float* __restrict__ stats, int n_img, int groups,
+                                         int tiles_per_img, int nt, int cpg, int Cq, int d2s, float cnt, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img * groups) return;
+    const int img = i / groups, g = i - img * groups;
+    double s = 0.0, q = 0.0;
+    const int nsub = d2s ? 4 : 1;
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int colb = sub * Cq + g * cpg;  // conv output column of the group's first channel
+        const int n_tile = colb >> 7, lg = (colb & 127) / cpg;
+        for (int j = 0; j < tiles_per_img; ++j) {
+            const float* pp = part + ((size_t)(img * tiles_per_img + j) * nt + n_tile) * 64 + lg * 2;
+            s += (double)pp[0];
+            q += (double)pp[1];
+        }
+    }
+    const double mean = s / cnt;
+    const double var = fmax(q / cnt - mean * mean, 0.0);
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// gn_part != NULL: also write the GroupNorm(gn_groups) partial sums of the output (per 256x128 tile: [64] floats =
+// (sum, sumsq) per local group), to be finalised by launch_gn_swish_tiles.  Needs whole images per 256-pixel tile row block
+// (H*W % 256 == 0), whole groups per 128-column tile and C_out % 128 == 0; GENIE_E_UNSUPPORTED otherwise (nothing launched).
 int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bias, const uint16_t* residual, uint16_t* Y,
                          const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st,
-                         int stride) {
+                         int stride, float* gn_part, int gn_groups) {
     GENIE_CHECK_SHAPE(stride == 1 || (stride == 2 && !d2s), "conv3x3_igemm: stride %d unsupported", stride);
     GENIE_CHECK_SHAPE(Cin % 64 == 0 && Cout % 4 == 0, "conv3x3_igemm: C_in %% 64 and C_out %% 4 required (got %d, %d)", Cin,
                       Cout);
@@ -195,12 +251,20 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
     const long M = (long)n_img * H * Wd;
     if (M <= 0) return GENIE_OK;
     const int mt = (int)((M + 255) / 256), nt = (Cout + 127) / 128;
+    int gn_cpg = 0;
+    if (gn_part) {
+        const int Cgn = d2s ? Cout / 4 : Cout;
+        if (gn_groups <= 0 || Cgn % gn_groups) return GENIE_E_UNSUPPORTED;
+        gn_cpg = Cgn / gn_groups;
+        if (((long)H * Wd) % 256 || Cout % 128 || gn_cpg % 4 || 128 % gn_cpg || 128 / gn_cpg > 32 || (d2s && Cgn % 128))
+            return GENIE_E_UNSUPPORTED;
+    }
     const size_t lds = 3 * 48 * 1024;
     ProfScope prof(GENIE_KC_OTHER, 2.0 * M * Cout * 9.0 * Cin, 2.0 * (M * (double)Cin + M * (double)Cout + 9.0 * Cin * Cout),
                    st);
     (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv3x3_igemm_kernel<<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout,
-                                                    d2s ? CONV_D2S : 0, stride);
+                                                    d2s ? CONV_D2S : 0, stride, gn_part, gn_cpg);
     GENIE_LAUNCH_CHECK("conv3x3_igemm");
     return GENIE_OK;
 }
@@ -321,6 +385,31 @@ int launch_gn_swish(const uint16_t* X, const float* gamma, const float* beta, ui
     gn_finalize_kernel<<<(n_img * groups + 255) / 256, 256, 0, st>>>(part, stats, n_img * groups, groups, nblk,
                                                                       (float)HW * (C / groups), eps);
     GENIE_LAUNCH_CHECK("gn_finalize");
+    const long n_chunks = (long)n_img * HW * (C / 8);
+    gn_swish_kernel<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>(X, stats, gamma, beta, Y, n_chunks, HW, C, groups,
+                                                                        apply_swish);
+    GENIE_LAUNCH_CHECK("gn_swish");
+    return GENIE_OK;
+}
+
+// floats of `gn_part` a conv launch with fused statistics writes: 64 per 256x128 tile
+size_t conv_gn_part_floats(int n_img, int H, int Wd, int Cout) {
+    const long M = (long)n_img * H * Wd;
+    return (size_t)((M + 255) / 256) * (size_t)((Cout + 127) / 128) * 64;
+}
+
+// GroupNorm + swish of the tensor a conv with fused statistics produced: X is that conv's output ((n, H, W, Cout), or
+// (n, 2H, 2W, Cout/4) with depth-to-space), `part` its partials.  stats: n * groups * 2 floats of scratch.
+int launch_gn_swish_tiles(const uint16_t* X, const float* gamma, const float* beta, uint16_t* Y, const float* part, float* stats,
+                          int n_img, int H, int Wd, int Cout, int d2s, int groups, float eps, int apply_swish, hipStream_t st) {
+    const int C = d2s ? Cout / 4 : Cout;
+    const int HW = (d2s ? 4 : 1) * H * Wd;
+    GENIE_CHECK_SHAPE(C % groups == 0 && (C / groups) % 4 == 0 && C % 8 == 0 && ((long)H * Wd) % 256 == 0 && Cout % 128 == 0,
+                      "group_norm (fused statistics): geometry unsupported (C=%d, H*W=%d)", C, H * Wd);
+    const int cpg = C / groups;
+    gn_finalize_tiles_kernel<<<(n_img * groups + 255) / 256, 256, 0, st>>>(part, stats, n_img, groups, (H * Wd) / 256, Cout / 128, cpg,
+                                                                           Cout / 4, d2s, (float)HW * cpg, eps);
+    GENIE_LAUNCH_CHECK("gn_finalize_tiles");
     const long n_chunks = (long)n_img * HW * (C / 8);
     gn_swish_kernel<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>(X, stats, gamma, beta, Y, n_chunks, HW, C, groups,
                                                                         apply_swish);

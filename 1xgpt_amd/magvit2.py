@@ -310,23 +310,53 @@ class HipDecoder:
 
     # -- primitive wrappers (x: (n, H, W, C) bf16 contiguous)
     def _gn(self, x, gb, swish=True):
+        """GroupNorm(32, 1e-6) [+ swish].  When x came out of ``_conv3`` with fused statistics (``x._gn``: the conv's
+        per-tile partial sums and geometry) no statistics pass over x runs."""
         n, H, W, C = x.shape
         y = torch.empty_like(x)
+        fused = getattr(x, "_gn", None)
+        if fused is not None:
+            part, ch, cw, cout, d2s = fused
+            stats = torch.empty(n * 32 * 2, dtype=torch.float32, device=self.dev)
+            _lib.check(self.lib.genie_group_norm_swish_fused_bf16(x.data_ptr(), gb[0].data_ptr(), gb[1].data_ptr(), y.data_ptr(),
+                                                                  part.data_ptr(), stats.data_ptr(), n, ch, cw, cout, int(d2s),
+                                                                  32, 1e-6, int(swish), _stream()),
+                       "genie_group_norm_swish_fused_bf16")
+            return y
         stats = torch.empty(self.lib.genie_group_norm_scratch_floats(n, H * W, 32), dtype=torch.float32, device=self.dev)
         _lib.check(self.lib.genie_group_norm_swish_bf16(x.data_ptr(), gb[0].data_ptr(), gb[1].data_ptr(), y.data_ptr(),
                                                         stats.data_ptr(), n, H * W, C, 32, 1e-6, int(swish), _stream()),
                    "genie_group_norm_swish_bf16")
         return y
 
-    def _conv3(self, x, wp, residual=None, d2s=False):
+    def _conv3(self, x, wp, residual=None, d2s=False, stride=1, gn=True):
+        """3x3 conv (stride 1, or 2 for the encoder's downsample; H, W below are the OUTPUT size).  gn=True asks the conv
+        to also emit the GroupNorm statistics of its output (every conv here but the last feeds a GroupNorm); geometries
+        the fused form does not cover (tiles that straddle images, narrow layers) take the plain conv and the separate
+        statistics pass."""
         w, b, ci, co = wp
-        n, H, W, C = x.shape
+        n, Hi, Wi, C = x.shape
         assert C == ci
+        H, W = Hi // stride, Wi // stride
         y = torch.empty((n, 2 * H, 2 * W, co // 4) if d2s else (n, H, W, co), dtype=torch.bfloat16, device=self.dev)
-        _lib.check(self.lib.genie_conv3x3_bf16(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
-                                               0 if residual is None else residual.data_ptr(), y.data_ptr(),
-                                               self.zero.data_ptr(), n, H, W, ci, co, int(d2s), _stream()),
-                   "genie_conv3x3_bf16")
+        bp = 0 if b is None else b.data_ptr()
+        rp = 0 if residual is None else residual.data_ptr()
+        if gn:
+            part = torch.empty(self.lib.genie_conv_gn_part_floats(n, H, W, co), dtype=torch.float32, device=self.dev)
+            rc = self.lib.genie_conv3x3_gn_bf16(x.data_ptr(), w.data_ptr(), bp, rp, y.data_ptr(), self.zero.data_ptr(), n, H, W,
+                                                ci, co, int(d2s), stride, part.data_ptr(), 32, _stream())
+            if rc == 0:
+                y._gn = (part, H, W, co, d2s)
+                return y
+            if rc != _lib.E_UNSUPPORTED:
+                _lib.check(rc, "genie_conv3x3_gn_bf16")
+        if stride == 2:
+            assert residual is None and not d2s
+            _lib.check(self.lib.genie_conv3x3_s2_bf16(x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), self.zero.data_ptr(), n, H, W,
+                                                      ci, co, _stream()), "genie_conv3x3_s2_bf16")
+        else:
+            _lib.check(self.lib.genie_conv3x3_bf16(x.data_ptr(), w.data_ptr(), bp, rp, y.data_ptr(), self.zero.data_ptr(), n, H, W,
+                                                   ci, co, int(d2s), _stream()), "genie_conv3x3_bf16")
         return y
 
     def _conv1(self, x, wp):
@@ -365,7 +395,7 @@ class HipDecoder:
             if lvl["up"] is not None:
                 x = self._conv3(x, lvl["up"], d2s=True)
         x = self._gn(x, self.norm_out)
-        return self._conv3(x, self.conv_out)
+        return self._conv3(x, self.conv_out, gn=False)
 
     @torch.no_grad()
     def decode_tokens(self, ids_nhw: torch.LongTensor, return_float=False):
@@ -427,13 +457,7 @@ class HipEncoder(HipDecoder):
             for blk in lvl["blocks"]:
                 x = self._res(x, blk)
             if lvl["down"] is not None:
-                w, b, ci, co = lvl["down"]
-                nn_, h_, w_, _ = x.shape
-                y = torch.empty(nn_, h_ // 2, w_ // 2, co, dtype=torch.bfloat16, device=self.dev)
-                _lib.check(self.lib.genie_conv3x3_s2_bf16(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
-                                                          y.data_ptr(), self.zero.data_ptr(), nn_, h_ // 2, w_ // 2, ci, co,
-                                                          _stream()), "genie_conv3x3_s2_bf16")
-                x = y
+                x = self._conv3(x, lvl["down"], stride=2)
         for blk in self.mid:
             x = self._res(x, blk)
         x = self._gn(x, self.norm_out)

@@ -298,6 +298,21 @@ int genie_conv_direct_bf16(const uint16_t* x, const uint16_t* w_packed, const fl
 size_t genie_group_norm_scratch_floats(int n, int HW, int groups);
 int genie_group_norm_swish_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats_ws, int n,
                                 int HW, int C, int groups, float eps, int apply_swish, void* stream);
+/* GroupNorm statistics fused into the producing convolution ("fused GN+swish").
+ * genie_conv3x3_gn_bf16 = genie_conv3x3_bf16 / genie_conv3x3_s2_bf16 (stride 1 or 2) that also writes, per 256-pixel x
+ *   128-channel output tile, the (sum, sumsq) of the STORED bf16 output for each GroupNorm(groups) group of the tile
+ *   (gn_part: genie_conv_gn_part_floats(n, H, W, Cout) floats; fixed reduction order, no atomics).  Needs H*W %% 256 == 0,
+ *   C_out %% 128 == 0 and groups of 4, 8 or 16 channels; returns GENIE_E_UNSUPPORTED otherwise
+ *   without launching, and the caller uses the separate-statistics path.
+ * genie_group_norm_swish_fused_bf16: GroupNorm(groups, eps) [+ swish] of that convolution's output x from its partials:
+ *   no statistics pass over x.  H, W, Cout, depth_to_space are the CONVOLUTION's; stats_ws: n * groups * 2 floats. */
+size_t genie_conv_gn_part_floats(int n, int H, int W, int Cout);
+int genie_conv3x3_gn_bf16(const uint16_t* x, const uint16_t* w_packed, const float* bias, const uint16_t* residual, uint16_t* y,
+                          const uint16_t* zero_page, int n, int H, int W, int Cin, int Cout, int depth_to_space, int stride,
+                          float* gn_part, int groups, void* stream);
+int genie_group_norm_swish_fused_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y,
+                                      const float* gn_part, float* stats_ws, int n, int H, int W, int Cout, int depth_to_space,
+                                      int groups, float eps, int apply_swish, void* stream);
 int genie_bits_from_tokens_nhwc_bf16(const int64_t* ids, uint16_t* z, int64_t n_pix, int bits, int cpad, void* stream);
 int genie_rescale_u8_nhwc_bf16(const uint16_t* x, uint8_t* out, int n, int HW, int cpad, int cout, void* stream);
 

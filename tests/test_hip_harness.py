@@ -131,3 +131,61 @@ def test_hip_encoder_conv_stack(magvit):
     hd = mv.HipDecoder(m.decoder)
     rgb = hd.decode_tokens(torch.from_numpy(ids).cuda())
     assert rgb.is_cuda and rgb.dtype == torch.uint8 and tuple(rgb.shape) == (3, 3, 32, 32)
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,d2s,stride", [(2, 16, 16, 64, 512, False, 1), (1, 32, 32, 128, 1024, True, 1),
+                                                       (2, 16, 32, 128, 256, False, 2), (1, 64, 64, 64, 128, False, 1)])
+def test_conv_fused_groupnorm_statistics(n, H, W, cin, cout, d2s, stride):
+    """genie_conv3x3_gn_bf16 + genie_group_norm_swish_fused_bf16 (GroupNorm statistics from the conv epilogue) against
+    (a) the plain conv + separate statistics pass (same conv bytes; normalised output within one bf16 ulp) and
+    (b) torch GroupNorm in f64 on the stored conv output (improved_model.py:24-34: GroupNorm(32, eps 1e-6) + x*sigmoid(x))."""
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + cout)
+    Hi, Wi = H * stride, W * stride
+    x = torch.randn(n, Hi, Wi, cin, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3 * cin ** 0.5)).contiguous()
+    b = torch.randn(cout, device="cuda", generator=g)
+    wp = torch.empty(cout, 9, cin, dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.genie_pack_conv_weight(w.data_ptr(), wp.data_ptr(), cout, cin, 9, st), "pack")
+    zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    C = cout // 4 if d2s else cout
+    oshape = (n, 2 * H, 2 * W, C) if d2s else (n, H, W, C)
+    res = None if (d2s or stride == 2) else torch.randn(oshape, device="cuda", generator=g).to(torch.bfloat16)
+    rp = 0 if res is None else res.data_ptr()
+    y0, y1 = torch.empty(oshape, dtype=torch.bfloat16, device="cuda"), torch.empty(oshape, dtype=torch.bfloat16, device="cuda")
+    if stride == 2:
+        _lib.check(lib.genie_conv3x3_s2_bf16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y0.data_ptr(), zero.data_ptr(), n, H, W, cin,
+                                             cout, st), "conv_s2")
+    else:
+        _lib.check(lib.genie_conv3x3_bf16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), rp, y0.data_ptr(), zero.data_ptr(), n, H, W, cin,
+                                          cout, int(d2s), st), "conv")
+    part = torch.empty(lib.genie_conv_gn_part_floats(n, H, W, cout), dtype=torch.float32, device="cuda")
+    _lib.check(lib.genie_conv3x3_gn_bf16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), rp, y1.data_ptr(), zero.data_ptr(), n, H, W, cin,
+                                         cout, int(d2s), stride, part.data_ptr(), 32, st), "conv_gn")
+    assert torch.equal(y0, y1)                                   # the convolution itself is unchanged
+    gamma = (1 + 0.1 * torch.randn(C, device="cuda", generator=g)).contiguous()
+    beta = (0.1 * torch.randn(C, device="cuda", generator=g)).contiguous()
+    HWo = oshape[1] * oshape[2]
+    z0, z1 = torch.empty_like(y0), torch.empty_like(y0)
+    ws = torch.empty(lib.genie_group_norm_scratch_floats(n, HWo, 32), dtype=torch.float32, device="cuda")
+    _lib.check(lib.genie_group_norm_swish_bf16(y0.data_ptr(), gamma.data_ptr(), beta.data_ptr(), z0.data_ptr(), ws.data_ptr(), n, HWo,
+                                               C, 32, 1e-6, 1, st), "gn")
+    ws1 = torch.empty(n * 64, dtype=torch.float32, device="cuda")
+    _lib.check(lib.genie_group_norm_swish_fused_bf16(y1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), z1.data_ptr(), part.data_ptr(),
+                                                     ws1.data_ptr(), n, H, W, cout, int(d2s), 32, 1e-6, 1, st), "gn_fused")
+    stats_sep, stats_fused = ws[:n * 64].view(n, 32, 2), ws1.view(n, 32, 2)
+    assert (stats_sep - stats_fused).abs().max().item() < 2e-5 * max(1.0, stats_sep.abs().max().item())
+    yf = y1.double().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.group_norm(yf, 32, gamma.double(), beta.double(), eps=1e-6)
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1)
+    err = (z1.double() - ref).abs()
+    assert (err <= 2.0 ** -7 * ref.abs() + 1e-3).all(), err.max().item()   # one bf16 rounding of the result
+    assert ((z0.float() - z1.float()).abs() <= 2.0 ** -7 * z0.float().abs() + 1e-6).all()
+    # order-fixed reductions: same bytes on a second call
+    part2 = torch.empty_like(part)
+    _lib.check(lib.genie_conv3x3_gn_bf16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), rp, y1.data_ptr(), zero.data_ptr(), n, H, W, cin,
+                                         cout, int(d2s), stride, part2.data_ptr(), 32, st), "conv_gn")
+    used = part.view(-1, 64)[:, : 2 * (128 // (C // 32))]
+    assert torch.equal(used, part2.view(-1, 64)[:, : 2 * (128 // (C // 32))])
