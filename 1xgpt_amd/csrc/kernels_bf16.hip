@@ -556,6 +556,11 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
             if (rc != GENIE_E_UNSUPPORTED) return rc;
         }
     }
+    {   // latency-bound problems (batch-1 generate: 256 rows per frame pass): split-K inside the workgroup, no LDS ring
+        const int rc = launch_gemm16_sm(NPL, A, lda, planeA, W, ldw, planeW, bias, Rf, Cf, C16, plane16, ldc, M, N, K, flags, alpha,
+                                        st, batch, strideA, strideW, strideC);
+        if (rc != GENIE_E_UNSUPPORTED) return rc;
+    }
     static const int force_v1 = [] { const char* e = getenv("GENIE_GEMM16_V1"); return e ? atoi(e) : 0; }();
     // small problems (batch-1 generate: M = 4096 or 256 rows): 256x128 tiles would leave most of the 256 CUs idle, the
     // 128x128 kernel below makes 2x the workgroups (and runs two of them per CU)

@@ -1,0 +1,244 @@
+// gemm16_sm_kernel: the 16-bit NT GEMM for SMALL problems (batch-1 generate: M = 256 rows per frame pass), where a launch is
+// bound by the serial chain "load a K-step -> barrier -> MFMA" of a tiled kernel, not by throughput.
+//
+//   C[M,N] (+)= epilogue( alpha * A[M,K] . W[N,K]^T + bias )      (nn.Linear; st_transformer.py:16-25, attention.py:27-29)
+//
+//   * No LDS staging and no barrier in the main loop: a workgroup owns one TM x TN output tile and its NW waves split K
+//     between them (split-K INSIDE the workgroup).  Each wave streams its K range of the tile's A rows and W rows straight
+//     from L2 into MFMA fragments, the whole range (or 64-wide chunks, double buffered) in flight at once.
+//   * Fragment loads are 32 contiguous bytes per lane: the k index inside a 32-wide block is permuted (lane half h takes
+//     k = 16h .. 16h+15; its first 8 values feed MFMA step 0, the other 8 step 1) -- a contraction does not care about the
+//     order of k as long as A and W agree.
+//   * The NW partial tiles meet in LDS and are added in wave order (fixed order: bit-reproducible), then the usual fused
+//     epilogue (bias, erf-GELU, residual, f32 and/or 16-bit operand output) runs on whole rows.
+//   * NPL = 2 ("f16x3"): split operands a = hi + lo'/2048; hi.hi goes to one accumulator, hi.lo' + lo'.hi to a second one
+//     that is scaled by 2^-11 at the end (no in-register weight scaling: valid for any operand magnitudes).
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mma_sm(const s16x8& a, const s16x8& b, const f32x16& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+}  // namespace
+
+template <int NPL, int TM, int TN, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
+                                                                const uint16_t* __restrict__ W, long ldw, long planeW,
+                                                                const float* __restrict__ bias, float* __restrict__ Cf,
+                                                                uint16_t* __restrict__ C16, long plane16, long ldc, int M, int N,
+                                                                int K, int flags, float alpha, long strideA, long strideC,
+                                                                const float* Rf, long strideW) {
+    constexpr int MI = TM / 32, NJ = TN / 32;
+    constexpr int NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][TM][TN] partial tiles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nt = (N + TN - 1) / TN;
+    const int m0 = (blockIdx.x / nt) * TM, n0 = (blockIdx.x % nt) * TN;
+    A += (size_t)blockIdx.y * strideA;
+    W += (size_t)blockIdx.y * strideW;
+    const int KW = K / NW;                  // this wave's K range (launcher: KW % 32 == 0)
+    const int kw0 = wid * KW;
+
+    const uint16_t* ap[MI];
+    const uint16_t* bp[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int row = m0 + 32 * i + r;
+        row = row < M ? row : M - 1;        // ragged tiles: the surplus rows are computed and never stored
+        ap[i] = A + (size_t)row * lda + kw0 + 16 * h;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int row = n0 + 32 * j + r;
+        row = row < N ? row : N - 1;
+        bp[j] = W + (size_t)row * ldw + kw0 + 16 * h;
+    }
+
+    f32x16 accm[MI][NJ], accc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accc[i][j][e] = 0.f; }
+
+    // one block = 32 k: per (row tile, plane) a lane holds 16 values = the operands of two MFMA steps.  NB blocks are in
+    // flight per wave (a register ring: a block's registers are refilled right after its MFMAs have been issued).
+    struct Block {
+        s16x8 a[MI][NPL][2];
+        s16x8 b[NJ][NPL][2];
+    };
+    constexpr int REGS = (MI + NJ) * NPL * 8;
+    constexpr int NB = 128 / REGS < 2 ? 2 : (128 / REGS > 8 ? 8 : 128 / REGS);
+    auto load = [&](Block& c, int k) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const s16x8* src = reinterpret_cast<const s16x8*>(ap[i] + (size_t)p * planeA + k);
+                c.a[i][p][0] = src[0];
+                c.a[i][p][1] = src[1];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const s16x8* src = reinterpret_cast<const s16x8*>(bp[j] + (size_t)p * planeW + k);
+                c.b[j][p][0] = src[0];
+                c.b[j][p][1] = src[1];
+            }
+        }
+    };
+    auto compute = [&](const Block& c) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (NPL == 1) {
+                        accm[i][j] = mma_sm<false>(c.a[i][0][s], c.b[j][0][s], accm[i][j]);
+                    } else {
+                        accm[i][j] = mma_sm<true>(c.a[i][0][s], c.b[j][0][s], accm[i][j]);
+                        accc[i][j] = mma_sm<true>(c.a[i][0][s], c.b[j][NPL - 1][s], accc[i][j]);
+                        accc[i][j] = mma_sm<true>(c.a[i][NPL - 1][s], c.b[j][0][s], accc[i][j]);
+                    }
+                }
+    };
+    Block buf[NB];
+    const int nblk = KW / 32;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b < nblk) load(buf[b], b * 32);
+    for (int c = 0; c < nblk; c += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (c + b < nblk) {
+                compute(buf[b]);
+                if (c + b + NB < nblk) load(buf[b], (c + b + NB) * 32);
+            }
+        }
+    }
+
+    // ---- the NW partial tiles meet in LDS (accumulator element e of lane (r, h): row 8*(e>>2) + 4h + (e&3), column r)
+    float* mine = red + (size_t)wid * TM * TN;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = NPL == 2 ? accm[i][j][e] + accc[i][j][e] * (1.0f / 2048.0f) : accm[i][j][e];
+                mine[(32 * i + 8 * (e >> 2) + 4 * h + (e & 3)) * TN + 32 * j + r] = v;
+            }
+    __syncthreads();
+    if (Cf) Cf += (size_t)blockIdx.y * strideC;
+    if (C16) C16 += (size_t)blockIdx.y * strideC;
+    const float* Rsrc = Rf ? Rf + (size_t)blockIdx.y * strideC : Cf;
+    const bool do_gelu = flags & G16X_GELU, do_acc = flags & G16X_ACCUM;
+    const bool out16 = flags & G16X_OUT16, outf = flags & G16X_OUTF32;
+    constexpr int C4 = TN / 4;
+#pragma unroll
+    for (int idx4 = tid; idx4 < TM * C4; idx4 += NT) {
+        const int rl = idx4 / C4, c4 = (idx4 % C4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(red + rl * TN + c4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {  // wave order: the sum does not depend on timing
+            const float4 o = *reinterpret_cast<const float4*>(red + (size_t)w * TM * TN + rl * TN + c4);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        const int row = m0 + rl, col = n0 + c4;
+        if (row >= M || col >= N) continue;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+        v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
+        if (do_gelu) {
+            const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+            v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+        }
+        const size_t idx = (size_t)row * ldc + col;
+        if (do_acc) {
+            const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
+        if (out16) {
+            if (flags & G16X_GELU16) {
+                const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+                v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+            }
+            if (NPL == 1 || plane16 == 0) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>(C16 + idx) = pk;
+            } else {
+                uint32_t h01, h23, l01, l23;
+                split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
+                *reinterpret_cast<uint2*>(C16 + idx) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(C16 + (size_t)plane16 + idx) = make_uint2(l01, l23);
+            }
+        }
+    }
+}
+
+// Returns GENIE_E_UNSUPPORTED when the problem is not "small" or does not fit the tiling; the caller (launch_gemm16 in
+// kernels_bf16.hip) then takes a throughput kernel.  npl = 1: bf16 operands; 2: split-f16 planes.
+int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
+                     const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,
+                     int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC) {
+    static const int on = [] { const char* e = getenv("GENIE_GEMM16_SM"); return e ? atoi(e) : 1; }();
+    static const long max_out = [] { const char* e = getenv("GENIE_GEMM16_SM_MAX"); return e ? atol(e) : 1L << 20; }();
+    if (!on || (long)M * N * batch > max_out) return GENIE_E_UNSUPPORTED;
+    if (N % 4 || ldc % 4 || lda % 8 || ldw % 8 || planeA % 8 || planeW % 8 || K % 128) return GENIE_E_UNSUPPORTED;
+    if (npl == 2 && (flags & G16X_OUT16) && plane16 == 0) return GENIE_E_UNSUPPORTED;
+    const int nw = K >= 2048 ? 8 : 4;       // waves = K-splits: every wave gets >= 64 k and at most 256
+    if ((K / nw) % 32) return GENIE_E_UNSUPPORTED;
+    const double mn = (double)M * N * batch;
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
+                   2.0 * npl * ((double)M * K * batch + (double)N * K) +
+                       mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) +
+                             (flags & G16X_OUT16 ? 2 * npl : 0)),
+                   st);
+    // tile: 64x64 unless that leaves most CUs idle (N = 512 at M = 256: 32 tiles) -> 32x64 / 32x32
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    const int tm = (t64 >= 96 && !(nw == 8 && npl == 2)) ? 64 : 32;  // (8 waves share the register file two per SIMD)
+    const int tn = (t64 >= 96 || (long)((M + 31) / 32) * ((N + 63) / 64) * batch >= 96) ? 64 : 32;
+    const dim3 grid((unsigned)(((M + tm - 1) / tm) * ((N + tn - 1) / tn)), (unsigned)batch);
+#define SM_LAUNCH(NPL_, TM_, TN_, NW_)                                                                                    \
+    do {                                                                                                                  \
+        const size_t lds = (size_t)NW_ * TM_ * TN_ * 4;                                                                   \
+        (void)hipFuncSetAttribute((const void*)gemm16_sm_kernel<NPL_, TM_, TN_, NW_>,                                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+        gemm16_sm_kernel<NPL_, TM_, TN_, NW_><<<grid, NW_ * 64, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, \
+                                                                          plane16, ldc, M, N, K, flags, alpha, strideA,  \
+                                                                          strideC, Rf, strideW);                         \
+    } while (0)
+#define SM_TILE(NPL_, NW_)                                                                                                \
+    do {                                                                                                                  \
+        if constexpr (!(NPL_ == 2 && NW_ == 8)) { if (tm == 64) { SM_LAUNCH(NPL_, 64, 64, NW_); break; } }               \
+        if (tn == 64) SM_LAUNCH(NPL_, 32, 64, NW_);                                                                  \
+        else SM_LAUNCH(NPL_, 32, 32, NW_);                                                                                \
+    } while (0)
+    if (npl == 1) { if (nw == 4) SM_TILE(1, 4); else SM_TILE(1, 8); }
+    else { if (nw == 4) SM_TILE(2, 4); else SM_TILE(2, 8); }
+#undef SM_TILE
+#undef SM_LAUNCH
+    GENIE_LAUNCH_CHECK("gemm16_sm");
+    return GENIE_OK;
+}
+
+}  // namespace genie

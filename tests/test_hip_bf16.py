@@ -33,9 +33,11 @@ def models(golden):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16x3"])
-@pytest.mark.parametrize("M,N,K", [(128, 192, 64), (100, 70, 64), (513, 1024, 256), (4096, 1536, 512), (37, 64, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 192, 64), (100, 70, 64), (513, 1024, 256), (4096, 1536, 512), (37, 64, 2048),
+                                   (256, 1536, 512), (256, 512, 512), (256, 2048, 512), (256, 512, 2048), (250, 1024, 512)])
 def test_linear_lowp(prec, M, N, K):
-    """genie_linear_lowp on pre-packed operands vs float64 on the SAME rounded operands (asymmetric, ragged M/N)."""
+    """genie_linear_lowp on pre-packed operands vs float64 on the SAME rounded operands (asymmetric, ragged M/N).  The
+    256-row shapes are one frame of the batch-1 generate path: the split-K small-problem kernel (kernels_gemm_sm.hip)."""
     lib_mod = pkg("_lib")
     L = lib_mod.load()
     g = np.random.default_rng(M + N + K)
