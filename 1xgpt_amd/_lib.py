@@ -67,8 +67,8 @@ SIGNATURES = {
     "genie_compute_logits": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int,
                                        C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_prefix_cache_bytes": (C.c_size_t, [C.POINTER(GenieCfg), C.c_int]),
-    "genie_clean_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, c_ptr, C.c_size_t,
-                                   c_ptr, C.c_size_t, c_ptr]),
+    "genie_clean_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, c_ptr,
+                                   C.c_size_t, c_ptr, C.c_size_t, c_ptr]),
     "genie_masked_frames_logits": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, c_ptr,
                                              C.c_size_t, c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_frame_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, c_ptr, C.c_size_t,

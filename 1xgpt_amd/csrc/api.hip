@@ -120,6 +120,11 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
         return launch_gemm_f32(ao, d, 0, aw.proj_w, d, 0, c.proj_bias ? aw.proj_b : nullptr, x, d, 0, M, d, d, 1,
                                GEMM_ACCUM, 1.0f, st);
     }
+    const int Tq = (temporal && w.tqkv && w.tq_frames > c.T) ? w.tq_frames : c.T;  // frames per clip in qkv's layout
+    if (Tq != c.T && B > 1)  // a short clean pass into a longer cache: one GEMM batch entry per clip
+        GENIE_TRY(launch_gemm_f32(u, d, (long)c.T * c.S * d, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, qkv, 3 * d,
+                                  (long)Tq * c.S * 3 * d, c.T * c.S, 3 * d, d, B, 0, 1.0f, st));
+    else
     GENIE_TRY(launch_gemm_f32(u, d, 0, aw.qkv_w, d, 0, c.qkv_bias ? aw.qkv_b : nullptr, qkv, 3 * d, 0, M, 3 * d, d, 1,
                               0, 1.0f, st));
     if (temporal && w.stop_after_tqkv) return GENIE_OK;
@@ -135,7 +140,11 @@ static int attention_block(const genie_cfg& c, const genie_attn_weights& aw, con
                                               nw, nb, st, nullptr, 0, w.tshift));
     } else {
         int rc = launch_attn_temporal_f32_mfma(qkv, ao, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nw, nb,
-                                               st);
+                                               st, nullptr, 0, Tq);
+        if (rc == GENIE_E_UNSUPPORTED && !(Tq == c.T || B == 1)) {
+            set_error("strided temporal qkv needs the MFMA temporal kernel (8 <= frames <= 16)");
+            return GENIE_E_UNSUPPORTED;
+        }
         if (rc == GENIE_E_UNSUPPORTED)
             rc = launch_attn_generic(qkv, ao, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
                                      c.head_dim, c.attn_scale, 1, nw, nb, st);
@@ -372,13 +381,14 @@ size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B) {
 }
 
 static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int64_t* ids, int B, float* cache,
-                          bool clean, int tshift, Workspace& w, hipStream_t st) {
-    const size_t per_layer = (size_t)B * c.T * c.S * 3 * c.d_model;
+                          bool clean, int tshift, Workspace& w, hipStream_t st, int cache_frames = 0) {
+    if (cache_frames <= 0) cache_frames = c.T;  // frames per clip in the cache layout (L, B, cache_frames, S, 3d)
+    const size_t per_layer = (size_t)B * cache_frames * c.S * 3 * c.d_model;
     GENIE_TRY(launch_embed(c, wt, ids, B, w.x, st));
     if (c.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c, w.x, w, B, st));
     if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, w.x, w, B, st));
     for (int i = 0; i < c.num_layers; ++i) {
-        if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; }
+        if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; w.tq_frames = cache_frames; }
         else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; w.tshift = tshift; }
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
         w.stop_after_tqkv = clean && i + 1 == c.num_layers;  // nothing reads the clean pass's final hidden state
@@ -386,6 +396,7 @@ static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int
         w.skip_shadow_mlp = false;
         w.stop_after_tqkv = false;
         w.tqkv = nullptr;
+        w.tq_frames = 0;
         w.tcache = nullptr;
         w.tshift = 0;
         GENIE_TRY(rc);
@@ -396,28 +407,36 @@ static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int
 // The prefix passes run on `nframes` <= T frame slots per clip: a private copy of the config with T = nframes (dense
 // (B, nframes, S, *) buffers) and the positional table advanced to clip frame `frame0`.
 static int prefix_view(const genie_cfg* cfg, const genie_weights* wt, int B, int frame0, int nframes, size_t cache_bytes,
-                       genie_cfg& c2, genie_weights& w2) {
+                       genie_cfg& c2, genie_weights& w2, int cache_frames = 0) {
+    if (cache_frames <= 0) cache_frames = nframes;
     GENIE_CHECK_ARG(nframes >= 1 && frame0 >= 0 && frame0 + nframes <= cfg->T, "prefix pass: frames [%d, %d) outside the clip (T=%d)",
                     frame0, frame0 + nframes, cfg->T);
     c2 = *cfg;
     c2.T = nframes;
     w2 = *wt;
     w2.pos_embed = wt->pos_embed + (size_t)frame0 * cfg->S * cfg->d_model;  // pos_embed_TSC[0, frame0 + i]
-    const size_t need = (size_t)cfg->num_layers * B * nframes * cfg->S * 3 * cfg->d_model * sizeof(float);
+    GENIE_CHECK_ARG(cache_frames >= nframes && cache_frames <= cfg->T, "prefix pass: cache_frames %d outside [%d, %d]", cache_frames,
+                    nframes, cfg->T);
+    const size_t need = (size_t)cfg->num_layers * B * cache_frames * cfg->S * 3 * cfg->d_model * sizeof(float);
     GENIE_CHECK_ARG(cache_bytes >= need, "prefix pass: cache too small (%zu < %zu bytes)", cache_bytes, need);
     return GENIE_OK;
 }
 
-int genie_clean_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int nframes, float* cache,
-                     size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+int genie_clean_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int nframes, int cache_frames,
+                     float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream) {
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(wt && wt->layers_host && ids && cache, "clean_pass: NULL pointer");
     GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
     genie_cfg c2;
     genie_weights w2;
-    GENIE_TRY(prefix_view(cfg, wt, B, 0, nframes, cache_bytes, c2, w2));
+    GENIE_TRY(prefix_view(cfg, wt, B, 0, nframes, cache_bytes, c2, w2, cache_frames));
+    if (cache_frames != nframes && B > 1 && !(nframes >= 8 && nframes <= 16 && (cfg->head_dim == 32 || cfg->head_dim == 64))) {
+        set_error("clean_pass: a strided cache (cache_frames %d != nframes %d) at B > 1 needs 8 <= nframes <= 16 and head_dim 32/64",
+                  cache_frames, nframes);
+        return GENIE_E_UNSUPPORTED;
+    }
     Workspace w = carve(c2, B, workspace);
-    return prefix_forward(c2, w2, ids, B, cache, true, 0, w, as_stream(stream));
+    return prefix_forward(c2, w2, ids, B, cache, true, 0, w, as_stream(stream), cache_frames);
 }
 
 int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frames, int B, int frame0,

@@ -20,6 +20,8 @@ struct Workspace {
     size_t total;
     // teacher-forced prefix reuse (set per layer by the prefix entry points, NULL otherwise):
     float* tqkv;         // where the temporal qkv GEMM writes (clean pass: this layer's slice of the cache)
+    int tq_frames = 0;   // frames per clip in the layout of `tqkv` (0 = dense: cfg.T); > cfg.T when a short clean pass fills a
+                         // full-length cache (generate: prompt frames into the T-frame KV cache)
     const float* tcache; // non-NULL: temporal attention takes keys j < i + tshift from this cached qkv (masked-frames pass)
     int tshift = 0;      // clip-frame offset of the masked-frames buffers against the cache (0 or 1)
     // single-frame decode (generate with a temporal KV cache): the block runs on ONE frame (cfg.T == 1, dense
@@ -65,7 +67,7 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
                                  size_t plane = 0);
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
                                   const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
-                                  size_t plane = 0);
+                                  size_t plane = 0, int Tq = 0);
 int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
                               const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
                               size_t plane = 0);

@@ -30,7 +30,10 @@ template <int DH>
 __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  int d, float scale, const float* __restrict__ nw,
                                                                  const float* __restrict__ nb,
-                                                                 uint16_t* __restrict__ out16, size_t plane) {
+                                                                 uint16_t* __restrict__ out16, size_t plane, int qw) {
+    // qw = query waves per workgroup: 8 = the whole sequence; 1, 2, 4 = the workgroup stages all keys with its 8 waves but
+    // only waves < qw go on, with queries (blockIdx.z * qw + wave) * 32 ..: few-sequence launches (batch-1 generate: 8
+    // (sequence, head) pairs) spread over 8 / qw times as many CUs
     constexpr int S = 256, NKT = 8;
     constexpr int ROWB = DH * 2, SPR = ROWB / 16, RPB = 256 / ROWB;  // K rows: bytes, 16-B slots, rows per 256 B
     constexpr int K_PLANE = S * ROWB;                                 // bytes
@@ -118,8 +121,9 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
         }
     }
     __syncthreads();
+    if (wid >= qw) return;
 
-    const int qb = wid;  // 8 waves x 32 queries = 256
+    const int qb = blockIdx.z * qw + wid;  // 32 queries per wave
     // ---- Q fragments: lane (r,h) holds Q[r][16kk + 8h + j], split, scale folded in before the split
     f16x8 qh[DH / 16], ql[DH / 16];
     const float scale_l2 = scale * 1.4426950408889634f;  // scores carried as s*log2(e): softmax = one v_exp_f32 each
@@ -249,16 +253,17 @@ int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, i
                               const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
     if (S != 256 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
     const size_t lds = (size_t)2 * 256 * Dh * 2 + (size_t)2 * Dh * 520;
-    dim3 grid((unsigned)n_seq, H);
+    const int qw = n_seq * H <= 16 ? 1 : (n_seq * H <= 48 ? 2 : (n_seq * H <= 128 ? 4 : 8));
+    dim3 grid((unsigned)n_seq, H, 8 / qw);
     ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * Dh * H * (double)n_seq, (double)n_seq * S * H * Dh * 16.0, st);
     if (Dh == 64) {
         (void)hipFuncSetAttribute((const void*)attn_spatial_split_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attn_spatial_split_kernel<64><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane);
+        attn_spatial_split_kernel<64><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane, qw);
     } else {
         (void)hipFuncSetAttribute((const void*)attn_spatial_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attn_spatial_split_kernel<32><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane);
+        attn_spatial_split_kernel<32><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane, qw);
     }
     GENIE_LAUNCH_CHECK("attn_spatial_split");
     return GENIE_OK;

@@ -532,7 +532,7 @@ template <int NPL>
 static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                          const float* bias, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,
                          int flags, float alpha, hipStream_t st, int batch = 1, long strideA = 0, long strideC = 0,
-                         const float* Rf = nullptr, long strideW = 0, bool weights_on_w = true) {
+                         const float* Rf = nullptr, long strideW = 0, bool weights_on_w = true, bool allow_sm = true) {
     constexpr int BK = NPL == 1 ? 64 : 32;
     GENIE_CHECK_SHAPE(K % BK == 0 && K > 0, "gemm16: K=%d must be a positive multiple of %d", K, BK);
     GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
@@ -556,7 +556,7 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
             if (rc != GENIE_E_UNSUPPORTED) return rc;
         }
     }
-    {   // latency-bound problems (batch-1 generate: 256 rows per frame pass): split-K inside the workgroup, no LDS ring
+    if (allow_sm) {   // latency-bound problems (batch-1 generate: 256 rows per frame pass): split-K inside the workgroup, no LDS ring
         const int rc = launch_gemm16_sm(NPL, A, lda, planeA, W, ldw, planeW, bias, Rf, Cf, C16, plane16, ldc, M, N, K, flags, alpha,
                                         st, batch, strideA, strideW, strideC);
         if (rc != GENIE_E_UNSUPPORTED) return rc;
@@ -725,6 +725,12 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
         rc = launch_attn_temporal_single(w.fcache, nullptr, B, w.frame_T, c.S, w.frame_t, d, c.num_heads, c.head_dim,
                                          c.attn_scale, nwt, nbt, st, xn16, 0);
     } else {
+    const int Tq = (w.tqkv && w.tq_frames > c.T) ? w.tq_frames : c.T;  // frames per clip in tq's layout
+    if (Tq != c.T && B > 1)  // a short clean pass into a longer cache: one GEMM batch entry per clip
+        GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq, nullptr, 0,
+                                   3 * d, c.T * c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.T * c.S * d,
+                                   (long)Tq * c.S * 3 * d));
+    else
     GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     if (w.stop_after_tqkv) return GENIE_OK;
@@ -738,8 +744,9 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
         }
     } else {
         rc = launch_attn_temporal_f32_mfma(tq, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt,
-                                           st, xn16, 0);
+                                           st, xn16, 0, Tq);
         if (rc == GENIE_E_UNSUPPORTED) {
+            GENIE_CHECK_ARG(Tq == c.T || B == 1, "strided temporal qkv needs the MFMA temporal kernel (8 <= frames <= 16)");
             GENIE_TRY(launch_attn_generic(tq, w.logits, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
                                           c.head_dim, c.attn_scale, 1, nwt, nbt, st));
             rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
@@ -840,6 +847,12 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
         rc = launch_attn_temporal_single(w.fcache, nullptr, B, w.frame_T, c.S, w.frame_t, d, c.num_heads, c.head_dim,
                                          c.attn_scale, nwt, nbt, st, as, pd);
     } else {
+    const int Tq = (w.tqkv && w.tq_frames > c.T) ? w.tq_frames : c.T;  // frames per clip in tq's layout
+    if (Tq != c.T && B > 1)  // a short clean pass into a longer cache: one GEMM batch entry per clip
+        GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
+                                   nullptr, 0, 3 * d, c.T * c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.T * c.S * d,
+                                   (long)Tq * c.S * 3 * d));
+    else
     GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     if (w.stop_after_tqkv) return GENIE_OK;
@@ -853,8 +866,9 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
         }
     } else {
         rc = launch_attn_temporal_f32_mfma(tq, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt,
-                                           st, as, pd);
+                                           st, as, pd, Tq);
         if (rc == GENIE_E_UNSUPPORTED) {
+            GENIE_CHECK_ARG(Tq == c.T || B == 1, "strided temporal qkv needs the MFMA temporal kernel (8 <= frames <= 16)");
             float* tmp = w.logits;
             GENIE_TRY(launch_attn_generic(tq, tmp, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
                                           c.head_dim, c.attn_scale, 1, nwt, nbt, st));
@@ -915,7 +929,10 @@ int launch_linear_lowp(int precision, const uint16_t* x16, const uint16_t* W16, 
 // bf16 x bf16 -> bf16 Linear (1x1 convolution on NHWC activations)
 int launch_gemm_bf16_out16(const uint16_t* A16, const uint16_t* W16, const float* bias, uint16_t* C16, int M, int N, int K,
                            hipStream_t st) {
-    return launch_gemm16<1>(A16, K, 0, W16, K, 0, bias, nullptr, C16, 0, N, M, N, K, G16_OUT16, 1.0f, st);
+    // (no split-K kernel here: the MAGVIT2 stacks promise the same bytes for an image whatever else is in the batch, so the
+    // accumulation order must not depend on the problem size)
+    return launch_gemm16<1>(A16, K, 0, W16, K, 0, bias, nullptr, C16, 0, N, M, N, K, G16_OUT16, 1.0f, st, 1, 0, 0, nullptr, 0, true,
+                            /*allow_sm=*/false);
 }
 
 }  // namespace genie

@@ -1113,10 +1113,11 @@ __device__ __forceinline__ void store_row_chunk(float* out, uint16_t* out16, siz
 template <int DH>
 __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float* __restrict__ qkv,
                                                                      float* __restrict__ out, long n_bs, int S,
-                                                                     int d, int H, int T, float scale,
+                                                                     int d, int H, int T, int Tq, float scale,
                                                                      const float* __restrict__ nw,
                                                                      const float* __restrict__ nb,
                                                                      uint16_t* __restrict__ out16, size_t plane) {
+    // Tq: frames per clip in the layout of `qkv` (>= T; the output is dense (B,T,S,d))
     constexpr int PER = DH / 4;  // floats per lane per row; T <= 16 frames fill a 16x16 tile (rows >= T are padding:
                                  // they repeat frame T-1 on the load side and are never stored)
     const int lane = threadIdx.x & 63;
@@ -1127,7 +1128,7 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     if (bs >= n_bs) return;
     const long b = bs / S, s = bs - b * S;
     const long tok_stride = (long)S * 3 * d;                       // frame t -> t+1
-    const float* base = qkv + ((size_t)(b * T) * S + s) * 3 * d + head * DH;
+    const float* base = qkv + ((size_t)(b * Tq) * S + s) * 3 * d + head * DH;
     const float* qp = base + (size_t)(r < T ? r : T - 1) * tok_stride + g * PER;     // row t = r
     float q[PER], k[PER];
 #pragma unroll
@@ -1212,13 +1213,14 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
 
 // Temporal attention over 8 <= T <= 16 frames on a (B,T,S,3d) buffer; GENIE_E_UNSUPPORTED for other geometries.
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
-                                  const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
+                                  const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane, int Tq) {
     if (T > 16 || T < 8 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
+    if (Tq <= 0) Tq = T;
     const long n_bs = (long)B * S, waves = n_bs * H;
     ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 16.0, st);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, scale, nw, nb, out16, plane);
-    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, scale, nw, nb, out16, plane);
+    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
+    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
     GENIE_LAUNCH_CHECK("attn_temporal_f32_mfma");
     return GENIE_OK;
 }
@@ -1525,6 +1527,41 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* 
     };
     float q = norm(base[(size_t)t * tok_stride]) * scale;
     if (!act) q = 0.f;
+    if (t < 16) {
+        // the shipped window (T = 16): every cached key / value of the (position, head) is fetched up front -- 2 (t + 1)
+        // independent 4-byte-per-lane loads in flight instead of a load -> reduce -> load chain -- and the scores live in
+        // registers (static indices)
+        float kj[16], vj[16], sc16[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            kj[j] = 0.f; vj[j] = 0.f;
+            if (j <= t) { kj[j] = base[(size_t)j * tok_stride + d]; vj[j] = base[(size_t)j * tok_stride + 2 * d]; }
+        }
+        float mx16 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j <= t) {
+                const float a = wave_sum(act ? q * norm(kj[j]) : 0.f);
+                sc16[j] = a;
+                mx16 = fmaxf(mx16, a);
+            }
+        }
+        float sum16 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j <= t) { sc16[j] = expf(sc16[j] - mx16); sum16 += sc16[j]; }
+        const float inv16 = 1.0f / sum16;
+        float o16 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j <= t) o16 = fmaf(sc16[j] * inv16, vj[j], o16);
+        if (!act) return;
+        const size_t oi16 = (size_t)bs * d + head * DH + lane;
+        if (!out16) out[oi16] = o16;
+        else if (plane) { uint16_t hi, lo; split_f16(o16, hi, lo); out16[oi16] = hi; out16[plane + oi16] = lo; }
+        else out16[oi16] = f32_to_bf16(o16);
+        return;
+    }
     float sc[64];
     float mx = -INFINITY;
     for (int j = 0; j <= t; ++j) {

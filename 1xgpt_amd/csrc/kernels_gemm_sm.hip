@@ -6,9 +6,9 @@
 //   * No LDS staging and no barrier in the main loop: a workgroup owns one TM x TN output tile and its NW waves split K
 //     between them (split-K INSIDE the workgroup).  Each wave streams its K range of the tile's A rows and W rows straight
 //     from L2 into MFMA fragments, the whole range (or 64-wide chunks, double buffered) in flight at once.
-//   * Fragment loads are 32 contiguous bytes per lane: the k index inside a 32-wide block is permuted (lane half h takes
-//     k = 16h .. 16h+15; its first 8 values feed MFMA step 0, the other 8 step 1) -- a contraction does not care about the
-//     order of k as long as A and W agree.
+//   * Fragment loads are 64 contiguous bytes per lane: the k index inside a 64-wide block is permuted (lane half h takes
+//     k = 32h .. 32h+31; values 8s .. 8s+7 feed MFMA step s = 0..3) -- a contraction does not care about the order of k as
+//     long as A and W agree.  The two halves of the wave consume one whole 128-byte line of every row they touch.
 //   * The NW partial tiles meet in LDS and are added in wave order (fixed order: bit-reproducible), then the usual fused
 //     epilogue (bias, erf-GELU, residual, f32 and/or 16-bit operand output) runs on whole rows.
 //   * NPL = 2 ("f16x3"): split operands a = hi + lo'/2048; hi.hi goes to one accumulator, hi.lo' + lo'.hi to a second one
@@ -34,7 +34,7 @@ __device__ __forceinline__ f32x16 mma_sm(const s16x8& a, const s16x8& b, const f
 }
 }  // namespace
 
-template <int NPL, int TM, int TN, int NW>
+template <int NPL, int TM, int TN, int NW, int NB>
 __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
                                                                 const uint16_t* __restrict__ W, long ldw, long planeW,
                                                                 const float* __restrict__ bias, float* __restrict__ Cf,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
     const int m0 = (blockIdx.x / nt) * TM, n0 = (blockIdx.x % nt) * TN;
     A += (size_t)blockIdx.y * strideA;
     W += (size_t)blockIdx.y * strideW;
-    const int KW = K / NW;                  // this wave's K range (launcher: KW % 32 == 0)
+    const int KW = K / NW;                  // this wave's K range (launcher: KW % 64 == 0)
     const int kw0 = wid * KW;
 
     const uint16_t* ap[MI];
@@ -60,13 +60,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
     for (int i = 0; i < MI; ++i) {
         int row = m0 + 32 * i + r;
         row = row < M ? row : M - 1;        // ragged tiles: the surplus rows are computed and never stored
-        ap[i] = A + (size_t)row * lda + kw0 + 16 * h;
+        ap[i] = A + (size_t)row * lda + kw0 + 32 * h;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         int row = n0 + 32 * j + r;
         row = row < N ? row : N - 1;
-        bp[j] = W + (size_t)row * ldw + kw0 + 16 * h;
+        bp[j] = W + (size_t)row * ldw + kw0 + 32 * h;
     }
 
     f32x16 accm[MI][NJ], accc[MI][NJ];
@@ -77,34 +77,33 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
 #pragma unroll
             for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accc[i][j][e] = 0.f; }
 
-    // one block = 32 k: per (row tile, plane) a lane holds 16 values = the operands of two MFMA steps.  NB blocks are in
+    // one block = 64 k: per (row tile, plane) a lane holds 32 values = the operands of four MFMA steps.  NB blocks are in
     // flight per wave (a register ring: a block's registers are refilled right after its MFMAs have been issued).
     struct Block {
-        s16x8 a[MI][NPL][2];
-        s16x8 b[NJ][NPL][2];
+        s16x8 a[MI][NPL][4];
+        s16x8 b[NJ][NPL][4];
     };
-    constexpr int REGS = (MI + NJ) * NPL * 8;
-    constexpr int NB = 128 / REGS < 2 ? 2 : (128 / REGS > 8 ? 8 : 128 / REGS);
+    constexpr int REGS = (MI + NJ) * NPL * 16;
     auto load = [&](Block& c, int k) {
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const s16x8* src = reinterpret_cast<const s16x8*>(ap[i] + (size_t)p * planeA + k);
-                c.a[i][p][0] = src[0];
-                c.a[i][p][1] = src[1];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) c.a[i][p][s] = src[s];
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const s16x8* src = reinterpret_cast<const s16x8*>(bp[j] + (size_t)p * planeW + k);
-                c.b[j][p][0] = src[0];
-                c.b[j][p][1] = src[1];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) c.b[j][p][s] = src[s];
             }
         }
     };
     auto compute = [&](const Block& c) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -118,17 +117,18 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
                     }
                 }
     };
+    static_assert(REGS * NB + MI * NJ * 16 * NPL <= (NW > 4 ? 232 : 480), "fragment ring + accumulators exceed the register file");
     Block buf[NB];
-    const int nblk = KW / 32;
+    const int nblk = KW / 64;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-        if (b < nblk) load(buf[b], b * 32);
+        if (b < nblk) load(buf[b], b * 64);
     for (int c = 0; c < nblk; c += NB) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (c + b < nblk) {
                 compute(buf[b]);
-                if (c + b + NB < nblk) load(buf[b], (c + b + NB) * 32);
+                if (c + b + NB < nblk) load(buf[b], (c + b + NB) * 64);
             }
         }
     }
@@ -203,39 +203,39 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
     static const int on = [] { const char* e = getenv("GENIE_GEMM16_SM"); return e ? atoi(e) : 1; }();
     static const long max_out = [] { const char* e = getenv("GENIE_GEMM16_SM_MAX"); return e ? atol(e) : 1L << 20; }();
     if (!on || (long)M * N * batch > max_out) return GENIE_E_UNSUPPORTED;
-    if (N % 4 || ldc % 4 || lda % 8 || ldw % 8 || planeA % 8 || planeW % 8 || K % 128) return GENIE_E_UNSUPPORTED;
+    if (N % 4 || ldc % 4 || lda % 8 || ldw % 8 || planeA % 8 || planeW % 8) return GENIE_E_UNSUPPORTED;
     if (npl == 2 && (flags & G16X_OUT16) && plane16 == 0) return GENIE_E_UNSUPPORTED;
-    const int nw = K >= 2048 ? 8 : 4;       // waves = K-splits: every wave gets >= 64 k and at most 256
-    if ((K / nw) % 32) return GENIE_E_UNSUPPORTED;
+    // 8 waves = 8 K-splits (every wave gets K/8 >= 64 k; at K = 512 the whole contraction is in flight at once)
+    if (K % 512) return GENIE_E_UNSUPPORTED;
     const double mn = (double)M * N * batch;
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
                    2.0 * npl * ((double)M * K * batch + (double)N * K) +
                        mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) +
                              (flags & G16X_OUT16 ? 2 * npl : 0)),
                    st);
-    // tile: 64x64 unless that leaves most CUs idle (N = 512 at M = 256: 32 tiles) -> 32x64 / 32x32
-    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
-    const int tm = (t64 >= 96 && !(nw == 8 && npl == 2)) ? 64 : 32;  // (8 waves share the register file two per SIMD)
-    const int tn = (t64 >= 96 || (long)((M + 31) / 32) * ((N + 63) / 64) * batch >= 96) ? 64 : 32;
-    const dim3 grid((unsigned)(((M + tm - 1) / tm) * ((N + tn - 1) / tn)), (unsigned)batch);
-#define SM_LAUNCH(NPL_, TM_, TN_, NW_)                                                                                    \
+    // tile 32x64 unless that leaves most CUs idle (N = 512 at M = 256: 64 tiles) or the ring would not fit (K/8 > 64 with
+    // split operands) -> 32x32
+    const long t64 = (long)((M + 31) / 32) * ((N + 63) / 64) * batch;
+    const int tn = (t64 >= 96 && !(npl == 2 && K > 512)) ? 64 : 32;
+    const dim3 grid((unsigned)(((M + 31) / 32) * ((N + tn - 1) / tn)), (unsigned)batch);
+#define SM_LAUNCH(NPL_, TM_, TN_, NB_)                                                                                    \
     do {                                                                                                                  \
-        const size_t lds = (size_t)NW_ * TM_ * TN_ * 4;                                                                   \
-        (void)hipFuncSetAttribute((const void*)gemm16_sm_kernel<NPL_, TM_, TN_, NW_>,                                     \
+        const size_t lds = (size_t)8 * TM_ * TN_ * 4;                                                                     \
+        (void)hipFuncSetAttribute((const void*)gemm16_sm_kernel<NPL_, TM_, TN_, 8, NB_>,                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-        gemm16_sm_kernel<NPL_, TM_, TN_, NW_><<<grid, NW_ * 64, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, \
-                                                                          plane16, ldc, M, N, K, flags, alpha, strideA,  \
-                                                                          strideC, Rf, strideW);                         \
+        gemm16_sm_kernel<NPL_, TM_, TN_, 8, NB_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,   \
+                                                                        plane16, ldc, M, N, K, flags, alpha, strideA,    \
+                                                                        strideC, Rf, strideW);                           \
     } while (0)
-#define SM_TILE(NPL_, NW_)                                                                                                \
-    do {                                                                                                                  \
-        if constexpr (!(NPL_ == 2 && NW_ == 8)) { if (tm == 64) { SM_LAUNCH(NPL_, 64, 64, NW_); break; } }               \
-        if (tn == 64) SM_LAUNCH(NPL_, 32, 64, NW_);                                                                  \
-        else SM_LAUNCH(NPL_, 32, 32, NW_);                                                                                \
-    } while (0)
-    if (npl == 1) { if (nw == 4) SM_TILE(1, 4); else SM_TILE(1, 8); }
-    else { if (nw == 4) SM_TILE(2, 4); else SM_TILE(2, 8); }
-#undef SM_TILE
+    // NB = blocks of 64 k in flight per wave: K = 512 needs one (K/8 = 64), longer contractions ring two
+    if (npl == 1) {
+        if (tn == 64) { if (K == 512) SM_LAUNCH(1, 32, 64, 1); else SM_LAUNCH(1, 32, 64, 2); }
+        else { if (K == 512) SM_LAUNCH(1, 32, 32, 1); else SM_LAUNCH(1, 32, 32, 2); }
+    } else if (tn == 64) {
+        SM_LAUNCH(2, 32, 64, 1);   // (launcher above: split operands take 32x64 only at K = 512)
+    } else {
+        if (K == 512) SM_LAUNCH(2, 32, 32, 1); else SM_LAUNCH(2, 32, 32, 2);
+    }
 #undef SM_LAUNCH
     GENIE_LAUNCH_CHECK("gemm16_sm");
     return GENIE_OK;

@@ -90,7 +90,7 @@ class GenieEvaluator:
         cache = self._cache
         st = torch.cuda.current_stream().cuda_stream
         ctx = ids[:, :n].contiguous()                       # ground-truth context frames 0..T-2
-        _lib.check(lib.genie_clean_pass(cfg, w, ctx.data_ptr(), B, n, cache.data_ptr(), nbytes, ws.data_ptr(), ws.numel(),
+        _lib.check(lib.genie_clean_pass(cfg, w, ctx.data_ptr(), B, n, n, cache.data_ptr(), nbytes, ws.data_ptr(), ws.numel(),
                                         st), "genie_clean_pass")
         cur = torch.full((B, n, S), m.mask_token_id, dtype=torch.int64, device=dev)
         unmasked = torch.zeros(B * n, S, dtype=torch.uint8, device=dev)

@@ -47,7 +47,7 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
                            teacher_force_time=False, noise=None, unmask_mode="random"):
     """``generate_frames`` with a temporal KV cache (genie_frame_pass): every pass runs ONE frame through the stack
     against the cached temporal keys/values of the earlier frames instead of the full 16-frame forward --
-    P + (T-P)*(steps+1) single-frame passes (= 2 full-pass equivalents at P=8, steps=2) instead of (T-P)*steps full
+    one P-frame pass for the prompt + (T-P)*(steps+1) single-frame passes (= 2 full-pass equivalents at P=8, steps=2) instead of (T-P)*steps full
     forwards (16).  Same outputs (per-row arithmetic is unchanged)."""
     import math
     from . import _lib
@@ -70,8 +70,15 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
                                         0 if logits is None else logits.data_ptr(), ws.data_ptr(), ws.numel(), st),
                    "genie_frame_pass")
 
-    for t in range(P):
-        frame_pass(ids[:, t].contiguous(), t)
+    # the prompt fills slots 0..P-1 of the cache in ONE P-frame pass (genie_clean_pass with the cache's T-frame layout);
+    # geometries that pass does not cover fill them frame by frame
+    rc = lib.genie_clean_pass(cfg, w, ids[:, :P].contiguous().data_ptr(), B, P, T, cache.data_ptr(), nbytes, ws.data_ptr(),
+                              ws.numel(), st) if P > 1 else _lib.E_UNSUPPORTED
+    if rc == _lib.E_UNSUPPORTED:
+        for t in range(P):
+            frame_pass(ids[:, t].contiguous(), t)
+    else:
+        _lib.check(rc, "genie_clean_pass")
     logits = torch.empty(B, S, V, dtype=torch.float32, device=dev)
     samples = torch.empty(B, S, dtype=torch.int64, device=dev)
     conf = torch.empty(B, S, dtype=torch.float32, device=dev)

@@ -172,8 +172,11 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int
  * the ground-truth frames < t equal those of ONE forward over the ground-truth clip ("clean pass"), and frame t
  * itself only needs their temporal keys/values.
  *   genie_clean_pass: `ids` (B, nframes, S) = clip frames 0..nframes-1; runs that forward and stores every layer's
- *     temporal qkv (L, B, nframes, S, 3d) f32 in `cache`.  The evaluator needs nframes = T-1 (no timeline has the
- *     last frame as context).
+ *     temporal qkv f32 in `cache`, laid out (L, B, cache_frames, S, 3d) with cache_frames >= nframes (0 = nframes).  The
+ *     evaluator needs nframes = cache_frames = T-1 (no timeline has the last frame as context); generate() fills the
+ *     prompt's slots of its T-frame KV cache in one pass with nframes = P, cache_frames = T (then genie_frame_pass
+ *     continues from slot P).  cache_frames != nframes at B > 1 needs 8 <= nframes <= 16 and head_dim 32/64
+ *     (GENIE_E_UNSUPPORTED otherwise: fill the cache with genie_frame_pass instead).
  *   genie_masked_frames_logits: evaluates "frame t in timeline t" for nframes timelines at once: slot i of `frames`
  *     (B, nframes, S) holds the current tokens of clip frame frame0 + i in its own timeline (all-mask at MaskGIT step 0);
  *     it attends the cached keys of clip frames < frame0 + i and its own key.  `cache` comes from a clean pass with the
@@ -182,8 +185,8 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int
  * Same per-row arithmetic as the full forwards: (1 + steps) passes over T-1 frames instead of 15*steps over T.
  * genie_prefix_cache_bytes is the size for nframes = T (an upper bound). */
 size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B);
-int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int nframes, float* cache,
-                     size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int nframes, int cache_frames,
+                     float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);
 int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* w, const int64_t* frames, int B, int frame0,
                                int nframes, const float* cache, size_t cache_bytes, float* logits, void* workspace,
                                size_t workspace_bytes, void* stream);
