@@ -121,9 +121,9 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
         }
     }
     __syncthreads();
-    if (wid >= qw) return;
+    if (qw > 0 && wid >= qw) return;
 
-    const int qb = blockIdx.z * qw + wid;  // 32 queries per wave
+    const int qb = qw > 0 ? blockIdx.z * qw + wid : blockIdx.z;  // 32 queries per wave (qw = 0: per workgroup)
     // ---- Q fragments: lane (r,h) holds Q[r][16kk + 8h + j], split, scale folded in before the split
     f16x8 qh[DH / 16], ql[DH / 16];
     const float scale_l2 = scale * 1.4426950408889634f;  // scores carried as s*log2(e): softmax = one v_exp_f32 each
@@ -164,6 +164,105 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
                 split_h(qf[8 * kk + j] * scale_l2, a, b);  // q *= scale (attention.py:48), in log2 units (see softmax)
                 qh[kk][j] = a; ql[kk][j] = b;
             }
+    }
+    if (qw == 0) {
+        // ---- KEY-SPLIT mode (a handful of sequences, e.g. one frame of batch-1 generate): the workgroup owns 32 queries and
+        // its 8 waves take one 32-key tile each -- 24 MFMAs and 16 exponentials per wave instead of 192 and 128 in one wave --
+        // then the partial (max, sum, O) triples are merged like an online softmax, in wave order.
+        const int kt = wid;
+        f32x16 a0, c0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a0[e] = 0.f; c0[e] = 0.f; }
+        const int rowk = kt * 32 + r;
+#pragma unroll
+        for (int kk = 0; kk < DH / 16; ++kk) {
+            const int off = rowk * ROWB + (((2 * kk + h) ^ ((rowk / RPB) % SPR)) << 4);
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(sKh + off);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(sKl + off);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kk], a0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kk], c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kk], c0, 0, 0, 0);
+        }
+        float p[16];
+        float mw = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { p[e] = a0[e] + c0[e] * (1.0f / 2048.0f); mw = fmaxf(mw, p[e]); }
+        mw = fmaxf(mw, __shfl_xor(mw, 32));
+        float lw = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(p[e] - mw); lw += p[e]; }
+        lw += __shfl_xor(lw, 32);
+        float* stat = reinterpret_cast<float*>(smem + 2 * K_PLANE + 2 * VT_PLANE);  // [8 waves][32 queries][2]
+        if (h == 0) { stat[(wid * 32 + r) * 2] = mw; stat[(wid * 32 + r) * 2 + 1] = lw; }
+        f32x16 oa[DH / 32], oc[DH / 32];
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oa[dt][e] = 0.f; oc[dt][e] = 0.f; }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f16x8 ph, pl;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                _Float16 a, b;
+                split_h(p[8 * m + s8], a, b);
+                ph[s8] = a; pl[s8] = b;
+            }
+            const int key0 = kt * 32 + 4 * h + 16 * m;
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt) {
+                const int off = (dt * 32 + r) * VT_PITCH + key0 * 2;
+                f16x8 vh, vl;
+                const f16x4 h0 = *reinterpret_cast<const f16x4*>(sVh + off);
+                const f16x4 h1 = *reinterpret_cast<const f16x4*>(sVh + off + 16);
+                const f16x4 l0 = *reinterpret_cast<const f16x4*>(sVl + off);
+                const f16x4 l1 = *reinterpret_cast<const f16x4*>(sVl + off + 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vh[j] = h0[j]; vh[4 + j] = h1[j]; vl[j] = l0[j]; vl[4 + j] = l1[j]; }
+                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, oa[dt], 0, 0, 0);
+                oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[dt], 0, 0, 0);
+                oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave has read its K tile: the K planes become the partial-output scratch [wave][32 q][DH]
+        float* op = reinterpret_cast<float*>(smem) + (size_t)wid * 32 * DH;
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                op[((e & 3) + 8 * (e >> 2) + 4 * h) * DH + dt * 32 + r] = oa[dt][e] + oc[dt][e] * (1.0f / 2048.0f);
+        __syncthreads();
+        // merge: thread -> (query, 4 features); waves in order
+        constexpr int F4 = DH / 4;
+        for (int idx = tid; idx < 32 * F4; idx += 512) {
+            const int q = idx / F4, f4 = (idx % F4) * 4;
+            float mg = -INFINITY;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) mg = fmaxf(mg, stat[(w8 * 32 + q) * 2]);
+            float l = 0.f;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) {
+                const float sc8 = __builtin_amdgcn_exp2f(stat[(w8 * 32 + q) * 2] - mg);
+                l += stat[(w8 * 32 + q) * 2 + 1] * sc8;
+                const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem) + ((size_t)w8 * 32 + q) * DH + f4);
+                o.x += t.x * sc8; o.y += t.y * sc8; o.z += t.z * sc8; o.w += t.w * sc8;
+            }
+            const float invl = 1.0f / l;
+            o.x *= invl; o.y *= invl; o.z *= invl; o.w *= invl;
+            const size_t oi = (size_t)(row0 + qb * 32 + q) * d + head * DH + f4;
+            if (!out16) *reinterpret_cast<float4*>(out + oi) = o;
+            else if (plane) {
+                uint32_t h01, h23, l01, l23;
+                split_f16_x4(o.x, o.y, o.z, o.w, h01, h23, l01, l23);
+                *reinterpret_cast<uint2*>(out16 + oi) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(out16 + plane + oi) = make_uint2(l01, l23);
+            } else {
+                *reinterpret_cast<uint2*>(out16 + oi) = make_uint2((uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16),
+                                                                   (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16));
+            }
+        }
+        return;
     }
     // ---- S^T tiles: sc[kt][e] = score(key kt*32 + (e&3) + 8(e>>2) + 4h, query r)
     f32x16 sc[NKT];
@@ -252,9 +351,12 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
 int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
                               const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
     if (S != 256 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
-    const size_t lds = (size_t)2 * 256 * Dh * 2 + (size_t)2 * Dh * 520;
-    const int qw = n_seq * H <= 16 ? 1 : (n_seq * H <= 48 ? 2 : (n_seq * H <= 128 ? 4 : 8));
-    dim3 grid((unsigned)n_seq, H, 8 / qw);
+    const size_t lds = (size_t)2 * 256 * Dh * 2 + (size_t)2 * Dh * 520 + 2048;  // K planes, V^T planes, key-split statistics
+    // few (sequence, head) pairs: spread one pair over several workgroups -- by keys within the workgroup (qw = 0: 8 query
+    // blocks per pair) for a handful, by query blocks of 2 or 4 waves for a few dozen
+    static const int ksplit = [] { const char* e = getenv("GENIE_ATTN_KEYSPLIT"); return e ? atoi(e) : 1; }();
+    const int qw = n_seq * H <= 32 ? (ksplit ? 0 : 1) : (n_seq * H <= 64 ? 2 : (n_seq * H <= 128 ? 4 : 8));
+    dim3 grid((unsigned)n_seq, H, qw ? 8 / qw : 8);
     ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * Dh * H * (double)n_seq, (double)n_seq * S * H * Dh * 16.0, st);
     if (Dh == 64) {
         (void)hipFuncSetAttribute((const void*)attn_spatial_split_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
