@@ -215,6 +215,46 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
         mma(asub, csub);
         __builtin_amdgcn_s_setprio(0);
     };
+    // SCHED 2 (study knob GENIE_PP_SCHED=2, run-time-flag epilogue only): the phase's two LDS-DMA pieces are issued from INSIDE
+    // the matrix cluster (after the first pair of MFMAs of k-step 0 and of k-step KK/2) instead of in the LOAD part the other
+    // wave group waits on.  Measured (r2g_sched2.log): identical throughput to SCHED 0 on every shape, f16x3 and bf16 -- the
+    // launch rate is pinned by the board's power-managed clock, not by where the VMEM issue sits.  ht < 0: nothing to stage.
+    auto mfma_part_dma = [&](int asub, int csub, int scale_sub, int ht, int buf, int kt) {
+        wg_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (scale_sub >= 0) scale_b(scale_sub);
+        f32x16& c0 = acc[asub * 2][csub];
+        f32x16& c1 = acc[asub * 2 + 1][csub];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            if constexpr (NPL == 1) {
+                c0 = mma16<F16>(fa[0][kk], fb[csub][kk], c0);
+                c1 = mma16<F16>(fa[1][kk], fb[csub][kk], c1);
+                if (ht >= 0 && (kk == 0 || kk == KK / 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(ht, kk == 0 ? 0 : 1, buf, kt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                c0 = mma16<true>(fa[0][kk], fup[csub][kk], c0);
+                c1 = mma16<true>(fa[1][kk], fup[csub][kk], c1);
+                if (ht >= 0 && (kk == 0 || kk == KK / 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(ht, kk == 0 ? 0 : 1, buf, kt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (TERMS == 3) {
+                    c0 = mma16<true>(fa[0][kk], fb[csub][KK + kk], c0);
+                    c1 = mma16<true>(fa[1][kk], fb[csub][KK + kk], c1);
+                }
+                c0 = mma16<true>(fa[0][KK + kk], fb[csub][kk], c0);
+                c1 = mma16<true>(fa[1][KK + kk], fb[csub][kk], c1);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
     // MODE 0: steady state, 1: second-to-last K-tile (stages for tile t+1 only), 2: last K-tile (stages nothing).
     // SCHED 0: one half-tile per phase (q0 B-late(t+1), q1 A-late(t+1), q2 A-early(t+2), q3 B-early(t+2)).
     // SCHED 1: the LDS-DMA issue (the expensive part of a LOAD) is moved away from the phases that carry the fragment
@@ -223,6 +263,27 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     auto ktile = [&](auto bufc, auto modec, int t) {
         constexpr int BUF = decltype(bufc)::value, MODE = decltype(modec)::value;
         constexpr bool NOWAIT = (ABL & 4) != 0;
+        if constexpr (SCHED == 2) {
+            // same half-tile per phase as SCHED 0, issued half a phase later (inside the MFMA part), so every counted wait
+            // names one stage (2 loads) fewer: q0 B-late(t) landed <- younger: A-late(t), A-early(t+1), B-early(t+1) = 6; ...
+            read_a(BUF, 0);
+            read_b(BUF, 0);
+            if constexpr (MODE < 2) wait_vmcnt<6, NOWAIT>(); else wait_vmcnt<2>();
+            mfma_part_dma(0, 0, 0, MODE < 2 ? 3 : -1, BUF ^ 1, t + 1);
+            wg_barrier();
+            read_b(BUF, 1);
+            if constexpr (MODE < 2) wait_vmcnt<6, NOWAIT>(); else wait_vmcnt<0>();
+            mfma_part_dma(0, 1, 1, MODE < 2 ? 1 : -1, BUF ^ 1, t + 1);
+            wg_barrier();
+            read_a(BUF, 1);
+            mfma_part_dma(1, 1, -1, MODE == 0 ? 0 : -1, BUF, t + 2);
+            wg_barrier();
+            if constexpr (MODE == 0) wait_vmcnt<6, NOWAIT>();
+            if constexpr (MODE == 1) wait_vmcnt<4>();
+            mfma_part_dma(1, 0, -1, MODE == 0 ? 2 : -1, BUF, t + 2);
+            if (MODE < 2 || wm == 0) wg_barrier();
+            return;
+        }
         // q0: quadrant (a0, c0)
         read_a(BUF, 0);
         read_b(BUF, 0);
@@ -612,9 +673,9 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
         const int e = flags & 127;
 #define PP_EPI(NPL_, F16_, E_)                                                                                            \
         case E_: {                                                                                                        \
-            (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, 0, E_>,           \
+            (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, PP_SCHED, E_>,    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, 0, E_><<<grid, 512, lds, st>>>(                          \
+            gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, PP_SCHED, E_><<<grid, 512, lds, st>>>(                   \
                 A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,  \
                 strideW, qscale, head_dim);                                                                                                 \
             done = true;                                                                                                  \
@@ -636,16 +697,18 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
         static const int epi = [] { const char* e2 = getenv("GENIE_PP_EPI"); return e2 ? atoi(e2) : 1; }();
         const bool out_kind_ok = !(flags & G16X_OUT16) || (flags & G16X_QKV) || (npl == 2 ? plane16 != 0 : plane16 == 0);
         if (epi && sched == 0 && terms == 3 && out_kind_ok) {
+#define PP_SCHED 0
             if (npl == 1 && !f16) { PP_EPI_ALL(1, false) }
             else if (npl == 2) { PP_EPI_ALL(2, true) }
+#undef PP_SCHED
         }
 #undef PP_EPI_ALL
 #undef PP_EPI
         if (done) {
-        } else if (npl == 1 && !f16) { if (sched == 0) PP_LAUNCH(1, 1, false, 0, 0); else PP_LAUNCH(1, 1, false, 0, 1); }
+        } else if (npl == 1 && !f16) { if (sched == 0) PP_LAUNCH(1, 1, false, 0, 0); else if (sched == 2) PP_LAUNCH(1, 1, false, 0, 2); else PP_LAUNCH(1, 1, false, 0, 1); }
         else if (npl == 1) PP_LAUNCH(1, 1, true, 0, 0);
         else if (terms == 2) PP_LAUNCH(2, 2, true, 0, 0);
-        else { if (sched == 0) PP_LAUNCH(2, 3, true, 0, 0); else PP_LAUNCH(2, 3, true, 0, 1); }
+        else { if (sched == 0) PP_LAUNCH(2, 3, true, 0, 0); else if (sched == 2) PP_LAUNCH(2, 3, true, 0, 2); else PP_LAUNCH(2, 3, true, 0, 1); }
     }
 #undef PP_LAUNCH
 #undef PP_LAUNCH_ABL

@@ -205,8 +205,10 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
     if (!on || (long)M * N * batch > max_out) return GENIE_E_UNSUPPORTED;
     if (N % 4 || ldc % 4 || lda % 8 || ldw % 8 || planeA % 8 || planeW % 8) return GENIE_E_UNSUPPORTED;
     if (npl == 2 && (flags & G16X_OUT16) && plane16 == 0) return GENIE_E_UNSUPPORTED;
-    // 8 waves = 8 K-splits (every wave gets K/8 >= 64 k; at K = 512 the whole contraction is in flight at once)
-    if (K % 512) return GENIE_E_UNSUPPORTED;
+    // 8 waves = 8 K-splits (every wave gets K/8 >= 64 k; at K = 512 the whole contraction is in flight at once); K = 256
+    // (the 35M config's width) runs 4 waves of 64 k
+    if (K % 512 && K != 256) return GENIE_E_UNSUPPORTED;
+    const bool one = K == 512 || K == 256;   // one 64-k block per wave
     const double mn = (double)M * N * batch;
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
                    2.0 * npl * ((double)M * K * batch + (double)N * K) +
@@ -216,26 +218,27 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
     // tile 32x64 unless that leaves most CUs idle (N = 512 at M = 256: 64 tiles) or the ring would not fit (K/8 > 64 with
     // split operands) -> 32x32
     const long t64 = (long)((M + 31) / 32) * ((N + 63) / 64) * batch;
-    const int tn = (t64 >= 96 && !(npl == 2 && K > 512)) ? 64 : 32;
+    const int tn = (t64 >= 96 && !(npl == 2 && !one)) ? 64 : 32;
     const dim3 grid((unsigned)(((M + 31) / 32) * ((N + tn - 1) / tn)), (unsigned)batch);
-#define SM_LAUNCH(NPL_, TM_, TN_, NB_)                                                                                    \
+#define SM_LAUNCH(NPL_, TM_, TN_, NW_, NB_)                                                                               \
     do {                                                                                                                  \
-        const size_t lds = (size_t)8 * TM_ * TN_ * 4;                                                                     \
-        (void)hipFuncSetAttribute((const void*)gemm16_sm_kernel<NPL_, TM_, TN_, 8, NB_>,                                  \
+        const size_t lds = (size_t)NW_ * TM_ * TN_ * 4;                                                                   \
+        (void)hipFuncSetAttribute((const void*)gemm16_sm_kernel<NPL_, TM_, TN_, NW_, NB_>,                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-        gemm16_sm_kernel<NPL_, TM_, TN_, 8, NB_><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16,   \
-                                                                        plane16, ldc, M, N, K, flags, alpha, strideA,    \
-                                                                        strideC, Rf, strideW);                           \
+        gemm16_sm_kernel<NPL_, TM_, TN_, NW_, NB_><<<grid, NW_ * 64, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, \
+                                                                               C16, plane16, ldc, M, N, K, flags, alpha, \
+                                                                               strideA, strideC, Rf, strideW);           \
     } while (0)
-    // NB = blocks of 64 k in flight per wave: K = 512 needs one (K/8 = 64), longer contractions ring two
-    if (npl == 1) {
-        if (tn == 64) { if (K == 512) SM_LAUNCH(1, 32, 64, 1); else SM_LAUNCH(1, 32, 64, 2); }
-        else { if (K == 512) SM_LAUNCH(1, 32, 32, 1); else SM_LAUNCH(1, 32, 32, 2); }
-    } else if (tn == 64) {
-        SM_LAUNCH(2, 32, 64, 1);   // (launcher above: split operands take 32x64 only at K = 512)
-    } else {
-        if (K == 512) SM_LAUNCH(2, 32, 32, 1); else SM_LAUNCH(2, 32, 32, 2);
-    }
+    // NB = blocks of 64 k in flight per wave: one when K/waves = 64, longer contractions ring two
+#define SM_SHAPE(NPL_, TN_)                                                                                               \
+    do {                                                                                                                  \
+        if (K == 256) SM_LAUNCH(NPL_, 32, TN_, 4, 1);                                                                     \
+        else if (K == 512) SM_LAUNCH(NPL_, 32, TN_, 8, 1);                                                                \
+        else if constexpr (!(NPL_ == 2 && TN_ == 64)) SM_LAUNCH(NPL_, 32, TN_, 8, 2);                                     \
+    } while (0)
+    if (npl == 1) { if (tn == 64) SM_SHAPE(1, 64); else SM_SHAPE(1, 32); }
+    else { if (tn == 64) SM_SHAPE(2, 64); else SM_SHAPE(2, 32); }
+#undef SM_SHAPE
 #undef SM_LAUNCH
     GENIE_LAUNCH_CHECK("gemm16_sm");
     return GENIE_OK;
