@@ -14,12 +14,14 @@ sys.path.insert(0, REPO)
 _lib = importlib.import_module("1xgpt_amd._lib")
 
 
-def run(prec, M, N, K, iters=20, check=True, gelu=0):
+def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False):
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
     W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
     b = torch.randn(N, device="cuda", generator=g)
+    if zero:  # power study only: all-zero operands toggle no multiplier inputs (never quote these numbers as throughput)
+        x.zero_(); W.zero_()
     y = torch.empty(M, N, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     if prec == "exact":
@@ -61,6 +63,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--prec", nargs="+", default=["exact", "f16x3", "bf16"])
     ap.add_argument("--gelu", type=int, default=0, help="fused erf-GELU epilogue (16-bit precisions)")
+    ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power study, not a throughput figure)")
     a = ap.parse_args()
     M = 4096 * a.batch
     shapes = [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), ("fc2", 512, 2048), ("readout", 1024, 512),
@@ -68,6 +71,6 @@ if __name__ == "__main__":
     for prec in a.prec:
         for name, N, K in shapes:
             m = 4096 if name == "sq4096" else M
-            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0)
+            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0, zero=a.zero)
             print(f"{prec:6s} {name:8s} M={m:6d} N={N:5d} K={K:5d}  {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s  max|err| {err:.2e}",
                   flush=True)
