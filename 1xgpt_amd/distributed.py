@@ -27,7 +27,20 @@ def init_distributed(backend=None):
             dev_index = local_device_index(local_rank)
             torch.cuda.set_device(dev_index)
             kwargs["device_id"] = torch.device("cuda", dev_index)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        if backend == "gloo":
+            # gloo announces its connections on STDOUT; callers (bench.py) print exactly one JSON line there
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 
 

@@ -181,6 +181,13 @@ def main():
                     help="do not bracket GEMM launches with HIP events (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
+    # watchdog: a rank stuck in a collective (a peer died, a mismatched sequence) must not hang the node -- dump every
+    # thread's Python stack to stderr and exit after GENIE_BENCH_WATCHDOG seconds (default 600; the default run takes ~2 min)
+    import faulthandler
+    wd = int(os.environ.get("GENIE_BENCH_WATCHDOG", "600"))
+    if wd > 0:
+        faulthandler.dump_traceback_later(wd, exit=True)
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)  # never returns
     dist_mod = importlib.import_module("1xgpt_amd.distributed")
