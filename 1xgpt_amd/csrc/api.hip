@@ -493,6 +493,14 @@ int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, con
     return launch_factored_ce(*cfg, logits, layout, targets, weight_ids, B, t0, t1, sums_out, as_stream(stream));
 }
 
+int genie_metric_hits(const int64_t* truth, int64_t truth_batch_stride, const int64_t* samples, int64_t samples_batch_stride,
+                      int batch, int64_t n_per_batch, const double* ce3, double n_tokens, double n_frames, double n_clips,
+                      double* sums6, void* stream) {
+    GENIE_CHECK_ARG(truth && samples && sums6 && batch >= 0 && n_per_batch >= 0, "metric_hits: bad argument");
+    return launch_count_equal(truth, (long)truth_batch_stride, samples, (long)samples_batch_stride, batch, (long)n_per_batch, ce3,
+                              sums6, n_tokens, n_frames, n_clips, as_stream(stream));
+}
+
 int genie_readout_ce(const genie_cfg* cfg, const genie_weights* wt, const float* x, const int64_t* targets,
                      const int64_t* weight_ids, int B, int t0, int t1, double* sums_out, void* workspace,
                      size_t workspace_bytes, void* stream) {

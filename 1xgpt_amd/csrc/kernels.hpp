@@ -81,6 +81,8 @@ int launch_layer_norm_split(const float* x, const float* g, const float* b, uint
                             float eps, hipStream_t st);
 int launch_split_f16(const float* src, uint16_t* dst, size_t plane, size_t n, hipStream_t st);
 int launch_transpose(const float* in, float* out, int batch, int rows, int cols, hipStream_t st);
+int launch_count_equal(const int64_t* a, long sa, const int64_t* b, long sb, int batch, long n, const double* ce3, double* sums6,
+                       double n_tokens, double n_frames, double n_clips, hipStream_t st);
 int launch_factored_ce(const genie_cfg& c, const float* logits, int layout, const int64_t* targets,
                        const int64_t* weight_ids, int B, int t0, int t1, double* sums, hipStream_t st);
 int launch_sample(const genie_cfg& c, const float* logits, int layout, int B, float temperature,

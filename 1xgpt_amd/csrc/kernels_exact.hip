@@ -693,6 +693,42 @@ __global__ __launch_bounds__(256) void ce_bcthw_kernel(const float* __restrict__
     block_accumulate3(ce, hit, cnt, sums);
 }
 
+// sampled-token accuracy numerator of the evaluator (evaluate.py:176-179: (samples == ground truth).sum()): a (batch, n) view
+// with batch stride `sa` against b (batch, n) with stride `sb`; the count is ADDED to sums6[2].  Block 0 also files the rest
+// of the metric vector: sums6 = [sum CE, n CE tokens, hits, n tokens, n frames, n clips] with the CE pair taken from the
+// 3-vector genie_factored_ce accumulated (ce3 = [sum CE, sum argmax-correct, n]; NULL = leave sums6[0..1] alone).
+__global__ __launch_bounds__(256) void count_equal_kernel(const int64_t* __restrict__ a, long sa, const int64_t* __restrict__ b,
+                                                          long sb, long n, long total, const double* __restrict__ ce3,
+                                                          double* sums6, double n_tokens, double n_frames, double n_clips) {
+    __shared__ int wsum[4];
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int hit = 0;
+    if (i < total) {
+        const long bi = i / n, r = i - bi * n;
+        hit = a[bi * sa + r] == b[bi * sb + r];
+    }
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int c = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (c) atomicAdd(&sums6[2], (double)c);  // integer-valued addends: the f64 sum is exact in any order
+        if (blockIdx.x == 0) {
+            if (ce3) { sums6[0] = ce3[0]; sums6[1] = ce3[2]; }
+            sums6[3] = n_tokens; sums6[4] = n_frames; sums6[5] = n_clips;
+        }
+    }
+}
+int launch_count_equal(const int64_t* a, long sa, const int64_t* b, long sb, int batch, long n, const double* ce3, double* sums6,
+                       double n_tokens, double n_frames, double n_clips, hipStream_t st) {
+    const long total = (long)batch * n;
+    if (total <= 0) return GENIE_OK;
+    count_equal_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, sa, b, sb, n, total, ce3, sums6, n_tokens, n_frames,
+                                                                        n_clips);
+    GENIE_LAUNCH_CHECK("count_equal");
+    return GENIE_OK;
+}
+
 int launch_factored_ce(const genie_cfg& c, const float* logits, int layout, const int64_t* targets,
                        const int64_t* weight_ids, int B, int t0, int t1, double* sums, hipStream_t st) {
     int nt = t1 - t0;

@@ -143,14 +143,19 @@ class GenieEvaluator:
         samples, _ = self.predict_zframe_logits_reuse(ids, noise=noise, return_logits=False)
         lg0 = self._last_token_major_logits0  # (B,T-1,S,V) token-major: clip frames 1..T-1
         lab = lab.contiguous()
-        hits = (ids.view(B, T, m.h, m.w)[:, 1:] == samples).sum().double()
+        ids = ids.contiguous()
+        st = torch.cuda.current_stream().cuda_stream
         ce = torch.zeros(3, dtype=torch.float64, device=ids.device)
+        sums = torch.zeros(6, dtype=torch.float64, device=ids.device)
         cfg = m._weights()[0]
         # logits hold frames [1, T) of the clip; targets are indexed in the full (B,T,S) clip
         _lib.check(lib.genie_factored_ce(cfg, lg0.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, lab.data_ptr(), 0, B, 1, T,
-                                         ce.data_ptr(), torch.cuda.current_stream().cuda_stream), "genie_factored_ce")
-        f64 = lambda v: torch.tensor(float(v), dtype=torch.float64, device=ids.device)  # noqa: E731
-        return torch.stack([ce[0], ce[2], hits, f64(B * (T - 1) * S), f64(B * (T - 1)), f64(B)])
+                                         ce.data_ptr(), st), "genie_factored_ce")
+        # (ground truth frames 1..T-1 == samples).sum() and the vector's sizes, on the device (no torch arithmetic)
+        _lib.check(lib.genie_metric_hits(ids.data_ptr() + S * 8, T * S, samples.data_ptr(), (T - 1) * S, B, (T - 1) * S,
+                                         ce.data_ptr(), float(B * (T - 1) * S), float(B * (T - 1)), float(B), sums.data_ptr(), st),
+                   "genie_metric_hits")
+        return sums
 
     @torch.no_grad()
     def evaluate_metric_sums(self, input_ids, labels=None, noise=None):
@@ -165,8 +170,9 @@ class GenieEvaluator:
         lab = ids if labels is None else labels.to(self.device).to(torch.int64).view(-1, T, m.h, m.w).contiguous()
         B = ids.shape[0]
         ce = torch.zeros(3, dtype=torch.float64, device=ids.device)
-        hits = torch.zeros((), dtype=torch.float64, device=ids.device)
+        sums = torch.zeros(6, dtype=torch.float64, device=ids.device)
         stream = torch.cuda.current_stream().cuda_stream
+        sizes = (float(B * (T - 1) * S), float(B * (T - 1)), float(B))
         for k, t in enumerate(range(1, T)):
             p = ids.clone()
             p[:, t:] = m.mask_token_id
@@ -178,11 +184,12 @@ class GenieEvaluator:
             assert lg.is_contiguous()
             _lib.check(lib.genie_factored_ce(cfg, lg.data_ptr(), _lib.LAYOUT_BCTHW, lab.data_ptr(), 0, B, t, t + 1,
                                              ce.data_ptr(), stream), "genie_factored_ce")
-            hits += (ids[:, t] == s).sum()
-        n_tok = float(B * (T - 1) * S)
-        return torch.stack([ce[0], ce[2], hits, torch.tensor(n_tok, dtype=torch.float64, device=ids.device),
-                            torch.tensor(float(B * (T - 1)), dtype=torch.float64, device=ids.device),
-                            torch.tensor(float(B), dtype=torch.float64, device=ids.device)])
+            s = s.contiguous()
+            # (ids[:, t] == s).sum() accumulated on the device; the last call also files the CE pair and the sizes
+            _lib.check(lib.genie_metric_hits(ids.data_ptr() + t * S * 8, T * S, s.data_ptr(), S, B, S,
+                                             ce.data_ptr() if t == T - 1 else 0, *sizes, sums.data_ptr(), stream),
+                       "genie_metric_hits")
+        return sums
 
 
 @torch.no_grad()

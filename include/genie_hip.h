@@ -209,6 +209,15 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t
 int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, const int64_t* targets,
                       const int64_t* weight_ids, int B, int t0, int t1, double* sums_out, void* stream);
 
+/* The evaluator's metric vector (evaluate.py:167-179 / eval_utils.py:16-25) as six device-side f64 sums
+ *   sums6 = [sum CE, n CE tokens, sum (sample == ground truth), n sampled tokens, n frames, n clips].
+ * genie_metric_hits ADDS the number of equal entries of two (batch, n_per_batch) int64 views (batch strides in elements) to
+ * sums6[2] (zero it first), writes sums6[3..5] = n_tokens, n_frames, n_clips, and -- when ce3 (the 3-vector
+ * genie_factored_ce accumulated on the same stream) is not NULL -- sums6[0] = ce3[0], sums6[1] = ce3[2]. */
+int genie_metric_hits(const int64_t* truth, int64_t truth_batch_stride, const int64_t* samples, int64_t samples_batch_stride,
+                      int batch, int64_t n_per_batch, const double* ce3, double n_tokens, double n_frames, double n_clips,
+                      double* sums6, void* stream);
+
 /* Fused readout + CE for frames [t0,t1) without materialising logits for the caller. */
 int genie_readout_ce(const genie_cfg* cfg, const genie_weights* w, const float* x, const int64_t* targets,
                      const int64_t* weight_ids, int B, int t0, int t1, double* sums_out, void* workspace,
