@@ -375,6 +375,11 @@ class STMaskGIT(nn.Module):
         from dataclasses import fields
         known = {f.name for f in fields(GenieConfig)}
         config = GenieConfig(**{k: v for k, v in raw.items() if k in known})
+        if config.use_mup:
+            import warnings
+            warnings.warn("use_mup=True: the readout factor follows mup's documented formula output_mult * x / width_mult "
+                          "(base width 256); the reference's own mup fork is not vendored, so this factor is not pinned "
+                          "against reference outputs (DESIGN.md section 7, 'parity unpinned')")
         model = cls(config, precision=precision)
         model.load_state_dict(load_file(os.path.join(d, "model.safetensors")), strict=True)
         model.eval()
