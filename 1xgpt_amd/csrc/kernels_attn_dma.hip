@@ -2,7 +2,7 @@
 // causal = False) as a persistent, LDS-DMA-fed kernel over the operand planes the QKV GEMM writes
 // (launch_gemm16_pp with G16X_OUT16 | G16X_QKV):
 //     qkv16 = [Q planes | K planes | V^T planes], 16-bit, NPL planes each (NPL = 2: f16 split pairs hi + lo'/2048, NPL = 1: bf16)
-//     Q, K   row-major (M, d), Q already multiplied by scale * log2(e)
+//     Q, K   head-major [(sequence, head)][256 rows][head_dim], Q already multiplied by scale * log2(e)
 //     V^T    [(sequence, head)][feature][256 keys]
 // so nothing is converted, split or transposed here: every global byte reaches LDS by buffer_load ... lds.
 //
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
         {   // K: 1024 / ROWB rows per piece
             const int row = pp * (1024 / ROWB) + lane / SPR;
             const int slot = (lane % SPR) ^ ((row / RPB) % SPR);
-            voK[j] = (unsigned)((size_t)pl * P * 2 + ((size_t)row * d + slot * 8) * 2);
+            voK[j] = (unsigned)((size_t)pl * P * 2 + ((size_t)row * DH + slot * 8) * 2);
         }
         {   // V^T: 8 feature rows of 128 bytes (64 keys) per piece, 16-byte slot XOR (feature / 2) % 8
             const int f = pp * 8 + (lane >> 3);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
         const int pl = j / (32 * ROWB / 1024), pp = j % (32 * ROWB / 1024);
         const int row = pp * (1024 / ROWB) + lane / SPR;
         const int slot = (lane % SPR) ^ ((row / RPB) % SPR);
-        voQ[j] = (unsigned)((size_t)pl * P * 2 + ((size_t)(wid * 32 + row) * d + slot * 8) * 2);
+        voQ[j] = (unsigned)((size_t)pl * P * 2 + ((size_t)(wid * 32 + row) * DH + slot * 8) * 2);
     }
     int issued = 0;                              // VMEM operations this wave has issued so far
     int idx_slot[4] = {0, 0, 0, 0};              // value of `issued` right after the chunk now owning slot s was issued
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
         const int head = (int)(item - seq * H);
         const bool isv = c >= 4;
         const int soff = isv ? (int)((((seq * H + head) * DH) * 256 + (c - 4) * 64) * 2)
-                             : (int)(((seq * 256 + c * 64) * (long)d + head * DH) * 2);
+                             : (int)((((seq * H + head) * 256 + c * 64) * (long)DH) * 2);
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
             if (wid + 8 * j < PCC) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
     auto issue_q = [&](long item) {
         const long seq = item / H;
         const int head = (int)(item - seq * H);
-        const int soff = (int)((seq * 256 * (long)d + head * DH) * 2);
+        const int soff = (int)(((seq * H + head) * 256 * (long)DH) * 2);
 #pragma unroll
         for (int j = 0; j < PCQ; ++j) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(smem + OFF_Q + wid * QW + j * 1024),

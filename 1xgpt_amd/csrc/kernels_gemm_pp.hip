@@ -419,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
         if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0) {
             // ---- spatial-attention operand layout (N = 3d, d % 256 == 0, so a 256-column tile is all-Q, all-K or all-V; the
             // 256 rows of a tile are exactly one (clip, frame) sequence).  C16 holds 3*NPL planes of M*d 16-bit values:
-            //   [Q planes | K planes | V^T planes], Q and K row-major (M, d) with Q multiplied by qscale (= scale * log2 e),
+            //   [Q planes | K planes | V^T planes], Q and K head-major [(sequence, head)][256 rows][head_dim] with Q multiplied by qscale (= scale * log2 e),
             //   V^T as [(sequence, head)][feature][256 keys]: what kernels_attn_dma.hip streams straight into LDS.
             const int dm = N / 3;
             const int which = n0e / dm;                      // 0 Q, 1 K, 2 V  (block-uniform)
@@ -440,7 +440,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
                         const int rl = it * 4 + (lane >> 4);
-                        const size_t idx = (size_t)(m0e + wm * 128 + q * 32 + rl) * dm + colq;
+                        // head-major: [(sequence, head)][row of the sequence][feature] -- a head's 256 rows are one contiguous
+                        // 256 * head_dim block, which is what the attention kernel's LDS-DMA pieces walk
+                        const int hq = colq / head_dim, fq = colq - hq * head_dim;
+                        const size_t idx = (((size_t)(m0e >> 8) * (dm / head_dim) + hq) * 256 + (wm * 128 + q * 32 + rl)) * head_dim + fq;
                         float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
                         v.x = (v.x * ascale + bvq.x) * qs; v.y = (v.y * ascale + bvq.y) * qs;
                         v.z = (v.z * ascale + bvq.z) * qs; v.w = (v.w * ascale + bvq.w) * qs;
