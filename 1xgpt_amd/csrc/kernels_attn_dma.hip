@@ -3,7 +3,7 @@
 // (launch_gemm16_pp with G16X_OUT16 | G16X_QKV):
 //     qkv16 = [Q planes | K planes | V^T planes], 16-bit, NPL planes each (NPL = 2: f16 split pairs hi + lo'/2048, NPL = 1: bf16)
 //     Q, K   head-major [(sequence, head)][256 rows][head_dim], Q already multiplied by scale * log2(e)
-//     V^T    [(sequence, head)][feature][256 keys]
+//     V^T    [(sequence, head)][feature][256 keys], the keys of every 16-key group stored {0-3, 8-11, 4-7, 12-15}
 // so nothing is converted, split or transposed here: every global byte reaches LDS by buffer_load ... lds.
 //
 // One workgroup (8 waves, 32 queries each) per CU walks the (sequence, head) items  bid, bid + grid, ...  An item is 8 chunks
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
     unsigned offK[4];                            // K / Q rows: lane (r, h) reads slot 2 kk + h of row r (+ 32 per key tile)
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) offK[kk] = r * ROWB + (((2 * kk + h) ^ ((r / RPB) % SPR)) << 4);
-    unsigned offV[2];                            // V^T rows: feature dt * 32 + r, 8 bytes at key 4 h of a 16-key group
+    unsigned offV[2];                            // V^T rows: feature dt * 32 + r; unit h of a 16-key group = this lane's 8 keys
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) offV[dt] = (dt * 32 + r) * 128 + 8 * h;
+    for (int dt = 0; dt < NDT; ++dt) offV[dt] = (dt * 32 + r) * 128;
     const int vsw = (r >> 1) & 7;                // slot swizzle of this lane's feature rows ((dt*32 + r) / 2) % 8 = (r / 2) % 8
     float* ct = reinterpret_cast<float*>(smem + OFF_S + wid * 4096);
 
@@ -271,20 +271,14 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
 #pragma unroll
                             for (int s2 = 0; s2 < 8; ++s2) pa[s2] = (short)f32_to_bf16(sc[kt][8 * m + s2]);
                         }
-                        const int s0 = ((t * 4 + 2 * m) ^ vsw) << 4, s1 = ((t * 4 + 2 * m + 1) ^ vsw) << 4;
+                        // the planes store the keys of a 16-key group as {0-3, 8-11 | 4-7, 12-15}: unit h is exactly the 8 keys
+                        // lane half h feeds to MFMA m (slots 0..3 -> key0 + 0..3, slots 4..7 -> key0 + 8..11): one ds_read_b128
+                        const int s0 = ((t * 4 + 2 * m + h) ^ vsw) << 4;
 #pragma unroll
                         for (int dt = 0; dt < NDT; ++dt) {
-                            s16x8 vh;
-                            const s16x4 h0 = *reinterpret_cast<const s16x4*>(sl + offV[dt] + s0);
-                            const s16x4 h1 = *reinterpret_cast<const s16x4*>(sl + offV[dt] + s1);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { vh[j] = h0[j]; vh[4 + j] = h1[j]; }
+                            const s16x8 vh = *reinterpret_cast<const s16x8*>(sl + offV[dt] + s0);
                             if constexpr (NPL == 2) {
-                                s16x8 vl;
-                                const s16x4 l0 = *reinterpret_cast<const s16x4*>(sl + VPL + offV[dt] + s0);
-                                const s16x4 l1 = *reinterpret_cast<const s16x4*>(sl + VPL + offV[dt] + s1);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) { vl[j] = l0[j]; vl[4 + j] = l1[j]; }
+                                const s16x8 vl = *reinterpret_cast<const s16x8*>(sl + VPL + offV[dt] + s0);
                                 oacc[dt] = mma_k16<2>(pa, vh, oacc[dt]);
                                 oacc[dt] = mma_k16<2>(pb, vl, oacc[dt]);
                                 oacc[dt] = mma_k16<2>(pc, vh, oacc[dt]);

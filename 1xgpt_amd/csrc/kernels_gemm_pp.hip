@@ -420,7 +420,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             // ---- spatial-attention operand layout (N = 3d, d % 256 == 0, so a 256-column tile is all-Q, all-K or all-V; the
             // 256 rows of a tile are exactly one (clip, frame) sequence).  C16 holds 3*NPL planes of M*d 16-bit values:
             //   [Q planes | K planes | V^T planes], Q and K head-major [(sequence, head)][256 rows][head_dim] with Q multiplied by qscale (= scale * log2 e),
-            //   V^T as [(sequence, head)][feature][256 keys]: what kernels_attn_dma.hip streams straight into LDS.
+            //   V^T as [(sequence, head)][feature][256 keys] (keys of a 16-group stored {0-3, 8-11, 4-7, 12-15}): what
+            //   kernels_attn_dma.hip streams straight into LDS.
             const int dm = N / 3;
             const int which = n0e / dm;                      // 0 Q, 1 K, 2 V  (block-uniform)
             const size_t P = (size_t)plane16;               // = M * d
@@ -485,8 +486,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     for (int it = 0; it < 4; ++it) {
                         const int c = it * 16 + fl4;                                 // feature column inside the wave's 64
                         const int cv = n0e - 2 * dm + wn * 64 + c;                   // feature column inside d
-                        const float4 a = *reinterpret_cast<const float4*>(ct + c * 32 + (((2 * kq) ^ (c & 7)) << 2));
-                        const float4 b = *reinterpret_cast<const float4*>(ct + c * 32 + (((2 * kq + 1) ^ (c & 7)) << 2));
+                        // key order inside a 16-key group is the PV operand's own: unit j (16 bytes) = keys {4j..4j+3, 8+4j..8+4j+3},
+                        // so the attention kernel fetches a lane's 8 keys with ONE conflict-free ds_read_b128
+                        const int ga = 4 * (kq >> 1) + (kq & 1);
+                        const float4 a = *reinterpret_cast<const float4*>(ct + c * 32 + ((ga ^ (c & 7)) << 2));
+                        const float4 b = *reinterpret_cast<const float4*>(ct + c * 32 + (((ga + 2) ^ (c & 7)) << 2));
                         const float bb = bias ? bias[n0e + wn * 64 + c] : 0.f;
                         const int head = cv / head_dim, f = cv - head * head_dim;
                         const size_t idx = (((size_t)seq * Hn + head) * head_dim + f) * 256 + wm * 128 + q * 32 + kq * 8;
