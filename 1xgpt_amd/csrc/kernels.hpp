@@ -165,6 +165,9 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
 int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                      const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,
                      int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC);
+int launch_gemm16_sm_ln(int npl, const float* x, long ldx, const float* ln_g, const float* ln_b, float eps, const uint16_t* W,
+                        long ldw, long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc,
+                        int M, int N, int K, int flags, float alpha, hipStream_t st);
 // kernels_attn_dma.hip: spatial attention over the operand planes written by launch_gemm16_pp(G16X_OUT16 | G16X_QKV)
 int launch_attn_spatial_dma(int npl, const uint16_t* qkv16, long n_seq, int d, int H, int Dh, uint16_t* out16, size_t out_plane,
                             hipStream_t st);

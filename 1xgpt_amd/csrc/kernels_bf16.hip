@@ -696,12 +696,24 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     const float* nbt = c.qk_norm ? lw.temporal.norm_b : nullptr;
     // spatial
     const uint16_t* u = x16;
-    if (!c.qk_norm) {
-        GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
-        u = xn16;
+    int rc = GENIE_E_UNSUPPORTED;
+    bool qkv_done = false;
+    if (!c.qk_norm) {  // one-frame passes: LayerNorm inside the small GEMM's fragment path (no LayerNorm launch)
+        const int r2 = launch_gemm16_sm_ln(1, x, d, lw.norm1_w, lw.norm1_b, 1e-5f, lw.spatial.qkv_w16, d, 0,
+                                           c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, qkv, nullptr, 0, 3 * d, M, 3 * d, d,
+                                           G16_OUTF32, 1.0f, st);
+        if (r2 == GENIE_OK) qkv_done = true;
+        else if (r2 != GENIE_E_UNSUPPORTED) return r2;
     }
-    int rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st);
+    if (!qkv_done) {
+        if (!c.qk_norm) {
+            GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
+            u = xn16;
+        }
+        rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st);
+    }
     if (rc == GENIE_E_UNSUPPORTED) {
+    if (!qkv_done)
     GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.spatial.qkv_w16, d, 0, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv, nullptr,
                                0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
@@ -760,12 +772,21 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
                                x16, 0, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
     // MLP
     u = x16;
+    bool fc1_done = false;
+    if (!c.qk_norm) {
+        const int r2 = launch_gemm16_sm_ln(1, x, d, lw.norm2_w, lw.norm2_b, 1e-5f, lw.fc1_w16, d, 0, c.mlp_bias ? lw.fc1_b : nullptr,
+                                           nullptr, nullptr, big16, 0, c.hidden, M, c.hidden, d, G16_GELU | G16_OUT16, 1.0f, st);
+        if (r2 == GENIE_OK) fc1_done = true;
+        else if (r2 != GENIE_E_UNSUPPORTED) return r2;
+    }
+    if (!fc1_done) {
     if (!c.qk_norm) {
         GENIE_TRY(launch_layer_norm_bf16(x, lw.norm2_w, lw.norm2_b, xn16, M, d, 1e-5f, st));
         u = xn16;
     }
     GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.fc1_w16, d, 0, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, big16, 0, c.hidden,
                                M, c.hidden, d, G16_GELU | G16_OUT16, 1.0f, st));
+    }
     GENIE_TRY(launch_gemm16<1>(big16, c.hidden, 0, lw.fc2_w16, c.hidden, 0, c.mlp_bias ? lw.fc2_b : nullptr, x, x16, 0,
                                d, M, d, c.hidden, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
     return GENIE_OK;
@@ -817,12 +838,24 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     const float* nbt = c.qk_norm ? lw.temporal.norm_b : nullptr;
     // ---- spatial
     const uint16_t* u = xs;
-    if (!c.qk_norm) {
-        GENIE_TRY(launch_layer_norm_split(x, lw.norm1_w, lw.norm1_b, as, pd, M, d, 1e-5f, st));
-        u = as;
+    int rc = GENIE_E_UNSUPPORTED;
+    bool qkv_done = false;
+    if (!c.qk_norm) {  // one-frame passes: LayerNorm inside the small GEMM's fragment path (no LayerNorm launch)
+        const int r2 = launch_gemm16_sm_ln(2, x, d, lw.norm1_w, lw.norm1_b, 1e-5f, lw.spatial.qkv_w16, d, pw_qkv,
+                                           c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, qkv, nullptr, 0, 3 * d, M, 3 * d, d,
+                                           G16_OUTF32, 1.0f, st);
+        if (r2 == GENIE_OK) qkv_done = true;
+        else if (r2 != GENIE_E_UNSUPPORTED) return r2;
     }
-    int rc = spatial_attention_fused(2, c, lw, u, pd, pw_qkv, w, B, as, pd, st);
+    if (!qkv_done) {
+        if (!c.qk_norm) {
+            GENIE_TRY(launch_layer_norm_split(x, lw.norm1_w, lw.norm1_b, as, pd, M, d, 1e-5f, st));
+            u = as;
+        }
+        rc = spatial_attention_fused(2, c, lw, u, pd, pw_qkv, w, B, as, pd, st);
+    }
     if (rc == GENIE_E_UNSUPPORTED) {
+    if (!qkv_done)
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.spatial.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv,
                                nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
     rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
@@ -881,12 +914,21 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
                                x, xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
     // ---- MLP
     u = xs;
+    bool fc1_done = false;
+    if (!c.qk_norm) {
+        const int r2 = launch_gemm16_sm_ln(2, x, d, lw.norm2_w, lw.norm2_b, 1e-5f, lw.fc1_w16, d, pw_fc, c.mlp_bias ? lw.fc1_b : nullptr,
+                                           nullptr, nullptr, hs, ph, hid, M, hid, d, G16_GELU | G16_OUT16, 1.0f, st);
+        if (r2 == GENIE_OK) fc1_done = true;
+        else if (r2 != GENIE_E_UNSUPPORTED) return r2;
+    }
+    if (!fc1_done) {
     if (!c.qk_norm) {
         GENIE_TRY(launch_layer_norm_split(x, lw.norm2_w, lw.norm2_b, as, pd, M, d, 1e-5f, st));
         u = as;
     }
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.fc1_w16, d, pw_fc, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, hs, ph, hid, M,
                                hid, d, G16_GELU | G16_OUT16, 1.0f, st));
+    }
     GENIE_TRY(launch_gemm16<2>(hs, hid, ph, lw.fc2_w16, hid, pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, xs, pd, d, M, d,
                                hid, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
     return GENIE_OK;

@@ -11,6 +11,11 @@
 //     long as A and W agree.  The two halves of the wave consume one whole 128-byte line of every row they touch.
 //   * The NW partial tiles meet in LDS and are added in wave order (fixed order: bit-reproducible), then the usual fused
 //     epilogue (bias, erf-GELU, residual, f32 and/or 16-bit operand output) runs on whole rows.
+//   * LNF: the A operand is LayerNorm(x) of an f32 activation (nn.LayerNorm in front of qkv / fc1, st_transformer.py:73, 81): the
+//     kernel loads A into registers anyway, so every wave reads ITS K range of the tile's 32 f32 rows, the row statistics are
+//     completed across the 8 waves through LDS (mean, then the centred second moment: the two-pass form of the stand-alone
+//     kernel), and the normalised values are rounded into MFMA operands in registers -- the LayerNorm launch and its operand
+//     round trip disappear from the one-frame passes.
 //   * NPL = 2 ("f16x3"): split operands a = hi + lo'/2048; hi.hi goes to one accumulator, hi.lo' + lo'.hi to a second one
 //     that is scaled by 2^-11 at the end (no in-register weight scaling: valid for any operand magnitudes).
 #include <stdlib.h>
@@ -34,14 +39,17 @@ __device__ __forceinline__ f32x16 mma_sm(const s16x8& a, const s16x8& b, const f
 }
 }  // namespace
 
-template <int NPL, int TM, int TN, int NW, int NB>
+template <int NPL, int TM, int TN, int NW, int NB, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
                                                                 const uint16_t* __restrict__ W, long ldw, long planeW,
                                                                 const float* __restrict__ bias, float* __restrict__ Cf,
                                                                 uint16_t* __restrict__ C16, long plane16, long ldc, int M, int N,
                                                                 int K, int flags, float alpha, long strideA, long strideC,
-                                                                const float* Rf, long strideW) {
+                                                                const float* Rf, long strideW, const float* __restrict__ Xf = nullptr,
+                                                                long ldx = 0, const float* __restrict__ ln_g = nullptr,
+                                                                const float* __restrict__ ln_b = nullptr, float ln_eps = 0.f) {
     constexpr int MI = TM / 32, NJ = TN / 32;
+    static_assert(!LNF || (MI == 1 && NB == 1), "LayerNorm-fused A operand: 32-row tiles, one 64-k block per wave");
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][TM][TN] partial tiles
     const int tid = threadIdx.x, lane = tid & 63;
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
     const int r = lane & 31, h = lane >> 5;
     const int nt = (N + TN - 1) / TN;
     const int m0 = (blockIdx.x / nt) * TM, n0 = (blockIdx.x % nt) * TN;
-    A += (size_t)blockIdx.y * strideA;
+    if constexpr (!LNF) A += (size_t)blockIdx.y * strideA;
     W += (size_t)blockIdx.y * strideW;
     const int KW = K / NW;                  // this wave's K range (launcher: KW % 64 == 0)
     const int kw0 = wid * KW;
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
     for (int i = 0; i < MI; ++i) {
         int row = m0 + 32 * i + r;
         row = row < M ? row : M - 1;        // ragged tiles: the surplus rows are computed and never stored
-        ap[i] = A + (size_t)row * lda + kw0 + 32 * h;
+        ap[i] = LNF ? nullptr : A + (size_t)row * lda + kw0 + 32 * h;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -120,6 +128,74 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
     static_assert(REGS * NB + MI * NJ * 16 * NPL <= (NW > 4 ? 232 : 480), "fragment ring + accumulators exceed the register file");
     Block buf[NB];
     const int nblk = KW / 64;
+    if constexpr (LNF) {
+        // ---- A = LayerNorm(x): lane (r, h) owns x[row r][kw0 + 32 h .. + 31] (K = NW * 64: the waves tile the whole row)
+        float* stat = red + (size_t)NW * TM * TN;            // [2][NW][32] partial sums
+        int row = m0 + r;
+        row = row < M ? row : M - 1;
+        const float* xp = Xf + (size_t)row * ldx + kw0 + 32 * h;
+        float xv[32], gv[32], bv[32];
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + k);
+            xv[k] = t.x; xv[k + 1] = t.y; xv[k + 2] = t.z; xv[k + 3] = t.w;
+        }
+        // the W fragments of this wave's block go out now: they are in flight while the statistics are exchanged
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const s16x8* src = reinterpret_cast<const s16x8*>(bp[j] + (size_t)p * planeW);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) buf[0].b[j][p][s] = src[s];
+            }
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            const float4 tg = *reinterpret_cast<const float4*>(ln_g + kw0 + 32 * h + k);
+            const float4 tb = *reinterpret_cast<const float4*>(ln_b + kw0 + 32 * h + k);
+            gv[k] = tg.x; gv[k + 1] = tg.y; gv[k + 2] = tg.z; gv[k + 3] = tg.w;
+            bv[k] = tb.x; bv[k + 1] = tb.y; bv[k + 2] = tb.z; bv[k + 3] = tb.w;
+        }
+        float sx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sx += xv[k];
+        sx += __shfl_xor(sx, 32);
+        if (h == 0) stat[wid * 32 + r] = sx;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += stat[w * 32 + r];   // wave order: the same sum in every wave
+        const float mean = tot * (1.0f / (float)(NW * 64));
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { xv[k] -= mean; q += xv[k] * xv[k]; }
+        q += __shfl_xor(q, 32);
+        if (h == 0) stat[NW * 32 + wid * 32 + r] = q;
+        __syncthreads();
+        float qt = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) qt += stat[NW * 32 + w * 32 + r];
+        const float rstd = 1.0f / sqrtf(qt * (1.0f / (float)(NW * 64)) + ln_eps);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            s16x8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * s + e;
+                const float y = xv[k] * rstd * gv[k] + bv[k];
+                if constexpr (NPL == 2) {
+                    uint16_t hi, lo;
+                    split_f16(y, hi, lo);
+                    vh[e] = (short)hi; vl[e] = (short)lo;
+                } else {
+                    vh[e] = (short)f32_to_bf16(y);
+                }
+            }
+            buf[0].a[0][0][s] = vh;
+            if constexpr (NPL == 2) buf[0].a[0][NPL - 1][s] = vl;
+        }
+        compute(buf[0]);
+    } else {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
         if (b < nblk) load(buf[b], b * 64);
@@ -131,6 +207,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
                 if (c + b + NB < nblk) load(buf[b], (c + b + NB) * 64);
             }
         }
+    }
     }
 
     // ---- the NW partial tiles meet in LDS (accumulator element e of lane (r, h): row 8*(e>>2) + 4h + (e&3), column r)
@@ -241,6 +318,44 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
 #undef SM_SHAPE
 #undef SM_LAUNCH
     GENIE_LAUNCH_CHECK("gemm16_sm");
+    return GENIE_OK;
+}
+
+// C = epilogue(alpha * LayerNorm(x) . W^T + bias) for small problems with K = 512 (8 waves) or 256 (4 waves): x (M, K) f32 with
+// row stride ldx, LayerNorm over the whole row (eps, gamma, beta).  GENIE_E_UNSUPPORTED = take the separate LayerNorm + GEMM.
+int launch_gemm16_sm_ln(int npl, const float* x, long ldx, const float* ln_g, const float* ln_b, float eps, const uint16_t* W,
+                        long ldw, long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc,
+                        int M, int N, int K, int flags, float alpha, hipStream_t st) {
+    static const int on = [] { const char* e = getenv("GENIE_GEMM16_SM_LN"); return e ? atoi(e) : 1; }();
+    static const int sm_on = [] { const char* e = getenv("GENIE_GEMM16_SM"); return e ? atoi(e) : 1; }();
+    static const long max_out = [] { const char* e = getenv("GENIE_GEMM16_SM_MAX"); return e ? atol(e) : 1L << 20; }();
+    if (!on || !sm_on || (long)M * N > max_out || (K != 512 && K != 256)) return GENIE_E_UNSUPPORTED;
+    if (N % 4 || ldc % 4 || ldx % 4 || ldw % 8 || planeW % 8) return GENIE_E_UNSUPPORTED;
+    if (npl == 2 && (flags & G16X_OUT16) && plane16 == 0) return GENIE_E_UNSUPPORTED;
+    const double mn = (double)M * N;
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
+                   4.0 * (double)M * K + 2.0 * npl * (double)N * K +
+                       mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) + (flags & G16X_OUT16 ? 2 * npl : 0)),
+                   st);
+    const long t64 = (long)((M + 31) / 32) * ((N + 63) / 64);
+    const int tn = t64 >= 96 ? 64 : 32;
+    const dim3 grid((unsigned)(((M + 31) / 32) * ((N + tn - 1) / tn)), 1);
+#define SMLN_LAUNCH(NPL_, TN_, NW_)                                                                                       \
+    do {                                                                                                                  \
+        const size_t lds = (size_t)NW_ * 32 * TN_ * 4 + 2 * NW_ * 32 * 4;                                                 \
+        (void)hipFuncSetAttribute((const void*)gemm16_sm_kernel<NPL_, 32, TN_, NW_, 1, true>,                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+        gemm16_sm_kernel<NPL_, 32, TN_, NW_, 1, true><<<grid, NW_ * 64, lds, st>>>(                                       \
+            nullptr, 0, 0, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, 0, 0, Rf, 0, x, ldx, ln_g, ln_b, \
+            eps);                                                                                                         \
+    } while (0)
+#define SMLN_SHAPE(NPL_, TN_)                                                                                             \
+    do { if (K == 512) SMLN_LAUNCH(NPL_, TN_, 8); else SMLN_LAUNCH(NPL_, TN_, 4); } while (0)
+    if (npl == 1) { if (tn == 64) SMLN_SHAPE(1, 64); else SMLN_SHAPE(1, 32); }
+    else { if (tn == 64) SMLN_SHAPE(2, 64); else SMLN_SHAPE(2, 32); }
+#undef SMLN_SHAPE
+#undef SMLN_LAUNCH
+    GENIE_LAUNCH_CHECK("gemm16_sm_ln");
     return GENIE_OK;
 }
 
