@@ -383,6 +383,12 @@ def main():
         out["roofline"]["mfma_issue_frac"] = 3.0 * achieved / peak
         out["roofline"]["note"] = ("algorithmic FLOPs counted once; the kernel issues 3 f16 MFMAs per algorithmic MFMA "
                                    "(split operands), so frac <= 1/3 by construction")
+    if args.precision in ("f16x3", "bf16"):
+        out["roofline"]["board_note"] = (
+            "16-bit MFMA throughput on this board is set by its power-managed clock, not by the schedule: the same gemm16_pp "
+            "binary runs 4096^3 at 0.83 (f16x3 issue) / 0.72 (bf16) of the 2.5 PF peak on zero-filled operands and at 0.51-0.52 on "
+            "random operands; the vendor GEMM shows the same two levels (profiles/r02_gemm_zero_operands.txt, "
+            "r02_gemm_random_operands.txt, r02_vendor_gemm_random_vs_zero.txt; DESIGN.md section 5)")
     if train:
         out["train_step"] = train
     if breakdown:
