@@ -18,6 +18,9 @@
 //   acc' += a_hi (2048 b_hi) + a_hi b_lo' + a_lo' b_hi    (2048 q_hi / 2048 p_hi are exact: |q * scale| < 32, p <= 1).
 // vmcnt bookkeeping is per wave and dynamic (issue counters in SGPRs): a wait names how many younger operations may stay in
 // flight, which differs for the first / last items of a workgroup.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -62,9 +65,12 @@ __device__ __forceinline__ f32x16 mma_k16(const s16x8& a, const s16x8& b, const 
 
 }  // namespace
 
-template <int DH, int NPL>
+// STAMP (study knob GENIE_ATTN_STAMPS=1): wave 0 of every workgroup accumulates s_memtime deltas per phase -- counted wait,
+// barrier, compute -- and adds them to stamps[0..24] (p*3 + {wait, barrier, compute}, [24] = output section) at the end.
+template <int DH, int NPL, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t* __restrict__ qkv16, long P, int d, int H,
-                                                                  long n_items, uint16_t* __restrict__ out16, long out_plane) {
+                                                                  long n_items, uint16_t* __restrict__ out16, long out_plane,
+                                                                  unsigned long long* stamps = nullptr) {
     constexpr int ROWB = DH * 2;                // bytes of one K / Q row of this head
     constexpr int SPR = ROWB / 16;              // 16-byte slots per K / Q row
     constexpr int RPB = 256 / ROWB;             // K / Q rows per 256-byte bank row
@@ -138,17 +144,19 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
         }
         idx_slot[c & 3] = issued;
     };
-    auto issue_q = [&](long item) {
+    auto issue_q = [&](long item, int j0, int j1) {   // pieces [j0, j1) of this wave's Q tile
         const long seq = item / H;
         const int head = (int)(item - seq * H);
         const int soff = (int)(((seq * H + head) * 256 * (long)DH) * 2);
 #pragma unroll
         for (int j = 0; j < PCQ; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(smem + OFF_Q + wid * QW + j * 1024),
-                                                     16, voQ[j], soff, 0, 0);
-            ++issued;
+            if (j >= j0 && j < j1) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(smem + OFF_Q + wid * QW + j * 1024),
+                                                         16, voQ[j], soff, 0, 0);
+                ++issued;
+            }
         }
-        idx_q = issued;
+        idx_q = issued;   // (after the last piece: every Q piece is at least this old)
     };
 
     // fragment read offsets
@@ -163,8 +171,13 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
 
     const long item0 = blockIdx.x, step = gridDim.x;
     if (item0 >= n_items) return;
+    unsigned tacc[25];
+    if constexpr (STAMP) {
+#pragma unroll
+        for (int i = 0; i < 25; ++i) tacc[i] = 0;
+    }
     issue_chunk(item0, 0);
-    issue_q(item0);
+    issue_q(item0, 0, PCQ);
     issue_chunk(item0, 1);
     issue_chunk(item0, 2);
 
@@ -180,12 +193,19 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
             // ---- chunk p of this item (and, for p = 0, this wave's Q tile) must have landed; then every wave's share has
             int need = issued - idx_slot[p & 3];
             if (p == 0) need = min(need, issued - idx_q);
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+            if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
             wait_vm_dyn(need);
+            if constexpr (STAMP) ts1 = __builtin_amdgcn_s_memtime();
             attn_barrier();
+            if constexpr (STAMP) ts2 = __builtin_amdgcn_s_memtime();
             // slot (p - 1) & 3 is free now: refill it with the chunk three phases ahead
             if (p + 3 < 8) issue_chunk(item, p + 3);
             else if (has_next) issue_chunk(nxt, p + 3 - 8);
-            if (p == 1 && has_next) issue_q(nxt);   // this item's Q fragments are in registers since phase 0
+            // next item's Q tile: this item's Q fragments are in registers since phase 0; the 8 pieces are spread over phases
+            // 1..4 (LDS-DMA issue is the expensive part of a phase: all 8 in phase 1 made it 1.5x as long as its neighbours)
+            constexpr int QPP = (PCQ + 3) / 4;
+            if (p >= 1 && p <= 4 && has_next && (p - 1) * QPP < PCQ) issue_q(nxt, (p - 1) * QPP, min(p * QPP, PCQ));
             const unsigned char* sl = smem + (p & 3) * CHUNK;
             if (p == 0) {
 #pragma unroll
@@ -289,7 +309,16 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
                     }
                 }
             }
+            if constexpr (STAMP) {
+                asm volatile("s_nop 0" ::: "memory");
+                const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+                tacc[p * 3] += (unsigned)(ts1 - ts0);
+                tacc[p * 3 + 1] += (unsigned)(ts2 - ts1);
+                tacc[p * 3 + 2] += (unsigned)(ts3 - ts2);
+            }
         }
+        unsigned long long tso = 0;
+        if constexpr (STAMP) tso = __builtin_amdgcn_s_memtime();
         // ---- output: oacc[dt][e] = O(query (e&3) + 8(e>>2) + 4h, feature dt*32 + r); through the wave's scratch to whole rows
         const long seq = item / H;
         const int head = (int)(item - seq * H);
@@ -329,6 +358,13 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
             __builtin_amdgcn_wave_barrier();
         }
         issued += NST;
+        if constexpr (STAMP) tacc[24] += (unsigned)(__builtin_amdgcn_s_memtime() - tso);
+    }
+    if constexpr (STAMP) {
+        if (tid == 0 && stamps) {
+#pragma unroll
+            for (int i = 0; i < 25; ++i) atomicAdd(&stamps[i], (unsigned long long)tacc[i]);
+        }
     }
 }
 
@@ -349,6 +385,25 @@ int launch_attn_spatial_dma(int npl, const uint16_t* qkv16, long n_seq, int d, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                       \
         attn_spatial_dma_kernel<DH_, NPL_><<<grid, 512, lds, st>>>(qkv16, P, d, H, items, out16, (long)out_plane);        \
     } while (0)
+    static const int stamp = [] { const char* e = getenv("GENIE_ATTN_STAMPS"); return e ? atoi(e) : 0; }();
+    if (stamp && Dh == 64 && npl == 2) {
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) (void)hipMalloc(&dbuf, 25 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbuf, 0, 25 * sizeof(unsigned long long), st);
+        constexpr int lds = 4 * 2 * 64 * 64 * 2 + 8 * 2 * 32 * 64 * 2 + 8 * 4096;
+        (void)hipFuncSetAttribute((const void*)attn_spatial_dma_kernel<64, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attn_spatial_dma_kernel<64, 2, true><<<grid, 512, lds, st>>>(qkv16, P, d, H, items, out16, (long)out_plane, dbuf);
+        unsigned long long hbuf[25];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hbuf, dbuf, sizeof(hbuf), hipMemcpyDeviceToHost);
+        const double per = 1.0 / (double)items;  // ticks per item (wave 0 of the workgroup that ran it)
+        fprintf(stderr, "attn_stamps items=%ld per-item ticks:", items);
+        for (int p8 = 0; p8 < 8; ++p8)
+            fprintf(stderr, " p%d[w %.0f b %.0f c %.0f]", p8, hbuf[p8 * 3] * per, hbuf[p8 * 3 + 1] * per, hbuf[p8 * 3 + 2] * per);
+        fprintf(stderr, " out %.0f\n", hbuf[24] * per);
+        GENIE_LAUNCH_CHECK("attn_spatial_dma_stamps");
+        return GENIE_OK;
+    }
     if (Dh == 64 && npl == 2) ATTN_LAUNCH(64, 2);
     else if (Dh == 64) ATTN_LAUNCH(64, 1);
     else if (npl == 2) ATTN_LAUNCH(32, 2);
