@@ -278,6 +278,30 @@ def main():
                         "forward_passes": (cfg.T - 1) * args.maskgit_steps * nb, "ce": mf["loss"],
                         "note": "reference schedule: 15 x maskgit_steps full 16-frame forwards per clip"}
 
+    # secondary leg (N=1 only): the same clips in the throughput precision (bf16 MFMA operands, f32 accumulate), reported BESIDE
+    # the headline -- it does not meet the north star's 1e-4 CE / bit-exact-ids clause, which is why
+    # f16x3 is the default; its CE is printed so the deviation can be read off the same line
+    other_precision = None
+    if reuse and world == 1 and not args.no_secondary and args.precision == "f16x3":
+        try:
+            m2 = STMaskGIT(cfg, precision="bf16").load_numpy_state_dict(sd).to(dev)
+            ev2 = evalmod.GenieEvaluator(ev_args, None, dev, model=m2)
+            ev2.evaluate_metric_sums_reuse(clips, noise=noise)  # warm-up
+            torch.cuda.synchronize()
+            t20 = time.perf_counter()
+            s2 = ev2.evaluate_metric_sums_reuse(clips, noise=noise)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter() - t20
+            m2m = dist_mod.means_from_sums(s2.tolist())
+            other_precision = {"precision": "bf16", "value": (cfg.T - 1) * B / t2, "unit": "frames/s", "clips": B,
+                               "ms_per_step": t2 * 1e3, "ce": m2m["loss"],
+                               "note": "same schedule and clips as the headline; bf16 operands: CE differs from the f32-class "
+                                       "headline at the 1e-4..1e-3 level and ids are not bit-exact"}
+            del ev2, m2
+            torch.cuda.empty_cache()
+        except Exception as e:
+            other_precision = {"error": f"{type(e).__name__}: {e}"}
+
     breakdown = None
     if args.breakdown and rank == 0:
         lib.genie_profile_enable(0x1F)
@@ -379,6 +403,8 @@ def main():
     out["kernel_classes"] = other_classes
     if full_forward:
         out["full_forward_schedule"] = full_forward
+    if other_precision:
+        out["bf16_evaluate"] = other_precision
     if args.precision == "f16x3":
         out["roofline"]["mfma_issue_frac"] = 3.0 * achieved / peak
         out["roofline"]["note"] = ("algorithmic FLOPs counted once; the kernel issues 3 f16 MFMAs per algorithmic MFMA "
