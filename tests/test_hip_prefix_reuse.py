@@ -94,3 +94,32 @@ def test_generate_kv_cache_equals_full_forward(golden, name, steps):
     cached = G.generate_frames_cached(m, ex, 8, steps, 0.0, False, noise=noise)
     mism = (full != cached).float().mean().item()
     assert mism < 2e-3  # autoregressive: identical unless a top-2 logit gap sits below f32 accumulation noise
+
+
+@pytest.mark.parametrize("precision,B", [("exact", 2), ("f16x3", 2), ("f16x3", 1)])
+def test_prompt_pass_fills_cache_like_frame_passes(golden, precision, B):
+    """generate()'s prompt: ONE P-frame genie_clean_pass writing into the T-frame KV-cache layout must leave slots 0..P-1 of
+    every layer exactly as P single-frame genie_frame_pass calls do (same per-row arithmetic; different GEMM tilings)."""
+    z, cfg, sd = golden("shape_dh64")
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+    c, w = m._weights()[:2]
+    T, S, d, L, P = cfg.T, cfg.S, cfg.d_model, cfg.num_layers, 8
+    ids = dev(pkg("synthetic").make_clips(B, cfg, seed=31)).view(B, T, S)
+    ws = m._workspace(B)
+    nbytes = lib.genie_prefix_cache_bytes(c, B)
+    st = torch.cuda.current_stream().cuda_stream
+    ca = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    cb = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    _lib.check(lib.genie_clean_pass(c, w, ids[:, :P].contiguous().data_ptr(), B, P, T, ca.data_ptr(), nbytes, ws.data_ptr(),
+                                    ws.numel(), st), "genie_clean_pass")
+    for t in range(P):
+        _lib.check(lib.genie_frame_pass(c, w, ids[:, t].contiguous().data_ptr(), B, t, cb.data_ptr(), nbytes, 0, ws.data_ptr(),
+                                        ws.numel(), st), "genie_frame_pass")
+    a = ca.view(L, B, T, S, 3 * d)[:, :, :P]
+    b = cb.view(L, B, T, S, 3 * d)[:, :, :P]
+    assert torch.isfinite(a).all()
+    scale = b.abs().max().item()
+    assert (a - b).abs().max().item() < 3e-5 * max(1.0, scale)
+    assert (ca.view(L, B, T, S, 3 * d)[:, :, P:] == 0).all()   # slots >= P untouched
