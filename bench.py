@@ -182,14 +182,13 @@ def main():
     args = ap.parse_args()
 
     # watchdog: a rank stuck in a collective (a peer died, a mismatched sequence) must not hang the node -- dump every
-    # thread's Python stack to stderr and exit after GENIE_BENCH_WATCHDOG seconds (default 600; the default run takes ~2 min)
+    # thread's Python stack to stderr and exit after GENIE_BENCH_WATCHDOG seconds (default 900; the default run takes ~2 min)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)  # never returns (the parent only waits for its child launcher)
     import faulthandler
-    wd = int(os.environ.get("GENIE_BENCH_WATCHDOG", "600"))
+    wd = int(os.environ.get("GENIE_BENCH_WATCHDOG", "900"))
     if wd > 0:
         faulthandler.dump_traceback_later(wd, exit=True)
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args.gpus)  # never returns
     dist_mod = importlib.import_module("1xgpt_amd.distributed")
     rank, world, local_rank = dist_mod.init_distributed()
     if world != args.gpus:
