@@ -161,6 +161,9 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
                      long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M,
                      int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC,
                      float qscale = 1.0f, int head_dim = 0);
+// kernels_attn_bwd16.hip: spatial attention backward on the bf16 matrix cores (bf16 training precision)
+int launch_attn_spatial_bwd_bf16(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, float* stats, long n_bt,
+                                 int S, int d, int H, int Dh, float scale, hipStream_t st);
 // kernels_gemm_sm.hip: small (latency-bound) problems; GENIE_E_UNSUPPORTED = not small / tiling does not fit
 int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                      const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,

@@ -144,6 +144,10 @@ static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, QkSrc qk, cons
     const long q3 = (long)S * 3 * d, ss = (long)S * S, hss = (long)H * ss, sd = (long)S * d;
     const long qld = qk.ld, qs = (long)S * qk.ld;
     const float sc = c.attn_scale;
+    if (c.precision == GENIE_PREC_BF16) {   // bf16 training: the backward products on the bf16 matrix cores as well
+        const int rc = launch_attn_spatial_bwd_bf16(qkv, qk.p, qk.ld, dao, dqkv, w.p, BT, S, d, H, Dh, sc, st);
+        if (rc != GENIE_E_UNSUPPORTED) return rc;
+    }
     {   // production geometry: fused kernel, no S x S traffic
         const int rc = launch_attn_spatial_bwd_fused(qkv, qk.p, qk.ld, dao, dqkv, BT, S, d, H, Dh, sc, st);
         if (rc != GENIE_E_UNSUPPORTED) return rc;

@@ -121,6 +121,43 @@ def test_real_geometry_vs_reference_samples(golden, precision):
         assert np.abs(samp - z[f"s0_gradsample/{k}"]).max() <= tol * np.abs(g).max() + 1e-12, k
 
 
+def test_real_geometry_bf16(golden):
+    """The bf16 precision at the production geometry (T=16, S=256, Dh=64): forward on the bf16 GEMMs, spatial attention BACKWARD
+    on the bf16 matrix cores (kernels_attn_bwd16.hip: dQ / dK / dV and the softmax backward from bf16 operands): every tensor's
+    gradient norm within 2 % of the f32 reference's, sampled entries within 3 % of the tensor's largest."""
+    z, cfg, sd = golden("train_shape_dh64")
+    tr = make_trainer(cfg, sd, "bf16")
+    loss, _ = tr.forward_backward(dev(z["s0_input_ids"]), dev(z["s0_labels"]))
+    assert abs(float(loss) - float(z["s0_loss"])) < 1e-2
+    for k, g in tr.gradients().items():
+        g = g.cpu().numpy()
+        n_ref = float(z[f"s0_gradnorm/{k}"])
+        assert abs(np.sqrt((g.astype(np.float64) ** 2).sum()) - n_ref) <= 2e-2 * n_ref + 1e-12, k
+        samp = g.reshape(-1)[:: max(1, g.size // 64)][:64]
+        assert np.abs(samp - z[f"s0_gradsample/{k}"]).max() <= 3e-2 * np.abs(g).max() + 1e-12, k
+
+
+@pytest.mark.parametrize("H,d,qk_norm", [(4, 128, False), (2, 128, True), (4, 256, False)])
+def test_bf16_attention_backward_vs_exact(H, d, qk_norm):
+    """S = 256 with head_dim 32 and 64, with and without qk-norm: the bf16 trainer (bf16-MFMA spatial attention backward)
+    against the exact trainer on the same weights and batch -- every gradient tensor within 3 % (Frobenius)."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=H, d_model=d, T=4, S=256, num_factored_vocabs=2, qk_norm=qk_norm,
+                                    use_mup=False, num_prompt_frames=2)
+    synth = pkg("synthetic")
+    sd = synth.make_state_dict(cfg, seed=17, law="conditioned")
+    ids = synth.make_clips(2, cfg, seed=18)
+    x = ids.reshape(2, 4, 256).copy()
+    x[:, 2:] = cfg.image_vocab_size
+    grads = {}
+    for prec in ("exact", "bf16"):
+        tr = make_trainer(cfg, sd, prec)
+        tr.forward_backward(dev(x.reshape(2, -1)), dev(ids))
+        grads[prec] = {k: g.cpu().numpy().astype(np.float64) for k, g in tr.gradients().items()}
+    bad = {k: fro_err(grads["bf16"][k], grads["exact"][k]) for k in grads["exact"]}
+    bad = {k: v for k, v in bad.items() if v > 3e-2}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("H,d,B,qk_norm,T", [(4, 128, 3, False, 4), (2, 64, 1, False, 4), (2, 128, 2, True, 4),
                                               (4, 128, 1, True, 4), (4, 128, 2, False, 16), (2, 128, 1, True, 16),
                                               (4, 256, 2, False, 4), (8, 512, 1, False, 4)])
