@@ -174,7 +174,8 @@ static int spatial_attn_bwd(const genie_cfg& c, const float* qkv, QkSrc qk, cons
 
 // ================================================================================================
 // 16-bit matrix-core variant (GENIE_PREC_BF16 / GENIE_PREC_F16X3): every Linear product -- forward, dgrad, wgrad --
-// runs on the NT 16-bit GEMM of kernels_bf16.hip; LayerNorm, softmax, both attention cores (forward and backward),
+// runs on the NT 16-bit GEMM of kernels_bf16.hip; LayerNorm, softmax, both attention cores (forward and backward; bf16:
+// the spatial backward's products on the bf16 matrix cores, kernels_attn_bwd16.hip),
 // GELU, the residual stream, CE and all gradient reductions stay f32 exactly as in the exact variant.
 // Saved per layer (bytes/token: 52 d f32 + 18 d NPL 16-bit): f32 x0, qkv_s, x1, qkv_t, x2, z;  16-bit GEMM operands
 // u1 = norm1(x0), ao_s, x1, ao_t, u2 = norm2(x2), h = gelu(z).
