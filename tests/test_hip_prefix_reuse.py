@@ -123,3 +123,32 @@ def test_prompt_pass_fills_cache_like_frame_passes(golden, precision, B):
     scale = b.abs().max().item()
     assert (a - b).abs().max().item() < 3e-5 * max(1.0, scale)
     assert (ca.view(L, B, T, S, 3 * d)[:, :, P:] == 0).all()   # slots >= P untouched
+
+
+@pytest.mark.parametrize("name", ["shape_dh64", "shape_dh32"])
+@pytest.mark.parametrize("precision,tol_max,tol_med", [("f16x3", 3e-5, 1e-5), ("bf16", 8e-2, 6e-3), ("exact", 3e-5, 1e-5)])
+def test_single_frame_pass_equals_full_forward_frame(golden, name, precision, tol_max, tol_med):
+    """One-frame passes run their own kernels (split-K small GEMM with the LayerNorm in its fragment path, key-split spatial
+    attention, register-resident temporal attention over the cache): the logits of frames 0 and 1 from genie_frame_pass must
+    equal those frames of the full 16-frame forward (temporal attention is causal) -- to f32 noise in exact / f16x3, to bf16
+    noise in bf16."""
+    z, cfg, sd = golden(name)
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+    c, w = m._weights()[:2]
+    T, S = cfg.T, cfg.S
+    V = cfg.factored_vocab_size * cfg.num_factored_vocabs
+    ids = dev(pkg("synthetic").make_clips(1, cfg, seed=77)).view(1, T, S)
+    full = m.compute_logits(ids.view(1, T, 16, 16))                      # (1, V, T, 16, 16)
+    ws = m._workspace(1)
+    nbytes = lib.genie_prefix_cache_bytes(c, 1)
+    cache = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for t in (0, 1):
+        lg = torch.empty(1, S, V, dtype=torch.float32, device="cuda")
+        _lib.check(lib.genie_frame_pass(c, w, ids[:, t].contiguous().data_ptr(), 1, t, cache.data_ptr(), nbytes, lg.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), st), "genie_frame_pass")
+        ref = full[0, :, t].reshape(V, S).T                               # (S, V)
+        err = (lg[0] - ref).abs()
+        assert err.max().item() < tol_max and err.median().item() < tol_med, (t, err.max().item(), err.median().item())
