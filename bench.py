@@ -208,7 +208,9 @@ def main():
 
     cfg = cfgmod.c138() if args.model == "c138" else cfgmod.c35()
     reuse = not args.no_reuse
-    B = args.batch or ({"exact": 16, "f16x3": 48, "bf16": 64} if reuse else {"exact": 4, "f16x3": 16, "bf16": 32})[
+    # clips per GPU: 128 makes every launch of the 15-frame passes a whole number of rounds over the 256 CUs (1,920 row
+    # tiles of 256; 15,360 attention items) -- 48 clips left 1-2 % in partial last rounds
+    B = args.batch or ({"exact": 16, "f16x3": 128, "bf16": 128} if reuse else {"exact": 4, "f16x3": 16, "bf16": 32})[
         args.precision]
     sd = synth.make_state_dict(cfg, seed=0, law="conditioned")
     model = STMaskGIT(cfg, precision=args.precision).load_numpy_state_dict(sd).to(dev)

@@ -5,7 +5,7 @@ TAG=${1:-r02}
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 bash tools/gpu_profile_bench.sh ${TAG} > gpurun_out/${TAG}_profile.log 2>&1
-bash tools/gpu_pmc_bench.sh ${TAG} f16x3 48 > gpurun_out/${TAG}_pmc.log 2>&1
+bash tools/gpu_pmc_bench.sh ${TAG} f16x3 128 > gpurun_out/${TAG}_pmc.log 2>&1
 python tools/bench_generate.py --batches 1 16 --steps 2 8 > gpurun_out/${TAG}_generate.txt 2>&1
 python tools/bench_forward.py > gpurun_out/${TAG}_forward.txt 2>&1
 python tools/bench_e2e.py > gpurun_out/${TAG}_e2e.json 2> gpurun_out/${TAG}_e2e.err

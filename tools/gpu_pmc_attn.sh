@@ -3,7 +3,7 @@
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-events --no-secondary --no-train-leg --no-cpu-baseline --batch 48"
+ARGS="--steps 1 --warmup 0 --no-events --no-secondary --no-train-leg --no-cpu-baseline --batch 128"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
    -d $R/gpurun_out/${TAG}_pa1 --output-format csv -- python3 $R/bench.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_INST_LDS \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Three rocprofv3 --pmc passes of the default bench step (no trace domains) -> gpurun_out/<tag>_pmc_bench.json
 # usage: tools/gpu_pmc_bench.sh <tag> <precision> <clips>
-TAG=${1:-r02}; PREC=${2:-f16x3}; CLIPS=${3:-48}
+TAG=${1:-r02}; PREC=${2:-f16x3}; CLIPS=${3:-128}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 0 --no-events --no-secondary --no-train-leg --no-cpu-baseline --precision $PREC --batch $CLIPS"
