@@ -128,6 +128,12 @@ class STMaskGIT(nn.Module):
                 t = torch.empty((2,) + tuple(wt.shape), dtype=torch.float16, device=dev)
                 _lib.check(lib.genie_pack_split_f16(wt.data_ptr(), t.data_ptr(), wt.numel(), st),
                            "genie_pack_split_f16")
+                # the 256x256 GEMM multiplies the weight's hi plane by 2^11 in registers (gemm16_pp): exact below 32 only.
+                # Checked on the packed plane at load time (inf / > 31.98 would overflow f16): a checkpoint with such a
+                # weight must run in `exact` or `bf16`.
+                if not bool(torch.isfinite(t[0]).all()) or float(t[0].abs().max()) >= 31.98:
+                    raise ValueError("f16x3 precision needs |weight| < 32 (the split GEMM scales the weight's hi plane by 2^11 in "
+                                     "f16); this checkpoint has a larger or non-finite weight -- use precision='exact' or 'bf16'")
                 keep.append(t)
                 return t.data_ptr()
 
