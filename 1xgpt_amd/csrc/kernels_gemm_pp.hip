@@ -354,7 +354,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     const bool do_gelu = fl & G16X_GELU, do_acc = fl & G16X_ACCUM;
     const bool out16 = fl & G16X_OUT16, outf = fl & G16X_OUTF32, nts = fl & G16X_NT;
     const float ascale = NPL == 2 ? alpha * (1.0f / 2048.0f) : alpha;
-    const int c4 = (lane & 15) << 2;
 
     // K-tile 0 of the first tile; every later tile's K-tile 0 is staged BEFORE the previous tile's epilogue, so that its
     // loads run ahead of the 256 KB of output stores instead of queueing behind them
@@ -413,9 +412,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
         // ---- epilogue.  The accumulators hold one COLUMN per lane; each wave transposes its tile through its own 8 KB of
         // the ring's second buffer, 32 rows at a time, and then works on whole rows: 16 lanes x float4 = one 256-byte row
         // segment per quarter-wave for the residual read, the f32 store and the 16-bit operand store.
-        const int col = n0e + wn * 64 + c4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
         if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0) {
             // ---- spatial-attention operand layout (N = 3d, d % 256 == 0, so a 256-column tile is all-Q, all-K or all-V; the
             // 256 rows of a tile are exactly one (clip, frame) sequence).  C16 holds 3*NPL planes of M*d 16-bit values:
@@ -426,39 +422,53 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             const int which = n0e / dm;                      // 0 Q, 1 K, 2 V  (block-uniform)
             const size_t P = (size_t)plane16;               // = M * d
             uint16_t* base = C16 + (size_t)which * NPL * P;
-            const float4 bvq = bv;
             if (which < 2) {
+                // rows of 8 lanes x 8 columns: one 16-byte store per 16-bit plane and lane (the 8-byte form issued twice as
+                // many store instructions for the same bytes, and the epilogue is store-ISSUE bound).  The transpose scratch
+                // XORs its 16-byte slot with (row & 1) so that the two rows a 16-lane pass reads use disjoint banks.
                 const float qs = which == 0 ? qscale : 1.0f;
-                const int colq = n0e - which * dm + wn * 64 + c4;
+                const int c8 = (lane & 7) << 3;
+                const int colq = n0e - which * dm + wn * 64 + c8;
+                const int hq = colq / head_dim, fq = colq - hq * head_dim;
+                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                if (bias) { b0 = *reinterpret_cast<const float4*>(bias + n0e + wn * 64 + c8); b1 = *reinterpret_cast<const float4*>(bias + n0e + wn * 64 + c8 + 4); }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q][j][e];
+                        for (int e = 0; e < 16; ++e) {
+                            const int rw = (e & 3) + 8 * (e >> 2) + 4 * h;
+                            ct[rw * 64 + ((j * 32 + r) ^ ((rw & 1) << 2))] = acc[q][j][e];
+                        }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int rl = it * 4 + (lane >> 4);
+                    for (int it = 0; it < 4; ++it) {
+                        const int rl = it * 8 + (lane >> 3);
                         // head-major: [(sequence, head)][row of the sequence][feature] -- a head's 256 rows are one contiguous
                         // 256 * head_dim block, which is what the attention kernel's LDS-DMA pieces walk
-                        const int hq = colq / head_dim, fq = colq - hq * head_dim;
                         const size_t idx = (((size_t)(m0e >> 8) * (dm / head_dim) + hq) * 256 + (wm * 128 + q * 32 + rl)) * head_dim + fq;
-                        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
-                        v.x = (v.x * ascale + bvq.x) * qs; v.y = (v.y * ascale + bvq.y) * qs;
-                        v.z = (v.z * ascale + bvq.z) * qs; v.w = (v.w * ascale + bvq.w) * qs;
-                        typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                        const int sw = (rl & 1) << 2;
+                        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + (c8 ^ sw));
+                        float4 u = *reinterpret_cast<const float4*>(ct + rl * 64 + ((c8 + 4) ^ sw));
+                        v.x = (v.x * ascale + b0.x) * qs; v.y = (v.y * ascale + b0.y) * qs;
+                        v.z = (v.z * ascale + b0.z) * qs; v.w = (v.w * ascale + b0.w) * qs;
+                        u.x = (u.x * ascale + b1.x) * qs; u.y = (u.y * ascale + b1.y) * qs;
+                        u.z = (u.z * ascale + b1.z) * qs; u.w = (u.w * ascale + b1.w) * qs;
+                        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
                         if constexpr (NPL == 1) {
-                            const u2v t = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
-                                           (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16)};
-                            __builtin_nontemporal_store(t, reinterpret_cast<u2v*>(base + idx));
+                            const u4v t = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
+                                           (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16),
+                                           (uint32_t)f32_to_bf16(u.x) | ((uint32_t)f32_to_bf16(u.y) << 16),
+                                           (uint32_t)f32_to_bf16(u.z) | ((uint32_t)f32_to_bf16(u.w) << 16)};
+                            __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(base + idx));
                         } else {
-                            uint32_t h01, h23, l01, l23;
+                            uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
                             split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
-                            const u2v th = {h01, h23}, tl = {l01, l23};
-                            __builtin_nontemporal_store(th, reinterpret_cast<u2v*>(base + idx));
-                            __builtin_nontemporal_store(tl, reinterpret_cast<u2v*>(base + P + idx));
+                            split_f16_x4(u.x, u.y, u.z, u.w, h45, h67, l45, l67);
+                            const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
+                            __builtin_nontemporal_store(th, reinterpret_cast<u4v*>(base + idx));
+                            __builtin_nontemporal_store(tl, reinterpret_cast<u4v*>(base + P + idx));
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -515,7 +525,93 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+        } else if constexpr (EPI >= 0 && (EPI & G16X_OUT16) != 0 && (EPI & (G16X_OUTF32 | G16X_ACCUM)) == 0) {
+            // 16-bit output only (fc1: GELU + operand planes): 8 columns per lane
+            // rows of 8 lanes x 8 columns (see the Q / K path above): 16-byte stores for the 16-bit planes, two adjacent float4
+            // for the f32 output and the residual read
+            const int c8 = (lane & 7) << 3;
+            const int col8 = n0e + wn * 64 + c8;
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (bias) { b0 = *reinterpret_cast<const float4*>(bias + col8); b1 = *reinterpret_cast<const float4*>(bias + col8 + 4); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rw = (e & 3) + 8 * (e >> 2) + 4 * h;
+                        ct[rw * 64 + ((j * 32 + r) ^ ((rw & 1) << 2))] = acc[q][j][e];
+                    }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = it * 8 + (lane >> 3);
+                    const int row = m0e + wm * 128 + q * 32 + rl;
+                    const int sw = (rl & 1) << 2;
+                    float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + (c8 ^ sw));
+                    float4 u = *reinterpret_cast<const float4*>(ct + rl * 64 + ((c8 + 4) ^ sw));
+                    v.x = v.x * ascale + b0.x; v.y = v.y * ascale + b0.y; v.z = v.z * ascale + b0.z; v.w = v.w * ascale + b0.w;
+                    u.x = u.x * ascale + b1.x; u.y = u.y * ascale + b1.y; u.z = u.z * ascale + b1.z; u.w = u.w * ascale + b1.w;
+                    auto gelu4 = [](float4& t) {
+                        const genie_f2 g0 = gelu_erf_fast2(genie_f2{t.x, t.y}), g1 = gelu_erf_fast2(genie_f2{t.z, t.w});
+                        t.x = g0[0]; t.y = g0[1]; t.z = g1[0]; t.w = g1[1];
+                    };
+                    if (do_gelu) { gelu4(v); gelu4(u); }
+                    const size_t idx = (size_t)row * ldc + col8;
+                    if (do_acc) {
+                        const float4 o0 = *reinterpret_cast<const float4*>(Rsrc + idx);
+                        const float4 o1 = *reinterpret_cast<const float4*>(Rsrc + idx + 4);
+                        v.x += o0.x; v.y += o0.y; v.z += o0.z; v.w += o0.w;
+                        u.x += o1.x; u.y += o1.y; u.z += o1.z; u.w += o1.w;
+                    }
+                    if constexpr (ABL & 8) {
+                        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
+                        continue;
+                    }
+                    if (outf) {
+                        if (nts) {
+                            typedef float nt4 __attribute__((ext_vector_type(4)));
+                            nt4 t0 = {v.x, v.y, v.z, v.w}, t1 = {u.x, u.y, u.z, u.w};
+                            __builtin_nontemporal_store(t0, reinterpret_cast<nt4*>(Cf + idx));
+                            __builtin_nontemporal_store(t1, reinterpret_cast<nt4*>(Cf + idx + 4));
+                        } else {
+                            *reinterpret_cast<float4*>(Cf + idx) = v;
+                            *reinterpret_cast<float4*>(Cf + idx + 4) = u;
+                        }
+                    }
+                    if (out16) {
+                        if (fl & G16X_GELU16) { gelu4(v); gelu4(u); }
+                        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                        auto st4 = [&](uint16_t* p_, uint32_t a, uint32_t b, uint32_t c, uint32_t dd) {
+                            u4v t = {a, b, c, dd};
+                            if (nts) __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(p_));
+                            else *reinterpret_cast<u4v*>(p_) = t;
+                        };
+                        const bool split_out = EPI >= 0 ? (NPL == 2) : (plane16 != 0);  // compile-time in the EPI instantiations
+                        if (!split_out) {  // bf16 output
+                            st4(C16 + idx, (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
+                                (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16),
+                                (uint32_t)f32_to_bf16(u.x) | ((uint32_t)f32_to_bf16(u.y) << 16),
+                                (uint32_t)f32_to_bf16(u.z) | ((uint32_t)f32_to_bf16(u.w) << 16));
+                        } else {             // split f16 planes [hi | lo]
+                            uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
+                            split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
+                            split_f16_x4(u.x, u.y, u.z, u.w, h45, h67, l45, l67);
+                            st4(C16 + idx, h01, h23, h45, h67);
+                            st4(C16 + (size_t)plane16 + idx, l01, l23, l45, l67);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next round
+            }
         } else {
+            // f32 output (alone or with 16-bit planes): 4 columns per lane, 16 lanes per row -- every f32 store instruction
+            // covers whole 256-byte row segments (8 columns per lane would interleave two instructions inside each 32 bytes:
+            // measured 10-25 % slower on the f32-output flavours)
+            const int c4 = (lane & 15) << 2;
+            const int col = n0e + wn * 64 + c4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -612,7 +708,8 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
         flags |= G16X_NT;
     }
     if (M < 256 || M % 256 || N % 256 || K % (2 * bk) || K < 2 * bk) return GENIE_E_UNSUPPORTED;
-    if (lda % 8 || ldw % 8 || ldc % 4) return GENIE_E_UNSUPPORTED;
+    if (lda % 8 || ldw % 8 || ldc % 4 || ((flags & G16X_OUT16) && !(flags & (G16X_QKV | G16X_OUTF32 | G16X_ACCUM)) && ldc % 8))
+        return GENIE_E_UNSUPPORTED;  // (16-byte stores of the 16-bit-only epilogue)
     // 32-bit byte offsets inside one tile's buffer descriptor
     if ((double)(npl - 1) * planeA * 2 + 256.0 * lda * 2 + 2.0 * K >= 4.0e9) return GENIE_E_UNSUPPORTED;
     if ((double)(npl - 1) * planeW * 2 + 256.0 * ldw * 2 + 2.0 * K >= 4.0e9) return GENIE_E_UNSUPPORTED;
