@@ -23,16 +23,23 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { CONV_D2S = 1 };
 
-__global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+// BK = 64, OCC = 1: three 48 KB stages, one workgroup per CU.  BK = 32, OCC = 2: three 24 KB stages and <= 128 registers, two
+// workgroups per CU -- one's barrier / DMA waits are covered by the other's MFMAs.
+template <int BK, int OCC>
+__global__ __launch_bounds__(512, OCC) void conv3x3_igemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                               const float* __restrict__ bias,
                                                               const uint16_t* __restrict__ residual,
                                                               uint16_t* __restrict__ Y, const uint16_t* __restrict__ zero,
                                                               int n_img, int H, int Wd, int Cin, int Cout, int flags,
                                                               int stride, float* __restrict__ gn_part, int gn_cpg) {
-    constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
-    constexpr int ROWB = 128, SPR = 8, RPB = 2;
-    constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB, STAGE_B = A_TILE + W_TILE;  // 48 KB
-    constexpr int CPW = 6;  // 1 KB chunks per wave per stage: 4 of A (32 chunks / 8 waves), 2 of W
+    constexpr int BM = 256, BN = 128, NST = 3;
+    constexpr int ROWB = BK * 2;         // bytes of one LDS row
+    constexpr int SPR = ROWB / 16;       // 16-byte slots per row
+    constexpr int RPC = 1024 / ROWB;     // rows per 1 KB DMA chunk
+    constexpr int RPB = 2;
+    constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB, STAGE_B = A_TILE + W_TILE;  // 48 KB / 24 KB
+    constexpr int ACH = A_TILE / 1024 / 8, WCH = W_TILE / 1024 / 8;  // 1 KB chunks per wave per stage: 4 + 2 / 2 + 1
+    constexpr int CPW = ACH + WCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -40,9 +47,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
     const int r = lane & 31, h = lane >> 5;
     // H, Wd: OUTPUT height/width; the input image is (H*stride, Wd*stride) (stride 2 = the encoder's downsample conv)
     const int Hin = H * stride, Win = Wd * stride;
-    const long M = (long)n_img * H * Wd;
+    const int HW = H * Wd;
+    const int M = n_img * HW;            // launcher: pixel counts (output and input) < 2^31
     const int K = 9 * Cin;
-    const int mt = (int)((M + BM - 1) / BM), nt = (Cout + BN - 1) / BN;
+    const int mt = (M + BM - 1) / BM, nt = (Cout + BN - 1) / BN;
     int bid = blockIdx.x, m_tile, n_tile;
     const int full = (mt / 8) * 8 * nt;
     if (bid < full) {
@@ -54,29 +62,46 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
         m_tile = (mt / 8) * 8 + rem / nt;
         n_tile = rem % nt;
     }
-    const long m0 = (long)m_tile * BM;
+    const int m0 = m_tile * BM;
     const int n0 = n_tile * BN;
+    // pixel index -> (image, y, x): shifts when the image sides are powers of two (every MAGVIT2 level), 32-bit divisions
+    // otherwise (the 64-bit divisions this replaces were a fifth of a 256^2 tile's time)
+    const bool pow2 = !(Wd & (Wd - 1)) && !(HW & (HW - 1));
+    const int sh_w = 31 - __builtin_clz(Wd), sh_hw = 31 - __builtin_clz(HW);
+    auto pix_of = [&](int p, int& img, int& y, int& x) {
+        if (pow2) {
+            img = p >> sh_hw;
+            const int in_img = p & (HW - 1);
+            y = in_img >> sh_w;
+            x = in_img & (Wd - 1);
+        } else {
+            img = (int)((unsigned)p / (unsigned)HW);
+            const int in_img = p - img * HW;
+            y = (int)((unsigned)in_img / (unsigned)Wd);
+            x = in_img - y * Wd;
+        }
+    };
 
-    // ---- staging descriptors.  A chunks c = wid + 8*i (i < 4): rows c*8 .. c*8+7; W chunks: wid + 8*j (j < 2)
-    int a_y[4], a_x[4], a_slot[4];
-    long a_pix[4];  // INPUT pixel index under the centre tap of the lane's output pixel, -1 if the row is past M
-    const int c_row = lane >> 3, c_phys = lane & 7;
+    // ---- staging descriptors.  A chunks c = wid + 8*i (i < ACH): rows c*RPC .. c*RPC+RPC-1; W chunks: wid + 8*j (j < WCH)
+    int a_y[ACH], a_x[ACH], a_slot[ACH];
+    int a_pix[ACH];  // INPUT pixel index under the centre tap of the lane's output pixel, -1 if the row is past M
+    const int c_row = lane / SPR, c_phys = lane % SPR;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row_local = (wid + 8 * i) * 8 + c_row;
+    for (int i = 0; i < ACH; ++i) {
+        const int row_local = (wid + 8 * i) * RPC + c_row;
         a_slot[i] = c_phys ^ ((row_local / RPB) % SPR);
-        long p = m0 + row_local;
+        const int p = m0 + row_local;
         if (p >= M) { a_pix[i] = -1; a_y[i] = 0; a_x[i] = 0; continue; }
-        const long img = p / ((long)H * Wd);
-        const long in_img = p - img * (long)H * Wd;
-        a_y[i] = (int)(in_img / Wd) * stride;   // input coordinates of the centre tap
-        a_x[i] = (int)(in_img % Wd) * stride;
+        int img, y, x;
+        pix_of(p, img, y, x);
+        a_y[i] = y * stride;   // input coordinates of the centre tap
+        a_x[i] = x * stride;
         a_pix[i] = (img * Hin + a_y[i]) * Win + a_x[i];
     }
-    const uint16_t* w_src[2];
+    const uint16_t* w_src[WCH];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row_local = (wid + 8 * j) * 8 + c_row;
+    for (int j = 0; j < WCH; ++j) {
+        const int row_local = (wid + 8 * j) * RPC + c_row;
         const int slot = c_phys ^ ((row_local / RPB) % SPR);
         int rw = n0 + row_local;
         rw = rw < Cout ? rw : Cout - 1;
@@ -87,16 +112,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         unsigned char* base = smem + st * STAGE_B;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < ACH; ++i) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = a_pix[i] >= 0 && yy >= 0 && yy < Hin && xx >= 0 && xx < Win;
-            const uint16_t* src = ok ? X + (size_t)(a_pix[i] + (long)dy * Win + dx) * Cin + kc + a_slot[i] * 8 : zero;
+            const uint16_t* src = ok ? X + (size_t)(a_pix[i] + dy * Win + dx) * Cin + kc + a_slot[i] * 8 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + (wid + 8 * i) * 1024), 16, 0,
                                              0);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WCH; ++j)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(w_src[j] + k0),
                 (__attribute__((address_space(3))) void*)(base + A_TILE + (wid + 8 * j) * 1024), 16, 0, 0);
@@ -123,7 +148,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage((kt + 2) % NST, (kt + 2) * BK);
+        if (kt + 2 < nk && !(flags & 512)) stage((kt + 2) % NST, (kt + 2) * BK);
+        if (flags & 1024) continue;
         const unsigned char* sa = smem + (kt % NST) * STAGE_B;
         const unsigned char* sw = sa + A_TILE;
 #pragma unroll
@@ -141,97 +167,423 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_kernel(const uint16_t* _
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- epilogue through LDS: rows = pixels, 4 consecutive output channels per lane
+    // ---- epilogue through LDS: rows = pixels, 8 consecutive output channels per lane (16-byte stores: 8 lanes cover the wave's
+    // 64 columns, 8 rows per instruction); each wave transposes its 64x64 tile in two 32-row halves through an 8 KB slice
+    // (64 KB for the workgroup: fits the BK = 32 form's 72 KB together with the GroupNorm partials)
     __syncthreads();
-    float* ct = reinterpret_cast<float*>(smem) + wid * (64 * 64);
+    if ((flags & 256) && acc[0][0][0] != 12345.f) return;  // study knobs (GENIE_CONV_ABL): 256 no epilogue, 512 no DMA, 1024 no MFMA
+    float* ct = reinterpret_cast<float*>(smem) + wid * (32 * 64);
+    const int c8 = (lane & 7) << 3;
+    const int col = n0 + wn * 64 + c8;
+    float bv[8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (bias && col < Cout) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    const bool d2s = flags & CONV_D2S;
+    const int Cq = Cout >> 2;  // channels after depth-to-space (launcher: Cq % 8 == 0, so a lane's 8 channels share a sub-pixel)
+    const int d2_grp = d2s ? col / Cq : 0, d2_c = d2s ? col - d2_grp * Cq : 0;
+    // GroupNorm partials of this lane's channels 0-3 / 4-7 (each inside one group: cpg % 4 == 0) over its 8 rows
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
-    const int c4 = (lane & 15) << 2;
-    const int col = n0 + wn * 64 + c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && col < Cout) bv = *reinterpret_cast<const float4*>(bias + col);
-    const bool d2s = flags & CONV_D2S;
-    const int Cq = Cout >> 2;  // channels after depth-to-space
-    float gs = 0.f, gq = 0.f;  // GroupNorm partials of this lane's 4 channels (one group: cpg % 4 == 0) over its 16 rows
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int rl = it * 4 + (lane >> 4);
-        const long p = m0 + wm * 64 + rl;
-        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
-        if (p >= M || col >= Cout) continue;
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        size_t oidx;
-        if (!d2s) {
-            oidx = (size_t)p * Cout + col;
-        } else {  // DCR: conv channel (i*2 + j)*Cq + c -> pixel (2y+i, 2x+j), channel c
-            const int grp = col / Cq, c = col - grp * Cq;
-            const long img = p / ((long)H * Wd);
-            const long in_img = p - img * (long)H * Wd;
-            const int y = (int)(in_img / Wd), x = (int)(in_img % Wd);
-            oidx = (((size_t)img * (2 * H) + (2 * y + (grp >> 1))) * (2 * Wd) + (2 * x + (grp & 1))) * Cq + c;
+            for (int e = 0; e < 16; ++e) ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + (lane >> 3);
+            const int p = m0 + wm * 64 + i * 32 + rl;
+            const float4 v0 = *reinterpret_cast<const float4*>(ct + rl * 64 + c8);
+            const float4 v1 = *reinterpret_cast<const float4*>(ct + rl * 64 + c8 + 4);
+            if (p >= M || col >= Cout) continue;
+            float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3],
+                          v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+            size_t oidx;
+            if (!d2s) {
+                oidx = (size_t)p * Cout + col;
+            } else {  // DCR: conv channel (i*2 + j)*Cq + c -> pixel (2y+i, 2x+j), channel c
+                int img, y, x;
+                pix_of(p, img, y, x);
+                oidx = (((size_t)img * (2 * H) + (2 * y + (d2_grp >> 1))) * (2 * Wd) + (2 * x + (d2_grp & 1))) * Cq + d2_c;
+            }
+            if (residual) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(residual + oidx);
+                const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFF));
+                    v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
+                }
+            }
+            uint16_t b[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = f32_to_bf16(v[e]);
+            uint4 pk;
+            pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+            pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
+            pk.z = (uint32_t)b[4] | ((uint32_t)b[5] << 16);
+            pk.w = (uint32_t)b[6] | ((uint32_t)b[7] << 16);
+            *reinterpret_cast<uint4*>(Y + oidx) = pk;
+            if (gn_part) {  // statistics of the STORED (bf16-rounded) tensor, like a separate pass over Y would see
+                float q[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = bf16_to_f32(b[e]);
+                gs0 += (q[0] + q[1]) + (q[2] + q[3]);
+                gq0 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
+                gs1 += (q[4] + q[5]) + (q[6] + q[7]);
+                gq1 += (q[4] * q[4] + q[5] * q[5]) + (q[6] * q[6] + q[7] * q[7]);
+            }
         }
-        if (residual) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(residual + oidx);
-            v.x += bf16_to_f32((uint16_t)(rr.x & 0xFFFF)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
-            v.z += bf16_to_f32((uint16_t)(rr.y & 0xFFFF)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
-        }
-        const uint16_t b0 = f32_to_bf16(v.x), b1 = f32_to_bf16(v.y), b2 = f32_to_bf16(v.z), b3 = f32_to_bf16(v.w);
-        uint2 pk;
-        pk.x = (uint32_t)b0 | ((uint32_t)b1 << 16);
-        pk.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
-        *reinterpret_cast<uint2*>(Y + oidx) = pk;
-        if (gn_part) {  // statistics of the STORED (bf16-rounded) tensor, like a separate pass over Y would see
-            const float r0 = bf16_to_f32(b0), r1 = bf16_to_f32(b1), r2 = bf16_to_f32(b2), r3 = bf16_to_f32(b3);
-            gs += (r0 + r1) + (r2 + r3);
-            gq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-        }
+        __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the second half
     }
     if (gn_part) {
-        // ---- fixed-order reduction of the tile's GroupNorm partials: every lane parks (sum, sumsq) behind the transpose
-        // scratch, then one thread per (local group, moment) adds its contributors in (wave row, lane) order.  The tile's 128
-        // columns hold 128 / cpg whole groups (launcher: 128 % cpg == 0; with depth-to-space the 128 columns lie inside one
-        // sub-pixel block, so col - n0 indexes the GroupNorm channel relative to the tile as well).
-        float* ps = reinterpret_cast<float*>(smem + 8 * 64 * 64 * 4);  // [8 waves][64 lanes][2]
-        ps[(wid * 64 + lane) * 2] = gs;
-        ps[(wid * 64 + lane) * 2 + 1] = gq;
+        // ---- fixed-order reduction of the tile's GroupNorm partials: every lane parks its two (sum, sumsq) pairs behind the
+        // transpose slices, then one thread per (local group, moment) adds its contributors in (wave row, row group, channel
+        // quad) order.  The tile's 128 columns hold 128 / cpg whole groups (launcher: 128 % cpg == 0; with depth-to-space the
+        // 128 columns lie inside one sub-pixel block, so col - n0 indexes the GroupNorm channel relative to the tile as well).
+        float* ps = reinterpret_cast<float*>(smem + 8 * 32 * 64 * 4);  // [8 waves][64 lanes][4]
+        *reinterpret_cast<float4*>(ps + (wid * 64 + lane) * 4) = make_float4(gs0, gq0, gs1, gq1);
         __syncthreads();
         const int ngrp = BN / gn_cpg;
         if (tid < ngrp * 2) {
             const int g = tid >> 1, which = tid & 1;
             const int c_lo = g * gn_cpg;                 // first tile column of the group
             const int wn_g = c_lo >> 6;                  // the wave column that owns it
-            const int l_lo = (c_lo & 63) >> 2, l_n = gn_cpg >> 2;  // lanes (lane & 15) in [l_lo, l_lo + l_n)
+            const int q_lo = (c_lo & 63) >> 2, q_n = gn_cpg >> 2;  // channel quads [q_lo, q_lo + q_n): lane & 7 = q >> 1, pair q & 1
             float a = 0.f;
             for (int wmi = 0; wmi < 4; ++wmi)
-                for (int rg = 0; rg < 4; ++rg)
-                    for (int l = 0; l < l_n; ++l)
-                        a += ps[(((wmi * 2 + wn_g) * 64) + rg * 16 + l_lo + l) * 2 + which];
+                for (int rg = 0; rg < 8; ++rg)
+                    for (int q = q_lo; q < q_lo + q_n; ++q)
+                        a += ps[(((wmi * 2 + wn_g) * 64) + rg * 8 + (q >> 1)) * 4 + (q & 1) * 2 + which];
             gn_part[((size_t)m_tile * nt + n_tile) * 64 + tid] = a;
         }
     }
 }
 
-// per-tile (sum, sumsq) partials written by conv3x3_igemm_kernel -> (mean, rstd) per (image, group): tiles added in order (f64)
-__global__ void gn_finalize_tiles_kernel(const float* __restrict__ part, float* __restrict__ stats, int n_img, int groups,
-                                         int tiles_per_img, int nt, int cpg, int Cq, int d2s, float cnt, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- stride-1 form with the three horizontal taps served from ONE LDS slab.
+// A tile of 256 consecutive pixels needs, for a vertical tap dy and a 64-channel chunk, the pixels -1 .. 256 of the row(s) dy
+// away: the taps dx = -1, 0, +1 are the same slab read one LDS row up or down.  So the K loop runs (dy, chunk) slabs of 33 KB
+// (256 pixels + one halo chunk) with three weight stages each, instead of nine 32 KB A tiles per chunk: the LDS-DMA bytes of
+// a 128-column tile drop from 864 KB to 486 KB per 256 x 128 x 1152 tile (the DMA path alone took 0.4 of the kernel's time,
+// tools/gpu_conv_abl.sh).  Rows whose horizontal neighbour lies outside the image get their fragment zeroed in registers.
+//   slab rows: L = 0: pixel -1, L = 1: pixel 256, L = 8 + q: pixel q of the tile; XOR swizzle keyed on L.
+//   BN = 128: 4 x 2 waves of 64 x 64;  BN = 32: 8 x 1 waves of 32 x 32 for the narrow head (conv_out, 3 -> 8 padded columns).
+template <int BN>
+__global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                                              const float* __restrict__ bias,
+                                                              const uint16_t* __restrict__ residual, uint16_t* __restrict__ Y,
+                                                              const uint16_t* __restrict__ zero, int n_img, int H, int Wd, int Cin,
+                                                              int Cout, int flags, float* __restrict__ gn_part, int gn_cpg) {
+    constexpr int BM = 256, BK = 64, ROWB = 128, SPR = 8, RPB = 2;
+    constexpr int TI = BN == 128 ? 2 : 1, TJ = BN == 128 ? 2 : 1;  // 32x32 MFMA tiles per wave
+    constexpr int WCOLS = TJ * 32;                                 // columns of a wave's tile
+    constexpr int SLAB_B = (8 + BM) * ROWB;                        // 33 KB
+    constexpr int WROWS = BN == 128 ? 128 : 64;                    // BN = 32: 64 rows staged so every wave issues one chunk
+    constexpr int W_TILE = WROWS * ROWB, WCH = W_TILE / 1024 / 8;  // 2 / 1 chunks per wave per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm_off = BN == 128 ? (wid >> 1) * 64 : wid * 32, wn_off = BN == 128 ? (wid & 1) * 64 : 0;
+    const int r = lane & 31, h = lane >> 5;
+    const int HW = H * Wd;
+    const int M = n_img * HW;
+    const int K = 9 * Cin;
+    const int mt = (M + BM - 1) / BM, nt = (Cout + BN - 1) / BN;
+    int bid = blockIdx.x, m_tile, n_tile;
+    const int full = (mt / 8) * 8 * nt;
+    if (bid < full) {
+        const int grp = bid / (8 * nt), rem = bid - grp * 8 * nt;
+        m_tile = grp * 8 + (rem & 7);
+        n_tile = rem >> 3;
+    } else {
+        const int rem = bid - full;
+        m_tile = (mt / 8) * 8 + rem / nt;
+        n_tile = rem % nt;
+    }
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
+    const bool pow2 = !(Wd & (Wd - 1)) && !(HW & (HW - 1));
+    const int sh_w = 31 - __builtin_clz(Wd), sh_hw = 31 - __builtin_clz(HW);
+    auto pix_of = [&](int p, int& img, int& y, int& x) {
+        if (pow2) {
+            img = p >> sh_hw;
+            const int in_img = p & (HW - 1);
+            y = in_img >> sh_w;
+            x = in_img & (Wd - 1);
+        } else {
+            img = (int)((unsigned)p / (unsigned)HW);
+            const int in_img = p - img * HW;
+            y = (int)((unsigned)in_img / (unsigned)Wd);
+            x = in_img - y * Wd;
+        }
+    };
+
+    // ---- staging descriptors.  Main slab chunks c = wid + 8*i (i < 4): pixels c*8 .. c*8+7 at L = 8 + pixel; wave 0 also
+    // loads the halo chunk (L = 0: pixel -1, L = 1: pixel 256, L = 2..7 zero).  -1 = no source (zero page).
+    const int c_row = lane >> 3, c_phys = lane & 7;
+    int a_pix[4], a_y[4], a_slot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row_local = (wid + 8 * i) * 8 + c_row;
+        const int L = 8 + row_local;
+        a_slot[i] = c_phys ^ ((L / RPB) % SPR);
+        const int p = m0 + row_local;
+        a_pix[i] = -1; a_y[i] = 0;
+        if (p < M) {
+            int img, x;
+            pix_of(p, img, a_y[i], x);
+            a_pix[i] = p;
+        }
+    }
+    int h_pix = -1, h_y = 0;
+    const int h_slot = c_phys ^ ((c_row / RPB) % SPR);
+    if (wid == 0 && c_row < 2) {
+        const int p = c_row == 0 ? m0 - 1 : m0 + BM;
+        if (p >= 0 && p < M) {
+            int img, x;
+            pix_of(p, img, h_y, x);
+            h_pix = p;
+        }
+    }
+    const uint16_t* w_src[WCH];
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+        const int row_local = (wid + 8 * j) * 8 + c_row;
+        const int slot = c_phys ^ ((row_local / RPB) % SPR);
+        int rw = n0 + row_local;
+        rw = rw < Cout ? rw : Cout - 1;
+        w_src[j] = Wt + (size_t)rw * K + slot * 8;
+    }
+    const int nchunk = Cin / BK, nslab = 3 * nchunk, nk = 3 * nslab;
+    unsigned char* const wbase = smem + 2 * SLAB_B;
+    auto load_slab = [&](int a) {
+        const int dyi = a / nchunk, kc = (a - dyi * nchunk) * BK, dy = dyi - 1;
+        unsigned char* base = smem + (a & 1) * SLAB_B;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = a_y[i] + dy;
+            const bool ok = a_pix[i] >= 0 && yy >= 0 && yy < H;
+            const uint16_t* src = ok ? X + (size_t)(a_pix[i] + dy * Wd) * Cin + kc + a_slot[i] * 8 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + (1 + wid + 8 * i) * 1024), 16, 0,
+                                             0);
+        }
+        if (wid == 0) {
+            const int yy = h_y + dy;
+            const bool ok = h_pix >= 0 && yy >= 0 && yy < H;
+            const uint16_t* src = ok ? X + (size_t)(h_pix + dy * Wd) * Cin + kc + h_slot * 8 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)base, 16, 0, 0);
+        }
+    };
+    auto load_w = [&](int s) {
+        const int a = s / 3, d = s - 3 * a;
+        const int dyi = a / nchunk, kc = (a - dyi * nchunk) * BK;
+        const int k0 = (dyi * 3 + d) * Cin + kc;
+        unsigned char* base = wbase + d * W_TILE;
+#pragma unroll
+        for (int j = 0; j < WCH; ++j)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(w_src[j] + k0),
+                (__attribute__((address_space(3))) void*)(base + (wid + 8 * j) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // fragment addresses: the lane's pixel rows under the three horizontal taps, and whether the neighbour is inside the image
+    int aoff[TI][3], akey[TI][3];
+    bool okL[TI], okR[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int q0 = wm_off + i * 32 + r;
+        int img, y, x;
+        pix_of(m0 + q0, img, y, x);
+        okL[i] = x > 0;
+        okR[i] = x < Wd - 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int q = q0 + d - 1;
+            const int L = q < 0 ? 0 : (q >= BM ? 1 : q + 8);
+            aoff[i][d] = L * ROWB;
+            akey[i][d] = (L / RPB) % SPR;
+        }
+    }
+    int boff[TJ], bkey[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int rowB = wn_off + j * 32 + r;
+        boff[j] = rowB * ROWB;
+        bkey[j] = (rowB / RPB) % SPR;
+    }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    load_slab(0);
+    load_w(0);
+    if (nk > 1) load_w(1);
+    for (int a = 0; a < nslab; ++a) {
+        const unsigned char* sa = smem + (a & 1) * SLAB_B;
+        const bool more = a + 1 < nslab;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int s = 3 * a + d;
+            // outstanding DMAs younger than W(s): W(s+1) and, behind stage d = 0, the next slab (4 chunks, 5 for wave 0)
+            if (s + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (d == 1 && more) {
+                if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 5) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 4) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!(flags & 512)) {
+                if (d == 0 && more) load_slab(a + 1);
+                if (s + 2 < nk) load_w(s + 2);
+            }
+            if (flags & 1024) continue;
+            const unsigned char* sw = wbase + d * W_TILE;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int slot = 2 * kk + h;
+                bf16x8 av[TI], bv[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    av[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i][d] + ((slot ^ akey[i][d]) << 4));
+                    if (d == 0) av[i] = okL[i] ? av[i] : zero8;
+                    if (d == 2) av[i] = okR[i] ? av[i] : zero8;
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(sw + boff[j] + ((slot ^ bkey[j]) << 4));
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue through LDS (as conv3x3_igemm_kernel): 8 consecutive output channels per lane, 16-byte stores
+    __syncthreads();
+    if ((flags & 256) && acc[0][0][0] != 12345.f) return;
+    float* ct = reinterpret_cast<float*>(smem) + wid * (32 * WCOLS);
+    constexpr int LPR = WCOLS / 8, RPI = 64 / LPR;  // lanes per row, rows per iteration
+    const int c8 = (lane % LPR) << 3;
+    const int col = n0 + wn_off + c8;
+    float bvv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bvv[e] = 0.f;
+    if (bias && col < Cout) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+        bvv[0] = b0.x; bvv[1] = b0.y; bvv[2] = b0.z; bvv[3] = b0.w; bvv[4] = b1.x; bvv[5] = b1.y; bvv[6] = b1.z; bvv[7] = b1.w;
+    }
+    const bool d2s = flags & CONV_D2S;
+    const int Cq = Cout >> 2;
+    const int d2_grp = d2s ? col / Cq : 0, d2_c = d2s ? col - d2_grp * Cq : 0;
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ct[((e & 3) + 8 * (e >> 2) + 4 * h) * WCOLS + j * 32 + r] = acc[i][j][e];
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rl = it * RPI + lane / LPR;
+            const int p = m0 + wm_off + i * 32 + rl;
+            const float4 v0 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8);
+            const float4 v1 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8 + 4);
+            if (p >= M || col >= Cout) continue;
+            float v[8] = {v0.x + bvv[0], v0.y + bvv[1], v0.z + bvv[2], v0.w + bvv[3],
+                          v1.x + bvv[4], v1.y + bvv[5], v1.z + bvv[6], v1.w + bvv[7]};
+            size_t oidx;
+            if (!d2s) {
+                oidx = (size_t)p * Cout + col;
+            } else {
+                int img, y, x;
+                pix_of(p, img, y, x);
+                oidx = (((size_t)img * (2 * H) + (2 * y + (d2_grp >> 1))) * (2 * Wd) + (2 * x + (d2_grp & 1))) * Cq + d2_c;
+            }
+            if (residual) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(residual + oidx);
+                const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFF));
+                    v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
+                }
+            }
+            uint16_t b[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = f32_to_bf16(v[e]);
+            uint4 pk;
+            pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+            pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
+            pk.z = (uint32_t)b[4] | ((uint32_t)b[5] << 16);
+            pk.w = (uint32_t)b[6] | ((uint32_t)b[7] << 16);
+            *reinterpret_cast<uint4*>(Y + oidx) = pk;
+            if (BN == 128 && gn_part) {
+                float q[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = bf16_to_f32(b[e]);
+                gs0 += (q[0] + q[1]) + (q[2] + q[3]);
+                gq0 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
+                gs1 += (q[4] + q[5]) + (q[6] + q[7]);
+                gq1 += (q[4] * q[4] + q[5] * q[5]) + (q[6] * q[6] + q[7] * q[7]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (BN == 128 && gn_part) {  // same fixed-order reduction and partial layout as conv3x3_igemm_kernel
+        float* ps = reinterpret_cast<float*>(smem + 8 * 32 * 64 * 4);
+        *reinterpret_cast<float4*>(ps + (wid * 64 + lane) * 4) = make_float4(gs0, gq0, gs1, gq1);
+        __syncthreads();
+        const int ngrp = BN / gn_cpg;
+        if (tid < ngrp * 2) {
+            const int g = tid >> 1, which = tid & 1;
+            const int c_lo = g * gn_cpg;
+            const int wn_g = c_lo >> 6;
+            const int q_lo = (c_lo & 63) >> 2, q_n = gn_cpg >> 2;
+            float a = 0.f;
+            for (int wmi = 0; wmi < 4; ++wmi)
+                for (int rg = 0; rg < 8; ++rg)
+                    for (int q = q_lo; q < q_lo + q_n; ++q)
+                        a += ps[(((wmi * 2 + wn_g) * 64) + rg * 8 + (q >> 1)) * 4 + (q & 1) * 2 + which];
+            gn_part[((size_t)m_tile * nt + n_tile) * 64 + tid] = a;
+        }
+    }
+}
+
+// per-tile (sum, sumsq) partials written by conv3x3_igemm_kernel -> (mean, rstd) per (image, group).  One wave per (image, group):
+// lane l adds tiles l, l + 64, ... (f64), then a butterfly over the 64 lanes -- a fixed order, so the statistics are
+// bit-reproducible; the 256 tiles x 4 sub-pixel blocks of a 256^2 layer were a 1,024-long dependent chain per thread before.
+__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                int n_img, int groups, int tiles_per_img, int nt, int cpg, int Cq,
+                                                                int d2s, float cnt, float eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n_img * groups) return;
     const int img = i / groups, g = i - img * groups;
     double s = 0.0, q = 0.0;
     const int nsub = d2s ? 4 : 1;
-    for (int sub = 0; sub < nsub; ++sub) {
+    for (int f = lane; f < nsub * tiles_per_img; f += 64) {
+        const int sub = f / tiles_per_img, j = f - sub * tiles_per_img;
         const int colb = sub * Cq + g * cpg;  // conv output column of the group's first channel
         const int n_tile = colb >> 7, lg = (colb & 127) / cpg;
-        for (int j = 0; j < tiles_per_img; ++j) {
-            const float* pp = part + ((size_t)(img * tiles_per_img + j) * nt + n_tile) * 64 + lg * 2;
-            s += (double)pp[0];
-            q += (double)pp[1];
-        }
+        const float* pp = part + ((size_t)(img * tiles_per_img + j) * nt + n_tile) * 64 + lg * 2;
+        s += (double)pp[0];
+        q += (double)pp[1];
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    if (lane) return;
     const double mean = s / cnt;
     const double var = fmax(q / cnt - mean * mean, 0.0);
     stats[2 * i] = (float)mean;
@@ -245,11 +597,12 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
                          const uint16_t* zero_page, int n_img, int H, int Wd, int Cin, int Cout, int d2s, hipStream_t st,
                          int stride, float* gn_part, int gn_groups) {
     GENIE_CHECK_SHAPE(stride == 1 || (stride == 2 && !d2s), "conv3x3_igemm: stride %d unsupported", stride);
-    GENIE_CHECK_SHAPE(Cin % 64 == 0 && Cout % 4 == 0, "conv3x3_igemm: C_in %% 64 and C_out %% 4 required (got %d, %d)", Cin,
+    GENIE_CHECK_SHAPE(Cin % 64 == 0 && Cout % 8 == 0, "conv3x3_igemm: C_in %% 64 and C_out %% 8 required (got %d, %d)", Cin,
                       Cout);
-    GENIE_CHECK_SHAPE(!d2s || (Cout % 16 == 0), "conv3x3_igemm: depth-to-space needs C_out %% 16 == 0");
+    GENIE_CHECK_SHAPE(!d2s || (Cout % 32 == 0), "conv3x3_igemm: depth-to-space needs C_out %% 32 == 0");
     const long M = (long)n_img * H * Wd;
     if (M <= 0) return GENIE_OK;
+    GENIE_CHECK_SHAPE(M * stride * stride < (1L << 31) - 4096, "conv3x3_igemm: %ld pixels exceed the 32-bit pixel index", M);
     const int mt = (int)((M + 255) / 256), nt = (Cout + 127) / 128;
     int gn_cpg = 0;
     if (gn_part) {
@@ -259,12 +612,39 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
         if (((long)H * Wd) % 256 || Cout % 128 || gn_cpg % 4 || 128 % gn_cpg || 128 / gn_cpg > 32 || (d2s && Cgn % 128))
             return GENIE_E_UNSUPPORTED;
     }
-    const size_t lds = 3 * 48 * 1024;
     ProfScope prof(GENIE_KC_OTHER, 2.0 * M * Cout * 9.0 * Cin, 2.0 * (M * (double)Cin + M * (double)Cout + 9.0 * Cin * Cout),
                    st);
-    (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    conv3x3_igemm_kernel<<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout,
-                                                    d2s ? CONV_D2S : 0, stride, gn_part, gn_cpg);
+    static const int bk = [] { const char* e = getenv("GENIE_CONV_BK"); return e ? atoi(e) : 64; }();
+    static const int abl = [] { const char* e = getenv("GENIE_CONV_ABL"); return e ? atoi(e) : 0; }();
+    static const int slab = [] { const char* e = getenv("GENIE_CONV_SLAB"); return e ? atoi(e) : 1; }();
+    if (slab && stride == 1) {
+        const int fl = (d2s ? CONV_D2S : 0) | abl;
+        if (Cout <= 32 && !gn_part) {
+            const size_t lds = 2 * 33 * 1024 + 3 * 8 * 1024;
+            const int nt32 = (Cout + 31) / 32;
+            (void)hipFuncSetAttribute((const void*)conv3x3_slab_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            conv3x3_slab_kernel<32><<<mt * nt32, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout, fl,
+                                                                nullptr, 0);
+        } else {
+            const size_t lds = 2 * 33 * 1024 + 3 * 16 * 1024;
+            (void)hipFuncSetAttribute((const void*)conv3x3_slab_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            conv3x3_slab_kernel<128><<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout, fl,
+                                                                gn_part, gn_cpg);
+        }
+        GENIE_LAUNCH_CHECK("conv3x3_slab");
+        return GENIE_OK;
+    }
+    if (bk == 32) {
+        const size_t lds = 3 * 24 * 1024;
+        (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv3x3_igemm_kernel<32, 2><<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout,
+                                                               (d2s ? CONV_D2S : 0) | abl, stride, gn_part, gn_cpg);
+    } else {
+        const size_t lds = 3 * 48 * 1024;
+        (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv3x3_igemm_kernel<64, 1><<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout,
+                                                               (d2s ? CONV_D2S : 0) | abl, stride, gn_part, gn_cpg);
+    }
     GENIE_LAUNCH_CHECK("conv3x3_igemm");
     return GENIE_OK;
 }
@@ -407,7 +787,7 @@ int launch_gn_swish_tiles(const uint16_t* X, const float* gamma, const float* be
     GENIE_CHECK_SHAPE(C % groups == 0 && (C / groups) % 4 == 0 && C % 8 == 0 && ((long)H * Wd) % 256 == 0 && Cout % 128 == 0,
                       "group_norm (fused statistics): geometry unsupported (C=%d, H*W=%d)", C, H * Wd);
     const int cpg = C / groups;
-    gn_finalize_tiles_kernel<<<(n_img * groups + 255) / 256, 256, 0, st>>>(part, stats, n_img, groups, (H * Wd) / 256, Cout / 128, cpg,
+    gn_finalize_tiles_kernel<<<(n_img * groups + 3) / 4, 256, 0, st>>>(part, stats, n_img, groups, (H * Wd) / 256, Cout / 128, cpg,
                                                                            Cout / 4, d2s, (float)HW * cpg, eps);
     GENIE_LAUNCH_CHECK("gn_finalize_tiles");
     const long n_chunks = (long)n_img * HW * (C / 8);

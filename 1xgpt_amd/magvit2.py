@@ -274,7 +274,7 @@ class HipDecoder:
                                 "up": pack(up.upsample.conv1) if i_level > 0 else None})
         self.norm_out = (f32(decoder.norm_out.weight), f32(decoder.norm_out.bias))
         self.c_out = decoder.conv_out.weight.shape[0]
-        self.conv_out = pack(decoder.conv_out, pad_out=(self.c_out + 3) // 4 * 4)
+        self.conv_out = pack(decoder.conv_out, pad_out=(self.c_out + 7) // 8 * 8)
         torch.cuda.synchronize()
 
     # -- weight packing (tap-major bf16 once per model)
@@ -283,7 +283,7 @@ class HipDecoder:
         bsrc = conv.bias
         if pad_in is not None and w.shape[1] < pad_in:   # zero input channels: C_in % 64 == 0 for the implicit GEMM
             w = torch.cat([w, w.new_zeros(w.shape[0], pad_in - w.shape[1], *w.shape[2:])], 1)
-        if pad_out is not None and w.shape[0] < pad_out:  # zero output channels: C_out % 4 == 0
+        if pad_out is not None and w.shape[0] < pad_out:  # zero output channels: C_out % 8 == 0
             w = torch.cat([w, w.new_zeros(pad_out - w.shape[0], *w.shape[1:])], 0)
             if bsrc is not None:
                 bsrc = torch.cat([bsrc.detach().float(), bsrc.new_zeros(pad_out - bsrc.shape[0]).float()])

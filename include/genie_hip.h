@@ -281,7 +281,7 @@ int genie_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bits
 
 /* ---- MAGVIT2 decoder convolutions (improved_model.py:12-51, 124-237), activations NHWC bf16, f32 accumulate ------
  * genie_pack_conv_weight: (C_out, C_in, kh*kw) f32 torch layout -> (C_out, kh*kw, C_in) bf16 (tap-major K).
- * genie_conv3x3_bf16: 3x3 / pad 1 / stride 1 implicit GEMM on the bf16 matrix cores; C_in %% 64 == 0, C_out %% 4 == 0;
+ * genie_conv3x3_bf16: 3x3 / pad 1 / stride 1 implicit GEMM on the bf16 matrix cores; C_in %% 64 == 0, C_out %% 8 == 0 (%% 32 with depth-to-space);
  *   residual (same shape as the output) is added before the bf16 store (ResBlock skip); depth_to_space != 0 writes
  *   the Upsampler's DCR-permuted (n, 2H, 2W, C_out/4) image; zero_page: >= 16 zero bytes for out-of-image taps.
  * genie_conv1x1_bf16: the 1x1 nin_shortcut (a plain Linear over pixels).
