@@ -284,6 +284,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
     constexpr int SLAB_B = (8 + BM) * ROWB;                        // 33 KB
     constexpr int WROWS = BN == 128 ? 128 : 64;                    // BN = 32: 64 rows staged so every wave issues one chunk
     constexpr int W_TILE = WROWS * ROWB, WCH = W_TILE / 1024 / 8;  // 2 / 1 chunks per wave per stage
+    constexpr int CT_OFF = 2 * SLAB_B + 3 * W_TILE;                // epilogue scratch behind the rings: 8 waves x 16 rows
+    constexpr int PS_OFF = CT_OFF + 8 * 16 * WCOLS * 4;            // GroupNorm partials [8 waves][64 lanes][4]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,19 +295,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
     const int M = n_img * HW;
     const int K = 9 * Cin;
     const int mt = (M + BM - 1) / BM, nt = (Cout + BN - 1) / BN;
-    int bid = blockIdx.x, m_tile, n_tile;
+    const int ntiles = mt * nt;
     const int full = (mt / 8) * 8 * nt;
-    if (bid < full) {
-        const int grp = bid / (8 * nt), rem = bid - grp * 8 * nt;
-        m_tile = grp * 8 + (rem & 7);
-        n_tile = rem >> 3;
-    } else {
-        const int rem = bid - full;
-        m_tile = (mt / 8) * 8 + rem / nt;
-        n_tile = rem % nt;
-    }
-    const int m0 = m_tile * BM;
-    const int n0 = n_tile * BN;
+    auto tile_of = [&](int bid, int& m_tile, int& n_tile) {  // 8 consecutive row tiles (one per XCD) share a column tile
+        if (bid < full) {
+            const int grp = bid / (8 * nt), rem = bid - grp * 8 * nt;
+            m_tile = grp * 8 + (rem & 7);
+            n_tile = rem >> 3;
+        } else {
+            const int rem = bid - full;
+            m_tile = (mt / 8) * 8 + rem / nt;
+            n_tile = rem % nt;
+        }
+    };
     const bool pow2 = !(Wd & (Wd - 1)) && !(HW & (HW - 1));
     const int sh_w = 31 - __builtin_clz(Wd), sh_hw = 31 - __builtin_clz(HW);
     auto pix_of = [&](int p, int& img, int& y, int& x) {
@@ -322,42 +324,44 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
         }
     };
 
-    // ---- staging descriptors.  Main slab chunks c = wid + 8*i (i < 4): pixels c*8 .. c*8+7 at L = 8 + pixel; wave 0 also
-    // loads the halo chunk (L = 0: pixel -1, L = 1: pixel 256, L = 2..7 zero).  -1 = no source (zero page).
+    // ---- staging descriptors of a tile.  Main slab chunks c = wid + 8*i (i < 4): pixels c*8 .. c*8+7 at L = 8 + pixel; wave 0
+    // also loads the halo chunk (L = 0: pixel -1, L = 1: pixel 256, L = 2..7 zero).  pix = -1: no source (zero page).
     const int c_row = lane >> 3, c_phys = lane & 7;
     int a_pix[4], a_y[4], a_slot[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row_local = (wid + 8 * i) * 8 + c_row;
-        const int L = 8 + row_local;
-        a_slot[i] = c_phys ^ ((L / RPB) % SPR);
-        const int p = m0 + row_local;
-        a_pix[i] = -1; a_y[i] = 0;
-        if (p < M) {
-            int img, x;
-            pix_of(p, img, a_y[i], x);
-            a_pix[i] = p;
-        }
-    }
+    for (int i = 0; i < 4; ++i) a_slot[i] = c_phys ^ (((8 + (wid + 8 * i) * 8 + c_row) / RPB) % SPR);
     int h_pix = -1, h_y = 0;
     const int h_slot = c_phys ^ ((c_row / RPB) % SPR);
-    if (wid == 0 && c_row < 2) {
-        const int p = c_row == 0 ? m0 - 1 : m0 + BM;
-        if (p >= 0 && p < M) {
-            int img, x;
-            pix_of(p, img, h_y, x);
-            h_pix = p;
-        }
-    }
     const uint16_t* w_src[WCH];
+    auto setup_loads = [&](int m0, int n0) {
 #pragma unroll
-    for (int j = 0; j < WCH; ++j) {
-        const int row_local = (wid + 8 * j) * 8 + c_row;
-        const int slot = c_phys ^ ((row_local / RPB) % SPR);
-        int rw = n0 + row_local;
-        rw = rw < Cout ? rw : Cout - 1;
-        w_src[j] = Wt + (size_t)rw * K + slot * 8;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int p = m0 + (wid + 8 * i) * 8 + c_row;
+            a_pix[i] = -1; a_y[i] = 0;
+            if (p < M) {
+                int img, x;
+                pix_of(p, img, a_y[i], x);
+                a_pix[i] = p;
+            }
+        }
+        h_pix = -1; h_y = 0;
+        if (wid == 0 && c_row < 2) {
+            const int p = c_row == 0 ? m0 - 1 : m0 + BM;
+            if (p >= 0 && p < M) {
+                int img, x;
+                pix_of(p, img, h_y, x);
+                h_pix = p;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {
+            const int row_local = (wid + 8 * j) * 8 + c_row;
+            const int slot = c_phys ^ ((row_local / RPB) % SPR);
+            int rw = n0 + row_local;
+            rw = rw < Cout ? rw : Cout - 1;
+            w_src[j] = Wt + (size_t)rw * K + slot * 8;
+        }
+    };
     const int nchunk = Cin / BK, nslab = 3 * nchunk, nk = 3 * nslab;
     unsigned char* const wbase = smem + 2 * SLAB_B;
     auto load_slab = [&](int a) {
@@ -392,31 +396,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
                 (__attribute__((address_space(3))) void*)(base + (wid + 8 * j) * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[TI][TJ];
+    // fragment addresses (the same for every tile): the lane's pixel rows under the three horizontal taps
+    int aoff[TI][3], akey[TI][3];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // fragment addresses: the lane's pixel rows under the three horizontal taps, and whether the neighbour is inside the image
-    int aoff[TI][3], akey[TI][3];
-    bool okL[TI], okR[TI];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int q0 = wm_off + i * 32 + r;
-        int img, y, x;
-        pix_of(m0 + q0, img, y, x);
-        okL[i] = x > 0;
-        okR[i] = x < Wd - 1;
-#pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int q = q0 + d - 1;
+            const int q = wm_off + i * 32 + r + d - 1;
             const int L = q < 0 ? 0 : (q >= BM ? 1 : q + 8);
             aoff[i][d] = L * ROWB;
             akey[i][d] = (L / RPB) % SPR;
         }
-    }
     int boff[TJ], bkey[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -425,137 +415,179 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
         bkey[j] = (rowB / RPB) % SPR;
     }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool d2s = flags & CONV_D2S;
+    const int Cq = Cout >> 2;
+    constexpr int LPR = WCOLS / 8, RPI = 64 / LPR;  // epilogue: lanes per row, rows per iteration
+    const int c8 = (lane % LPR) << 3;
+    float* const ct = reinterpret_cast<float*>(smem + CT_OFF) + wid * (16 * WCOLS);
 
+    // ---- persistent: workgroup b walks tiles b, b + grid, ...; the next tile's first slab and weight stages are requested
+    // before the epilogue, whose stores then drain under the next tile's main loop
+    int tile = blockIdx.x, m_tile, n_tile;
+    tile_of(tile, m_tile, n_tile);
+    setup_loads(m_tile * BM, n_tile * BN);
     load_slab(0);
     load_w(0);
     if (nk > 1) load_w(1);
-    for (int a = 0; a < nslab; ++a) {
-        const unsigned char* sa = smem + (a & 1) * SLAB_B;
-        const bool more = a + 1 < nslab;
+    for (;;) {
+        const int m0 = m_tile * BM, n0 = n_tile * BN;
+        const int cur_m_tile = m_tile, cur_n_tile = n_tile;
+        bool okL[TI], okR[TI];  // is the horizontal neighbour inside the image?
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int s = 3 * a + d;
-            // outstanding DMAs younger than W(s): W(s+1) and, behind stage d = 0, the next slab (4 chunks, 5 for wave 0)
-            if (s + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (d == 1 && more) {
-                if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 5) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 4) : "memory");
-            } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH) : "memory");
-            __builtin_amdgcn_s_barrier();
-            if (!(flags & 512)) {
-                if (d == 0 && more) load_slab(a + 1);
-                if (s + 2 < nk) load_w(s + 2);
-            }
-            if (flags & 1024) continue;
-            const unsigned char* sw = wbase + d * W_TILE;
+        for (int i = 0; i < TI; ++i) {
+            int img, y, x;
+            pix_of(m0 + wm_off + i * 32 + r, img, y, x);
+            okL[i] = x > 0;
+            okR[i] = x < Wd - 1;
+        }
+        f32x16 acc[TI][TJ];
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                const int slot = 2 * kk + h;
-                bf16x8 av[TI], bv[TJ];
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    av[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i][d] + ((slot ^ akey[i][d]) << 4));
-                    if (d == 0) av[i] = okL[i] ? av[i] : zero8;
-                    if (d == 2) av[i] = okR[i] ? av[i] : zero8;
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int a = 0; a < nslab; ++a) {
+            const unsigned char* sa = smem + (a & 1) * SLAB_B;
+            const bool more = a + 1 < nslab;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int s = 3 * a + d;
+                // outstanding DMAs younger than W(s): W(s+1) and, behind stage d = 0, the next slab (4 chunks, 5 for wave 0);
+                // the first stage of a tile also waits for the previous tile's epilogue stores
+                if (s + 1 >= nk || s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (d == 1 && more) {
+                    if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 5) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 4) : "memory");
+                } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH) : "memory");
+                __builtin_amdgcn_s_barrier();
+                if (!(flags & 512)) {
+                    if (d == 0 && more) load_slab(a + 1);
+                    if (s + 2 < nk) load_w(s + 2);
                 }
+                if (flags & 1024) continue;
+                const unsigned char* sw = wbase + d * W_TILE;
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(sw + boff[j] + ((slot ^ bkey[j]) << 4));
+                for (int kk = 0; kk < BK / 16; ++kk) {
+                    const int slot = 2 * kk + h;
+                    bf16x8 av[TI], bv[TJ];
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
+                    for (int i = 0; i < TI; ++i) {
+                        av[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i][d] + ((slot ^ akey[i][d]) << 4));
+                        if (d == 0) av[i] = okL[i] ? av[i] : zero8;
+                        if (d == 2) av[i] = okR[i] ? av[i] : zero8;
+                    }
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-    // ---- epilogue through LDS (as conv3x3_igemm_kernel): 8 consecutive output channels per lane, 16-byte stores
-    __syncthreads();
-    if ((flags & 256) && acc[0][0][0] != 12345.f) return;
-    float* ct = reinterpret_cast<float*>(smem) + wid * (32 * WCOLS);
-    constexpr int LPR = WCOLS / 8, RPI = 64 / LPR;  // lanes per row, rows per iteration
-    const int c8 = (lane % LPR) << 3;
-    const int col = n0 + wn_off + c8;
-    float bvv[8];
+                        bv[j] = *reinterpret_cast<const bf16x8*>(sw + boff[j] + ((slot ^ bkey[j]) << 4));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bvv[e] = 0.f;
-    if (bias && col < Cout) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
-        bvv[0] = b0.x; bvv[1] = b0.y; bvv[2] = b0.z; bvv[3] = b0.w; bvv[4] = b1.x; bvv[5] = b1.y; bvv[6] = b1.z; bvv[7] = b1.w;
-    }
-    const bool d2s = flags & CONV_D2S;
-    const int Cq = Cout >> 2;
-    const int d2_grp = d2s ? col / Cq : 0, d2_c = d2s ? col - d2_grp * Cq : 0;
-    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+                    for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) ct[((e & 3) + 8 * (e >> 2) + 4 * h) * WCOLS + j * 32 + r] = acc[i][j][e];
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int rl = it * RPI + lane / LPR;
-            const int p = m0 + wm_off + i * 32 + rl;
-            const float4 v0 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8);
-            const float4 v1 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8 + 4);
-            if (p >= M || col >= Cout) continue;
-            float v[8] = {v0.x + bvv[0], v0.y + bvv[1], v0.z + bvv[2], v0.w + bvv[3],
-                          v1.x + bvv[4], v1.y + bvv[5], v1.z + bvv[6], v1.w + bvv[7]};
-            size_t oidx;
-            if (!d2s) {
-                oidx = (size_t)p * Cout + col;
-            } else {
-                int img, y, x;
-                pix_of(p, img, y, x);
-                oidx = (((size_t)img * (2 * H) + (2 * y + (d2_grp >> 1))) * (2 * Wd) + (2 * x + (d2_grp & 1))) * Cq + d2_c;
-            }
-            if (residual) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(residual + oidx);
-                const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFF));
-                    v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
+                        for (int j = 0; j < TJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
                 }
             }
-            uint16_t b[8];
+        }
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        __syncthreads();  // every wave is done with this tile's slabs and weight stages
+        if (has_next) {
+            tile_of(next, m_tile, n_tile);
+            setup_loads(m_tile * BM, n_tile * BN);
+            load_slab(0);
+            load_w(0);
+            if (nk > 1) load_w(1);
+        }
+        // ---- epilogue through LDS: each wave transposes its tile 16 rows at a time through a 4 KB slice; 8 consecutive output
+        // channels per lane, 16-byte stores
+        if (!((flags & 256) && acc[0][0][0] != 12345.f)) {
+            const int col = n0 + wn_off + c8;
+            float bvv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b[e] = f32_to_bf16(v[e]);
-            uint4 pk;
-            pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
-            pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
-            pk.z = (uint32_t)b[4] | ((uint32_t)b[5] << 16);
-            pk.w = (uint32_t)b[6] | ((uint32_t)b[7] << 16);
-            *reinterpret_cast<uint4*>(Y + oidx) = pk;
-            if (BN == 128 && gn_part) {
-                float q[8];
+            for (int e = 0; e < 8; ++e) bvv[e] = 0.f;
+            if (bias && col < Cout) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+                bvv[0] = b0.x; bvv[1] = b0.y; bvv[2] = b0.z; bvv[3] = b0.w; bvv[4] = b1.x; bvv[5] = b1.y; bvv[6] = b1.z; bvv[7] = b1.w;
+            }
+            const int d2_grp = d2s ? col / Cq : 0, d2_c = d2s ? col - d2_grp * Cq : 0;
+            float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) q[e] = bf16_to_f32(b[e]);
-                gs0 += (q[0] + q[1]) + (q[2] + q[3]);
-                gq0 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
-                gs1 += (q[4] + q[5]) + (q[6] + q[7]);
-                gq1 += (q[4] * q[4] + q[5] * q[5]) + (q[6] * q[6] + q[7] * q[7]);
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int eh = 0; eh < 2; ++eh) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            ct[((e & 3) + 8 * (e >> 2) + 4 * h) * WCOLS + j * 32 + r] = acc[i][j][eh * 8 + e];
+#pragma unroll
+                    for (int it = 0; it < 16 / RPI; ++it) {
+                        const int rl = it * RPI + lane / LPR;
+                        const int p = m0 + wm_off + i * 32 + eh * 16 + rl;
+                        const float4 v0 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8);
+                        const float4 v1 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8 + 4);
+                        if (p >= M || col >= Cout) continue;
+                        float v[8] = {v0.x + bvv[0], v0.y + bvv[1], v0.z + bvv[2], v0.w + bvv[3],
+                                      v1.x + bvv[4], v1.y + bvv[5], v1.z + bvv[6], v1.w + bvv[7]};
+                        size_t oidx;
+                        if (!d2s) {
+                            oidx = (size_t)p * Cout + col;
+                        } else {  // DCR: conv channel (i*2 + j)*Cq + c -> pixel (2y+i, 2x+j), channel c
+                            int img, y, x;
+                            pix_of(p, img, y, x);
+                            oidx = (((size_t)img * (2 * H) + (2 * y + (d2_grp >> 1))) * (2 * Wd) + (2 * x + (d2_grp & 1))) * Cq + d2_c;
+                        }
+                        if (residual) {
+                            const uint4 rr = *reinterpret_cast<const uint4*>(residual + oidx);
+                            const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFF));
+                                v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
+                            }
+                        }
+                        uint16_t b[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b[e] = f32_to_bf16(v[e]);
+                        uint4 pk;
+                        pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+                        pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
+                        pk.z = (uint32_t)b[4] | ((uint32_t)b[5] << 16);
+                        pk.w = (uint32_t)b[6] | ((uint32_t)b[7] << 16);
+                        *reinterpret_cast<uint4*>(Y + oidx) = pk;
+                        if (BN == 128 && gn_part) {  // statistics of the STORED (bf16-rounded) tensor
+                            float q[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) q[e] = bf16_to_f32(b[e]);
+                            gs0 += (q[0] + q[1]) + (q[2] + q[3]);
+                            gq0 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
+                            gs1 += (q[4] + q[5]) + (q[6] + q[7]);
+                            gq1 += (q[4] * q[4] + q[5] * q[5]) + (q[6] * q[6] + q[7] * q[7]);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next 16 rows
+                }
+            if (BN == 128 && gn_part) {  // same fixed-order reduction and partial layout as conv3x3_igemm_kernel
+                float* ps = reinterpret_cast<float*>(smem + PS_OFF);
+                *reinterpret_cast<float4*>(ps + (wid * 64 + lane) * 4) = make_float4(gs0, gq0, gs1, gq1);
+                __syncthreads();
+                const int ngrp = BN / gn_cpg;
+                if (tid < ngrp * 2) {
+                    const int g = tid >> 1, which = tid & 1;
+                    const int c_lo = g * gn_cpg;
+                    const int wn_g = c_lo >> 6;
+                    const int q_lo = (c_lo & 63) >> 2, q_n = gn_cpg >> 2;
+                    float a = 0.f;
+                    for (int wmi = 0; wmi < 4; ++wmi)
+                        for (int rg = 0; rg < 8; ++rg)
+                            for (int q = q_lo; q < q_lo + q_n; ++q)
+                                a += ps[(((wmi * 2 + wn_g) * 64) + rg * 8 + (q >> 1)) * 4 + (q & 1) * 2 + which];
+                    gn_part[((size_t)cur_m_tile * nt + cur_n_tile) * 64 + tid] = a;
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (BN == 128 && gn_part) {  // same fixed-order reduction and partial layout as conv3x3_igemm_kernel
-        float* ps = reinterpret_cast<float*>(smem + 8 * 32 * 64 * 4);
-        *reinterpret_cast<float4*>(ps + (wid * 64 + lane) * 4) = make_float4(gs0, gq0, gs1, gq1);
-        __syncthreads();
-        const int ngrp = BN / gn_cpg;
-        if (tid < ngrp * 2) {
-            const int g = tid >> 1, which = tid & 1;
-            const int c_lo = g * gn_cpg;
-            const int wn_g = c_lo >> 6;
-            const int q_lo = (c_lo & 63) >> 2, q_n = gn_cpg >> 2;
-            float a = 0.f;
-            for (int wmi = 0; wmi < 4; ++wmi)
-                for (int rg = 0; rg < 8; ++rg)
-                    for (int q = q_lo; q < q_lo + q_n; ++q)
-                        a += ps[(((wmi * 2 + wn_g) * 64) + rg * 8 + (q >> 1)) * 4 + (q & 1) * 2 + which];
-            gn_part[((size_t)m_tile * nt + n_tile) * 64 + tid] = a;
-        }
+        if (!has_next) break;
+        tile = next;
     }
 }
 
@@ -619,17 +651,26 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
     static const int slab = [] { const char* e = getenv("GENIE_CONV_SLAB"); return e ? atoi(e) : 1; }();
     if (slab && stride == 1) {
         const int fl = (d2s ? CONV_D2S : 0) | abl;
+        static const int n_cu = [] {
+            int dev = 0, n = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            const char* e = getenv("GENIE_CONV_PERSIST");  // 0: one workgroup per tile (A/B runs)
+            if (e && !atoi(e)) return 1 << 30;
+            return n > 0 ? n : 256;
+        }();
         if (Cout <= 32 && !gn_part) {
-            const size_t lds = 2 * 33 * 1024 + 3 * 8 * 1024;
-            const int nt32 = (Cout + 31) / 32;
+            const size_t lds = 2 * 33 * 1024 + 3 * 8 * 1024 + 8 * 16 * 32 * 4;
+            const int tiles = mt * ((Cout + 31) / 32);
             (void)hipFuncSetAttribute((const void*)conv3x3_slab_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            conv3x3_slab_kernel<32><<<mt * nt32, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout, fl,
-                                                                nullptr, 0);
+            conv3x3_slab_kernel<32><<<tiles < n_cu ? tiles : n_cu, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd,
+                                                                                  Cin, Cout, fl, nullptr, 0);
         } else {
-            const size_t lds = 2 * 33 * 1024 + 3 * 16 * 1024;
+            const size_t lds = 2 * 33 * 1024 + 3 * 16 * 1024 + 8 * 16 * 64 * 4 + 8 * 64 * 4 * 4;
+            const int tiles = mt * nt;
             (void)hipFuncSetAttribute((const void*)conv3x3_slab_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            conv3x3_slab_kernel<128><<<mt * nt, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd, Cin, Cout, fl,
-                                                                gn_part, gn_cpg);
+            conv3x3_slab_kernel<128><<<tiles < n_cu ? tiles : n_cu, 512, lds, st>>>(X, Wt, bias, residual, Y, zero_page, n_img, H, Wd,
+                                                                                   Cin, Cout, fl, gn_part, gn_cpg);
         }
         GENIE_LAUNCH_CHECK("conv3x3_slab");
         return GENIE_OK;
