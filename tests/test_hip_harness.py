@@ -189,3 +189,40 @@ def test_conv_fused_groupnorm_statistics(n, H, W, cin, cout, d2s, stride):
                                          cout, int(d2s), stride, part2.data_ptr(), 32, st), "conv_gn")
     used = part.view(-1, 64)[:, : 2 * (128 // (C // 32))]
     assert torch.equal(used, part2.view(-1, 64)[:, : 2 * (128 // (C // 32))])
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,d2s,res", [(3, 24, 40, 64, 128, False, True),    # non power-of-two sides, ragged last tile
+                                                    (2, 16, 16, 128, 8, False, False),    # narrow head (32-column form)
+                                                    (1, 20, 12, 64, 256, True, False),    # depth-to-space, non power-of-two
+                                                    (2, 8, 512, 64, 128, False, True),    # rows wider than a 256-pixel tile (halo pixels used)
+                                                    (5, 16, 16, 192, 384, False, False)])  # 3 channel chunks, 3 column tiles
+def test_conv3x3_slab_against_f64(n, H, W, cin, cout, d2s, res):
+    """genie_conv3x3_bf16 (stride 1: one LDS slab per vertical tap serving the three horizontal taps, persistent tiles) against
+    torch conv2d in f64 on the same bf16 operands (improved_model.py: Conv2d(k=3, padding=1); Upsampler's depth-to-space
+    :185-237): borders, image seams inside a tile, ragged tiles, narrow heads."""
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(n * 100 + cout + W)
+    x = torch.randn(n, H, W, cin, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3 * cin ** 0.5)).contiguous()
+    b = torch.randn(cout, device="cuda", generator=g)
+    wp = torch.empty(cout, 9, cin, dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.genie_pack_conv_weight(w.data_ptr(), wp.data_ptr(), cout, cin, 9, st), "pack")
+    zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    C = cout // 4 if d2s else cout
+    oshape = (n, 2 * H, 2 * W, C) if d2s else (n, H, W, C)
+    r = torch.randn(oshape, device="cuda", generator=g).to(torch.bfloat16) if res else None
+    y = torch.full(oshape, float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_conv3x3_bf16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), 0 if r is None else r.data_ptr(), y.data_ptr(),
+                                      zero.data_ptr(), n, H, W, cin, cout, int(d2s), st), "conv")
+    wq = wp.view(cout, 3, 3, cin).permute(0, 3, 1, 2).double()            # the packed (bf16-rounded) weights
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wq, b.double(), padding=1)
+    if d2s:  # DCR depth-to-space: channel (i*2 + j)*C + c -> pixel (2y+i, 2x+j)
+        ref = ref.view(n, 2, 2, C, H, W).permute(0, 3, 4, 1, 5, 2).reshape(n, C, 2 * H, 2 * W)
+    ref = ref.permute(0, 2, 3, 1)
+    if r is not None:
+        ref = ref + r.double()
+    err = (y.double() - ref).abs()
+    assert torch.isfinite(y.float()).all()
+    assert (err <= 2.0 ** -7 * ref.abs() + 2e-3).all(), err.max().item()
