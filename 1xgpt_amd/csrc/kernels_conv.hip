@@ -786,6 +786,65 @@ __global__ void gn_swish_kernel(const uint16_t* __restrict__ X, const float* __r
     *reinterpret_cast<uint4*>(Y + idx * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// The same pass with the per-channel and per-group constants hoisted: a block covers a run of pixels of ONE image, thread t owns
+// the fixed 8-channel slice t % (C/8) and walks the pixels t / (C/8), + 256/(C/8), ...  (the kernel above spends most of its
+// instructions on 64-bit index divisions and a full-precision division per element: 3.8 TB/s; this one is a plain stream).
+__global__ __launch_bounds__(256) void gn_swish_rows_kernel(const uint16_t* __restrict__ X, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            uint16_t* __restrict__ Y, int HW, int C, int groups, int ppb,
+                                                            int apply_swish) {
+    const int c8 = C >> 3, cpg = C / groups;
+    const int chunk = threadIdx.x % c8, prow = threadIdx.x / c8, pstep = 256 / c8;
+    const int img = blockIdx.y;
+    const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, HW);
+    const int c0 = chunk * 8;
+    const float* st0 = stats + ((size_t)img * groups + c0 / cpg) * 2;
+    const float* st1 = stats + ((size_t)img * groups + (c0 + 4) / cpg) * 2;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c0), gb = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    const float4 ba = *reinterpret_cast<const float4*>(beta + c0), bb = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    // y = (x - m) * r * g + b  ==  x * sc + sh is NOT used: the product order of the kernel above is kept
+    const float mean[2] = {st0[0], st1[0]}, rstd[2] = {st0[1], st1[1]};
+    const float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    const float be[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+    const size_t base = ((size_t)img * HW) * C + c0;
+#pragma unroll 2
+    for (int p = p0 + prow; p < p1; p += pstep) {
+        const uint4 v = *reinterpret_cast<const uint4*>(X + base + (size_t)p * C);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r2[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int j = 2 * k + hh;
+                const float x = __uint_as_float(hh ? (w[k] & 0xFFFF0000u) : (w[k] << 16));
+                float y = (x - mean[j >> 2]) * rstd[j >> 2] * gg[j] + be[j];
+                if (apply_swish) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                r2[hh] = y;
+            }
+            o[k] = (uint32_t)f32_to_bf16(r2[0]) | ((uint32_t)f32_to_bf16(r2[1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(Y + base + (size_t)p * C) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+static int launch_gn_apply(const uint16_t* X, const float* stats, const float* gamma, const float* beta, uint16_t* Y, int n_img,
+                           int HW, int C, int groups, int apply_swish, hipStream_t st) {
+    const int c8 = C / 8;
+    static const int rows = [] { const char* e = getenv("GENIE_GN_ROWS"); return e ? atoi(e) : 1; }();
+    if (rows && c8 <= 256 && 256 % c8 == 0) {
+        const int ppb = 8 * (256 / c8);
+        gn_swish_rows_kernel<<<dim3((HW + ppb - 1) / ppb, n_img), 256, 0, st>>>(X, stats, gamma, beta, Y, HW, C, groups, ppb,
+                                                                               apply_swish);
+    } else {
+        const long n_chunks = (long)n_img * HW * c8;
+        gn_swish_kernel<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>(X, stats, gamma, beta, Y, n_chunks, HW, C, groups,
+                                                                            apply_swish);
+    }
+    GENIE_LAUNCH_CHECK("gn_swish");
+    return GENIE_OK;
+}
+
 // floats of scratch genie_group_norm_swish_bf16 needs: final (mean, rstd) + the per-block partials
 size_t gn_scratch_floats(int n_img, int HW, int groups) {
     const int ppb = HW >= 16384 ? 512 : (HW >= 1024 ? 128 : (HW >= 64 ? 64 : HW));
@@ -806,11 +865,7 @@ int launch_gn_swish(const uint16_t* X, const float* gamma, const float* beta, ui
     gn_finalize_kernel<<<(n_img * groups + 255) / 256, 256, 0, st>>>(part, stats, n_img * groups, groups, nblk,
                                                                       (float)HW * (C / groups), eps);
     GENIE_LAUNCH_CHECK("gn_finalize");
-    const long n_chunks = (long)n_img * HW * (C / 8);
-    gn_swish_kernel<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>(X, stats, gamma, beta, Y, n_chunks, HW, C, groups,
-                                                                        apply_swish);
-    GENIE_LAUNCH_CHECK("gn_swish");
-    return GENIE_OK;
+    return launch_gn_apply(X, stats, gamma, beta, Y, n_img, HW, C, groups, apply_swish, st);
 }
 
 // floats of `gn_part` a conv launch with fused statistics writes: 64 per 256x128 tile
@@ -831,11 +886,7 @@ int launch_gn_swish_tiles(const uint16_t* X, const float* gamma, const float* be
     gn_finalize_tiles_kernel<<<(n_img * groups + 3) / 4, 256, 0, st>>>(part, stats, n_img, groups, (H * Wd) / 256, Cout / 128, cpg,
                                                                            Cout / 4, d2s, (float)HW * cpg, eps);
     GENIE_LAUNCH_CHECK("gn_finalize_tiles");
-    const long n_chunks = (long)n_img * HW * (C / 8);
-    gn_swish_kernel<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>(X, stats, gamma, beta, Y, n_chunks, HW, C, groups,
-                                                                        apply_swish);
-    GENIE_LAUNCH_CHECK("gn_swish");
-    return GENIE_OK;
+    return launch_gn_apply(X, stats, gamma, beta, Y, n_img, HW, C, groups, apply_swish, st);
 }
 
 // ---- direct 3x3 / pad 1 convolution for the edge layers: X NHWC bf16, Wt (Cout, 3, 3, Cin) bf16, f32 accumulate.
