@@ -150,6 +150,12 @@ int launch_sumsq(const float* x, size_t n, double* out, double* scratch, hipStre
 int launch_cast_transpose16(int npl, float* in, long ld, const float* z, uint16_t* out16, uint16_t* out16T, int rows,
                             int cols, hipStream_t st, float* colpart = nullptr);
 int launch_transpose16(int npl, const uint16_t* in, uint16_t* outT, int rows, int cols, hipStream_t st);
+// bf16 copy in the same orientation (+ gelu'(z)) and the [rows/64][cols] column-sum partials; no transposed copy
+int launch_cast_rows16(const float* in, long ld, const float* z, uint16_t* out16, int rows, int cols, hipStream_t st,
+                       float* colpart);
+// dW[N,K] (beta*dW +)= alpha * dY^T . X from ROW-MAJOR bf16 dY (Mtok, N) and X (Mtok, K) (kernels_gemm_tn.hip)
+int launch_wgrad16_tn(const uint16_t* dY, long ldy, const uint16_t* X, long ldx, float* dW, int Mtok, int N, int K, float alpha,
+                      float beta, float* slabs, size_t slab_floats, hipStream_t st);
 int launch_cast16(int npl, const float* src, uint16_t* dst, size_t n, hipStream_t st);
 enum { G16X_GELU = 1, G16X_ACCUM = 2, G16X_OUT16 = 4, G16X_OUTF32 = 8, G16X_GELU16 = 16, G16X_NT = 32,
        G16X_QKV = 64 /* gemm16_pp only: the spatial-attention operand layout, see launch_gemm16_pp */ };  // = the G16_* flags of kernels_bf16.hip

@@ -64,6 +64,61 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(float* __restrict__
     }
 }
 
+// in (rows, cols) f32 -> bf16 copy in the SAME orientation (times gelu'(z) in MODE 1) and, per 64-row block, the column sums
+// (bias gradient partials, same [rows/64][cols] layout as cast_transpose_kernel): the dY operand of launch_wgrad16_tn, which
+// needs no transposed copy.  Thread = 8 consecutive columns (two 16-byte loads, one 16-byte store) of 8 rows.
+template <int MODE>
+__global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __restrict__ in, long ld, const float* __restrict__ z,
+                                                               uint16_t* __restrict__ out16, int cols,
+                                                               float* __restrict__ colpart) {
+    __shared__ float csum[8][256];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 256;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 8; ++i) {
+        const size_t src = (size_t)(r0 + ty + 8 * i) * ld + c0 + tx * 8;
+        const float4 a = *reinterpret_cast<const float4*>(in + src), b = *reinterpret_cast<const float4*>(in + src + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if constexpr (MODE == 1) {
+            const float4 za = *reinterpret_cast<const float4*>(z + src), zb = *reinterpret_cast<const float4*>(z + src + 4);
+            const float zz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad16(zz[e]);
+        }
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cs[2 * e] += v[2 * e];
+            cs[2 * e + 1] += v[2 * e + 1];
+            pk[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(out16 + (size_t)(r0 + ty + 8 * i) * cols + c0 + tx * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    if (!colpart) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[ty][tx * 8 + e] = cs[e];
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a += csum[t][threadIdx.x];
+    colpart[(size_t)blockIdx.y * cols + c0 + threadIdx.x] = a;
+}
+// GENIE_E_UNSUPPORTED unless rows % 64 == 0, cols % 256 == 0, ld % 4 == 0
+int launch_cast_rows16(const float* in, long ld, const float* z, uint16_t* out16, int rows, int cols, hipStream_t st,
+                       float* colpart) {
+    if (rows % 64 || cols % 256 || ld % 4) return GENIE_E_UNSUPPORTED;
+    if (!rows || !cols) return GENIE_OK;
+    dim3 grid(cols / 256, rows / 64);
+    ProfScope prof(GENIE_KC_OTHER, 0.0, (double)rows * cols * (4.0 + (z ? 4.0 : 0.0) + 2.0), st);
+    if (z) cast_rows_colsum_kernel<1><<<grid, 256, 0, st>>>(in, ld, z, out16, cols, colpart);
+    else cast_rows_colsum_kernel<0><<<grid, 256, 0, st>>>(in, ld, nullptr, out16, cols, colpart);
+    GENIE_LAUNCH_CHECK("cast_rows16");
+    return GENIE_OK;
+}
+
 // 16-bit (rows, cols) planes -> (cols, rows) planes
 template <int NPL>
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ outT,

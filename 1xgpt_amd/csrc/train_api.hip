@@ -221,10 +221,20 @@ static TrainWs16 train_ws16(const genie_cfg& c, int B, int npl, void* base, size
     w.dy16 = (uint16_t*)(b + o1); w.dy16T = (uint16_t*)(b + o2); w.xT16 = (uint16_t*)(b + o3);
     return w;
 }
-// 16-bit copies of a gradient matrix in both orientations and, in the same pass, its column sums (= the bias gradient)
+// bf16: the weight gradient runs on the TN kernel (kernels_gemm_tn.hip) from row-major operands when the shapes allow, and then
+// neither the gradient nor the saved activation needs a transposed copy (GENIE_WGRAD_TN=0: the transposed-copy path, for A/B)
+static bool use_tn(int npl, int M, int N, int K) {
+    static const int tn = [] { const char* e = getenv("GENIE_WGRAD_TN"); return e ? atoi(e) : 1; }();
+    return tn && npl == 1 && M % 64 == 0 && N % 256 == 0 && K % 128 == 0;
+}
+// 16-bit copies of a gradient matrix (row-major, and transposed unless its weight gradient takes the TN kernel: Kw = the K of
+// that weight gradient) and, in the same pass, its column sums (= the bias gradient)
 static int cast_t_bias(int npl, float* in, int cols, const float* z, TrainWs16& h, int M, float* dbias, float beta,
-                       TrainWs& w, hipStream_t st) {
-    GENIE_TRY(launch_cast_transpose16(npl, in, cols, z, h.dy16, h.dy16T, M, cols, st, dbias ? w.colpart : nullptr));
+                       TrainWs& w, hipStream_t st, int Kw) {
+    if (use_tn(npl, M, cols, Kw))
+        GENIE_TRY(launch_cast_rows16(in, cols, z, h.dy16, M, cols, st, dbias ? w.colpart : nullptr));
+    else
+        GENIE_TRY(launch_cast_transpose16(npl, in, cols, z, h.dy16, h.dy16T, M, cols, st, dbias ? w.colpart : nullptr));
     return dbias ? launch_slab_reduce(w.colpart, M / 64, (size_t)cols, dbias, beta, st) : GENIE_OK;
 }
 static inline int npl_of(const genie_cfg& c) { return c.precision == GENIE_PREC_BF16 ? 1 : 2; }
@@ -254,6 +264,18 @@ static int wgrad16(int npl, const uint16_t* dYT, const uint16_t* XT, float* dW, 
     GENIE_TRY(launch_gemm16_ex(npl, dYT, Mtok, pa, XT, Mtok, pw, nullptr, nullptr, slabs, nullptr, 0, K, N, K, kc,
                                G16X_OUTF32, alpha, st, ns, kc, kc, (long)N * K));
     return launch_slab_reduce(slabs, ns, (size_t)N * K, dW, beta, st);
+}
+
+// weight gradient from the gradient copies in `h` and the saved row-major 16-bit activation X16 (Mtok, K)
+static int wgrad_any(int npl, TrainWs16& h, const uint16_t* X16, float* dW, int Mtok, int N, int K, float alpha, float beta,
+                     TrainWs& w, hipStream_t st) {
+    if (use_tn(npl, Mtok, N, K)) {
+        const int rc = launch_wgrad16_tn(h.dy16, N, X16, K, dW, Mtok, N, K, alpha, beta, w.slabs, w.slab_floats, st);
+        GENIE_CHECK_SHAPE(rc != GENIE_E_UNSUPPORTED, "wgrad: TN kernel refused N=%d K=%d after its operand was prepared", N, K);
+        return rc;
+    }
+    GENIE_TRY(launch_transpose16(npl, X16, h.xT16, Mtok, K, st));
+    return wgrad16(npl, h.dy16T, h.xT16, dW, Mtok, N, K, alpha, beta, w.slabs, w.slab_floats, st);
 }
 
 static int attn_fwd16(const genie_cfg& c, const genie_attn_weights& aw, const float* qkv, bool temporal, uint16_t* out16,
@@ -355,9 +377,8 @@ static int train_backward_head16(const genie_cfg& c, const genie_weights* wt, co
     const TrainActs16 a = train_acts16(c, B, npl);
     const int d = c.d_model, M = B * c.T * c.S, V = c.factored_vocab * c.num_factored;
     float* dl = (float*)(acts + a.logits);
-    GENIE_TRY(cast_t_bias(npl, dl, V, nullptr, h, M, (float*)grads->out_b, beta, w, st));
-    GENIE_TRY(launch_transpose16(npl, (const uint16_t*)(acts + a.xL16), h.xT16, M, d, st));
-    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)grads->out_w, M, V, d, c.readout_mult, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(cast_t_bias(npl, dl, V, nullptr, h, M, (float*)grads->out_b, beta, w, st, d));
+    GENIE_TRY(wgrad_any(npl, h, (const uint16_t*)(acts + a.xL16), (float*)grads->out_w, M, V, d, c.readout_mult, beta, w, st));
     return lin16(npl, h.dy16, (size_t)M * V, wT->out_w16, nullptr, nullptr, w.dx, nullptr, M, d, V, c.readout_mult, st);
 }
 
@@ -378,13 +399,11 @@ static int train_backward_layer16(const genie_cfg& c, const genie_weights* wt, c
     QkSrc qk;
 
     // ---- MLP
-    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.mlp_bias ? (float*)g.fc2_b : nullptr, beta, w, st));
-    GENIE_TRY(launch_transpose16(npl, H16(a.h), h.xT16, M, hid, st));
-    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.fc2_w, M, d, hid, 1.0f, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.mlp_bias ? (float*)g.fc2_b : nullptr, beta, w, st, hid));
+    GENIE_TRY(wgrad_any(npl, h, H16(a.h), (float*)g.fc2_w, M, d, hid, 1.0f, beta, w, st));
     GENIE_TRY(lin16(npl, h.dy16, pd, lt.fc2_w16, nullptr, nullptr, w.g, nullptr, M, hid, d, 1.0f, st));         // dh
-    GENIE_TRY(cast_t_bias(npl, w.g, hid, F(a.z), h, M, c.mlp_bias ? (float*)g.fc1_b : nullptr, beta, w, st));  // dz
-    GENIE_TRY(launch_transpose16(npl, H16(a.u2), h.xT16, M, d, st));
-    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.fc1_w, M, hid, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(cast_t_bias(npl, w.g, hid, F(a.z), h, M, c.mlp_bias ? (float*)g.fc1_b : nullptr, beta, w, st, d));  // dz
+    GENIE_TRY(wgrad_any(npl, h, H16(a.u2), (float*)g.fc1_w, M, hid, d, 1.0f, beta, w, st));
     if (c.qk_norm) {
         GENIE_TRY(lin16(npl, h.dy16, ph, lt.fc1_w16, nullptr, dx, dx, nullptr, M, d, hid, 1.0f, st));
     } else {
@@ -394,30 +413,26 @@ static int train_backward_layer16(const genie_cfg& c, const genie_weights* wt, c
     }
 
     // ---- temporal
-    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.proj_bias ? (float*)g.temporal.proj_b : nullptr, beta, w, st));
-    GENIE_TRY(launch_transpose16(npl, H16(a.aot), h.xT16, M, d, st));
-    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.temporal.proj_w, M, d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.proj_bias ? (float*)g.temporal.proj_b : nullptr, beta, w, st, d));
+    GENIE_TRY(wgrad_any(npl, h, H16(a.aot), (float*)g.temporal.proj_w, M, d, d, 1.0f, beta, w, st));
     GENIE_TRY(lin16(npl, h.dy16, pd, lt.temporal.proj_w16, nullptr, nullptr, w.d1, nullptr, M, d, d, 1.0f, st));
     GENIE_TRY(qk_source(c, lw.temporal, F(a.qkvt), w, B, &qk, st));
     GENIE_TRY(launch_attn_temporal_bwd(F(a.qkvt), qk.p, qk.ld, w.d1, w.g, B, c.T, c.S, d, c.num_heads, c.head_dim,
                                        c.attn_scale, st));
     GENIE_TRY(qk_norm_backward(c, lw.temporal, g.temporal, F(a.qkvt), w.g, w, B, beta, st));
-    GENIE_TRY(cast_t_bias(npl, w.g, 3 * d, nullptr, h, M, c.qkv_bias ? (float*)g.temporal.qkv_b : nullptr, beta, w, st));
-    GENIE_TRY(launch_transpose16(npl, H16(a.x1h), h.xT16, M, d, st));
-    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.temporal.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(cast_t_bias(npl, w.g, 3 * d, nullptr, h, M, c.qkv_bias ? (float*)g.temporal.qkv_b : nullptr, beta, w, st, d));
+    GENIE_TRY(wgrad_any(npl, h, H16(a.x1h), (float*)g.temporal.qkv_w, M, 3 * d, d, 1.0f, beta, w, st));
     GENIE_TRY(lin16(npl, h.dy16, p3, lt.temporal.qkv_w16, nullptr, dx, dx, nullptr, M, d, 3 * d, 1.0f, st));
 
     // ---- spatial
-    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.proj_bias ? (float*)g.spatial.proj_b : nullptr, beta, w, st));
-    GENIE_TRY(launch_transpose16(npl, H16(a.aos), h.xT16, M, d, st));
-    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.spatial.proj_w, M, d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(cast_t_bias(npl, dx, d, nullptr, h, M, c.proj_bias ? (float*)g.spatial.proj_b : nullptr, beta, w, st, d));
+    GENIE_TRY(wgrad_any(npl, h, H16(a.aos), (float*)g.spatial.proj_w, M, d, d, 1.0f, beta, w, st));
     GENIE_TRY(lin16(npl, h.dy16, pd, lt.spatial.proj_w16, nullptr, nullptr, w.d1, nullptr, M, d, d, 1.0f, st));
     GENIE_TRY(qk_source(c, lw.spatial, F(a.qkvs), w, B, &qk, st));
     GENIE_TRY(spatial_attn_bwd(c, F(a.qkvs), qk, w.d1, w.g, w, B, st));
     GENIE_TRY(qk_norm_backward(c, lw.spatial, g.spatial, F(a.qkvs), w.g, w, B, beta, st));
-    GENIE_TRY(cast_t_bias(npl, w.g, 3 * d, nullptr, h, M, c.qkv_bias ? (float*)g.spatial.qkv_b : nullptr, beta, w, st));
-    GENIE_TRY(launch_transpose16(npl, H16(a.u1), h.xT16, M, d, st));
-    GENIE_TRY(wgrad16(npl, h.dy16T, h.xT16, (float*)g.spatial.qkv_w, M, 3 * d, d, 1.0f, beta, w.slabs, w.slab_floats, st));
+    GENIE_TRY(cast_t_bias(npl, w.g, 3 * d, nullptr, h, M, c.qkv_bias ? (float*)g.spatial.qkv_b : nullptr, beta, w, st, d));
+    GENIE_TRY(wgrad_any(npl, h, H16(a.u1), (float*)g.spatial.qkv_w, M, 3 * d, d, 1.0f, beta, w, st));
     if (c.qk_norm) return lin16(npl, h.dy16, p3, lt.spatial.qkv_w16, nullptr, dx, dx, nullptr, M, d, 3 * d, 1.0f, st);
     GENIE_TRY(lin16(npl, h.dy16, p3, lt.spatial.qkv_w16, nullptr, nullptr, w.d1, nullptr, M, d, 3 * d, 1.0f, st));
     return launch_ln_bwd(F(a.x0), lw.norm1_w, w.d1, dx, (float*)g.norm1_w, (float*)g.norm1_b, M, d, 1e-5f, beta, w.lnpart, st);

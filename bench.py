@@ -176,7 +176,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the full-forward-schedule secondary leg (profiling runs: only headline launches in the trace)")
     ap.add_argument("--train-precision", choices=["exact", "f16x3", "bf16"], default="bf16")
-    ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--train-batch", type=int, default=32,
+                    help="clips per GPU of the training leg (141 GiB of saved activations at 32; halved on out-of-memory)")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
@@ -326,10 +327,24 @@ def main():
     if not args.no_train_leg and os.environ.get("GENIE_BENCH_TRAIN", "1") != "0":
         del ev, model
         torch.cuda.empty_cache()
-        try:
-            train = train_leg(cfg, dev, dist_mod, rank, world, args.train_precision, args.train_batch, 2)
-        except Exception as e:  # never let the secondary leg take the headline down
-            train = {"error": f"{type(e).__name__}: {e}"}
+        tb = args.train_batch
+        while True:
+            oom = None
+            try:
+                train = train_leg(cfg, dev, dist_mod, rank, world, args.train_precision, tb, 2)
+            except torch.OutOfMemoryError as e:  # every rank has the same memory: they all halve together
+                oom = f"{type(e).__name__}: {e}"
+            except Exception as e:  # never let the secondary leg take the headline down
+                train = {"error": f"{type(e).__name__}: {e}"}
+            if oom is None:
+                break
+            import gc
+            gc.collect()  # the failed attempt's tensors are only released once its traceback is gone
+            torch.cuda.empty_cache()
+            if tb <= 8:
+                train = {"error": oom}
+                break
+            tb //= 2
 
     if rank != 0:
         return

@@ -137,10 +137,12 @@ def test_real_geometry_bf16(golden):
         assert np.abs(samp - z[f"s0_gradsample/{k}"]).max() <= 3e-2 * np.abs(g).max() + 1e-12, k
 
 
-@pytest.mark.parametrize("H,d,qk_norm", [(4, 128, False), (2, 128, True), (4, 256, False)])
+@pytest.mark.parametrize("H,d,qk_norm", [(4, 128, False), (2, 128, True), (4, 256, False), (8, 512, False)])
 def test_bf16_attention_backward_vs_exact(H, d, qk_norm):
-    """S = 256 with head_dim 32 and 64, with and without qk-norm: the bf16 trainer (bf16-MFMA spatial attention backward)
-    against the exact trainer on the same weights and batch -- every gradient tensor within 3 % (Frobenius)."""
+    """S = 256 with head_dim 32 and 64, with and without qk-norm: the bf16 trainer (bf16-MFMA spatial attention backward; at
+    d = 256 / 512 every weight gradient on the TN kernel with its transposing LDS reads, kernels_gemm_tn.hip, several column
+    tiles and token slabs) against the exact trainer on the same weights and batch -- every gradient tensor within 3 %
+    (Frobenius)."""
     cfg = pkg("config").GenieConfig(num_layers=2, num_heads=H, d_model=d, T=4, S=256, num_factored_vocabs=2, qk_norm=qk_norm,
                                     use_mup=False, num_prompt_frames=2)
     synth = pkg("synthetic")
