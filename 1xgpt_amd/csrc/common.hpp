@@ -105,6 +105,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// two f32 -> packed bf16 pair (element 0 in the low half) on v_cvt_pk_bf16_f32: round-to-nearest-even like f32_to_bf16, one
+// instruction instead of ~10
+typedef __bf16 genie_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float a, float b) {
+    const genie_f2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, genie_bf2));
+}
 
 // f32 -> (hi, lo) f16 pair with a ~ hi + lo/2048 (GENIE_PREC_F16X3).  hi is flushed to zero below the f16 normal
 // range so that nothing depends on how the matrix core treats f16 subnormals.

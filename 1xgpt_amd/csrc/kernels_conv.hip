@@ -219,19 +219,20 @@ __global__ __launch_bounds__(512, OCC) void conv3x3_igemm_kernel(const uint16_t*
                     v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
                 }
             }
-            uint16_t b[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) b[e] = f32_to_bf16(v[e]);
             uint4 pk;
-            pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
-            pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
-            pk.z = (uint32_t)b[4] | ((uint32_t)b[5] << 16);
-            pk.w = (uint32_t)b[6] | ((uint32_t)b[7] << 16);
+            pk.x = f32x2_to_bf16x2(v[0], v[1]);
+            pk.y = f32x2_to_bf16x2(v[2], v[3]);
+            pk.z = f32x2_to_bf16x2(v[4], v[5]);
+            pk.w = f32x2_to_bf16x2(v[6], v[7]);
             *reinterpret_cast<uint4*>(Y + oidx) = pk;
             if (gn_part) {  // statistics of the STORED (bf16-rounded) tensor, like a separate pass over Y would see
+                const uint32_t pw[4] = {pk.x, pk.y, pk.z, pk.w};
                 float q[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) q[e] = bf16_to_f32(b[e]);
+                for (int e = 0; e < 4; ++e) {
+                    q[2 * e] = __uint_as_float(pw[e] << 16);
+                    q[2 * e + 1] = __uint_as_float(pw[e] & 0xFFFF0000u);
+                }
                 gs0 += (q[0] + q[1]) + (q[2] + q[3]);
                 gq0 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
                 gs1 += (q[4] + q[5]) + (q[6] + q[7]);
@@ -546,19 +547,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
                                 v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
                             }
                         }
-                        uint16_t b[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) b[e] = f32_to_bf16(v[e]);
                         uint4 pk;
-                        pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
-                        pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
-                        pk.z = (uint32_t)b[4] | ((uint32_t)b[5] << 16);
-                        pk.w = (uint32_t)b[6] | ((uint32_t)b[7] << 16);
+                        pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                        pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                        pk.z = f32x2_to_bf16x2(v[4], v[5]);
+                        pk.w = f32x2_to_bf16x2(v[6], v[7]);
                         *reinterpret_cast<uint4*>(Y + oidx) = pk;
                         if (BN == 128 && gn_part) {  // statistics of the STORED (bf16-rounded) tensor
+                            const uint32_t pw[4] = {pk.x, pk.y, pk.z, pk.w};
                             float q[8];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) q[e] = bf16_to_f32(b[e]);
+                            for (int e = 0; e < 4; ++e) {
+                                q[2 * e] = __uint_as_float(pw[e] << 16);
+                                q[2 * e + 1] = __uint_as_float(pw[e] & 0xFFFF0000u);
+                            }
                             gs0 += (q[0] + q[1]) + (q[2] + q[3]);
                             gq0 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
                             gs1 += (q[4] + q[5]) + (q[6] + q[7]);
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(256) void gn_swish_rows_kernel(const uint16_t* __re
                 if (apply_swish) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
                 r2[hh] = y;
             }
-            o[k] = (uint32_t)f32_to_bf16(r2[0]) | ((uint32_t)f32_to_bf16(r2[1]) << 16);
+            o[k] = f32x2_to_bf16x2(r2[0], r2[1]);
         }
         *reinterpret_cast<uint4*>(Y + base + (size_t)p * C) = make_uint4(o[0], o[1], o[2], o[3]);
     }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __re
         for (int e = 0; e < 4; ++e) {
             cs[2 * e] += v[2 * e];
             cs[2 * e + 1] += v[2 * e + 1];
-            pk[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+            pk[e] = f32x2_to_bf16x2(v[2 * e], v[2 * e + 1]);
         }
         *reinterpret_cast<uint4*>(out16 + (size_t)(r0 + ty + 8 * i) * cols + c0 + tx * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
