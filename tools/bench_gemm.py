@@ -14,7 +14,7 @@ sys.path.insert(0, REPO)
 _lib = importlib.import_module("1xgpt_amd._lib")
 
 
-def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False):
+def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False, acc=0):
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
@@ -37,8 +37,9 @@ def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False):
         _lib.check(pack(W.data_ptr(), W16.data_ptr(), W.numel(), st), "pack")
 
         def call():
-            _lib.check(lib.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, gelu, 0,
+            _lib.check(lib.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, gelu, acc,
                                              st), "lin16")
+    y.zero_()
     call()
     torch.cuda.synchronize()
     err = None
@@ -63,6 +64,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--prec", nargs="+", default=["exact", "f16x3", "bf16"])
     ap.add_argument("--gelu", type=int, default=0, help="fused erf-GELU epilogue (16-bit precisions)")
+    ap.add_argument("--acc", type=int, default=0, help="residual accumulate (y += ...) epilogue (16-bit precisions)")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power study, not a throughput figure)")
     a = ap.parse_args()
     M = 4096 * a.batch
@@ -71,6 +73,6 @@ if __name__ == "__main__":
     for prec in a.prec:
         for name, N, K in shapes:
             m = 4096 if name == "sq4096" else M
-            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0, zero=a.zero)
+            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0, zero=a.zero, acc=a.acc if prec != "exact" else 0)
             print(f"{prec:6s} {name:8s} M={m:6d} N={N:5d} K={K:5d}  {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s  max|err| {err:.2e}",
                   flush=True)
