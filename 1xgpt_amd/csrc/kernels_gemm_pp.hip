@@ -619,6 +619,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[q][j][e];
+                // the round's eight residual rows are requested together, ahead of the stores: the residual and the output may
+                // be the same buffer, so the compiler would keep each read behind the previous row's store (one exposed memory
+                // round trip per row); the rows of a round are distinct, so reading them all first is safe in place too
+                float4 res[8];
+                if (do_acc) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = m0e + wm * 128 + q * 32 + it * 4 + (lane >> 4);
+                        res[it] = *reinterpret_cast<const float4*>(Rsrc + (size_t)row * ldc + col);
+                    }
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     }
                     const size_t idx = (size_t)row * ldc + col;
                     if (do_acc) {
-                        const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
+                        const float4 o = res[it];
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
                     if constexpr (ABL & 8) {
