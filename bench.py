@@ -23,6 +23,37 @@ import os
 import sys
 import time
 
+
+def _board_sampler_main(path):
+    """Helper process of BoardSampler: loops rocm-smi and appends time-stamped (power, shader clock) samples per card to `path`.
+    Runs before torch is imported: this process never touches the GPU."""
+    import re
+    import subprocess
+    t_end = time.time() + 3600
+    parent = os.getppid()
+    with open(path, "w") as f:
+        while time.time() < t_end and os.getppid() == parent:
+            try:
+                r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True,
+                                   text=True, timeout=10)
+                d = json.loads(r.stdout)
+                cards = {}
+                for card, c in d.items():
+                    p = [float(v) for k, v in c.items() if "ower" in k and "(W)" in k]
+                    fq = [float(re.sub(r"[^0-9.]", "", v)) for k, v in c.items() if k.lower().startswith("sclk clock speed")]
+                    if p and fq:
+                        cards[card] = (p[0], fq[0])
+                f.write(json.dumps({"t": time.time(), "cards": cards}) + "\n")
+                f.flush()
+            except Exception:
+                pass
+            time.sleep(0.5)
+
+
+if __name__ == "__main__" and len(sys.argv) == 3 and sys.argv[1] == "--_board_sampler":
+    _board_sampler_main(sys.argv[2])
+    sys.exit(0)
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
@@ -87,6 +118,56 @@ def cpu_baseline(cfg, sd, clips, maskgit_steps, budget_s=20.0):
                       + ", ".join(f"{c}: {v:.2f} s/forward" for c, v in sorted(probe.items())),
             "reference_cpu_anchor": "SURVEY.md 8(d): the reference itself (genie/evaluate.py path, torch 2.10 CPU) in the build "
                                     "container, 8 threads of a 2.1 GHz Xeon: 2.81 s per C138-shape forward = 0.19 frames/s"}
+
+
+class BoardSampler:
+    """Socket power and shader clock of the GPUs, sampled every ~0.5 s by a helper process that loops
+    `rocm-smi --showpower --showclocks --json`.  The helper is started BEFORE this process touches the GPU (a process that has
+    initialised the GPU must not exec another program on this pool) and writes time-stamped samples to a file; the timed
+    region's window is cut out of it afterwards.  What the board's power management does under THIS workload goes into the
+    bench line."""
+
+    def __init__(self):
+        import subprocess
+        import tempfile
+        self.path = os.path.join(tempfile.gettempdir(), f"genie_board_{os.getpid()}.jsonl")
+        self.proc = None
+        if os.path.exists("/opt/rocm/bin/rocm-smi"):
+            try:
+                self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--_board_sampler", self.path],
+                                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            except Exception:
+                self.proc = None
+
+    def window(self, t0, t1, device_index):
+        """Stops the helper and returns the summary of the samples taken in [t0, t1] (time.time() stamps) for one device."""
+        if self.proc is None:
+            return None
+        try:
+            self.proc.terminate()
+            self.proc.wait(timeout=15)
+        except Exception:
+            pass
+        rows = []
+        try:
+            with open(self.path) as f:
+                for line in f:
+                    try:
+                        j = json.loads(line)
+                    except Exception:
+                        continue
+                    c = j["cards"].get(f"card{device_index}")
+                    if c and t0 <= j["t"] <= t1:
+                        rows.append(c)
+            os.remove(self.path)
+        except Exception:
+            return None
+        if not rows:
+            return None
+        n = len(rows)
+        return {"samples": n, "socket_power_w_avg": sum(p for p, _ in rows) / n, "socket_power_w_max": max(p for p, _ in rows),
+                "sclk_mhz_avg": sum(f for _, f in rows) / n, "sclk_mhz_min": min(f for _, f in rows),
+                "source": "rocm-smi --showpower --showclocks, sampled every ~0.5 s during the timed region (rank 0's GPU)"}
 
 
 def train_leg(cfg, dev, dist_mod, rank, world, precision, batch, steps):
@@ -176,6 +257,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the full-forward-schedule secondary leg (profiling runs: only headline launches in the trace)")
     ap.add_argument("--train-precision", choices=["exact", "f16x3", "bf16"], default="bf16")
+    ap.add_argument("--no-board-sampler", action="store_true", help="do not sample rocm-smi power / clock during the timed region")
     ap.add_argument("--train-batch", type=int, default=32,
                     help="clips per GPU of the training leg (141 GiB of saved activations at 32; halved on out-of-memory)")
     ap.add_argument("--no-events", action="store_true",
@@ -186,6 +268,8 @@ def main():
     # thread's Python stack to stderr and exit after GENIE_BENCH_WATCHDOG seconds (default 900; the default run takes ~2 min)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)  # never returns (the parent only waits for its child launcher)
+    # the power / clock sampler's helper process must exist before this process touches the GPU (rank 0 only)
+    sampler = BoardSampler() if int(os.environ.get("RANK", "0")) == 0 and not args.no_board_sampler else None
     import faulthandler
     wd = int(os.environ.get("GENIE_BENCH_WATCHDOG", "900"))
     if wd > 0:
@@ -239,12 +323,14 @@ def main():
     dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    wall0 = time.time()
     sums = None
     for _ in range(args.steps):
         sums = step()
     torch.cuda.synchronize()
     dist_mod.barrier()
     seconds = time.perf_counter() - t0
+    board = sampler.window(wall0, time.time(), dev_index) if sampler else None
     tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -425,9 +511,17 @@ def main():
         out["roofline"]["mfma_issue_frac"] = 3.0 * achieved / peak
         out["roofline"]["note"] = ("algorithmic FLOPs counted once; the kernel issues 3 f16 MFMAs per algorithmic MFMA "
                                    "(split operands), so frac <= 1/3 by construction")
+    if board:
+        # what the matrix pipe could deliver at the clock the board actually held (the 2.5 PF peak is quoted at 2.4 GHz)
+        board["peak_at_measured_clock"] = peak * board["sclk_mhz_avg"] / 2400.0
+        board["frac_at_measured_clock"] = achieved / board["peak_at_measured_clock"] if board["peak_at_measured_clock"] else None
+        board["note"] = ("informational: `frac` above stays achieved / nominal peak; on random operands the board runs at its socket "
+                         "power limit and power management lowers the shader clock (profiles/r02_power_clock_zero_vs_random.txt: "
+                         "2,395 MHz at 1,306 W on zero-filled operands, 1,475 MHz at the 1,400 W cap on random ones, same binary)")
+        out["roofline"]["board"] = board
     if args.precision in ("f16x3", "bf16"):
         out["roofline"]["board_note"] = (
-            "16-bit MFMA throughput on this board is set by its power-managed clock, not by the schedule: the same gemm16_pp "
+            "16-bit MFMA throughput on this board is set by its power-managed clock, not by the schedule (roofline.board: socket power and shader clock sampled in this run): the same gemm16_pp "
             "binary runs 4096^3 at 0.83 (f16x3 issue) / 0.72 (bf16) of the 2.5 PF peak on zero-filled operands and at 0.51-0.52 on "
             "random operands; the vendor GEMM shows the same two levels (profiles/r02_gemm_zero_operands.txt, "
             "r02_gemm_random_operands.txt, r02_vendor_gemm_random_vs_zero.txt; DESIGN.md section 5)")
