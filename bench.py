@@ -269,7 +269,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)  # never returns (the parent only waits for its child launcher)
     # the power / clock sampler's helper process must exist before this process touches the GPU (rank 0 only)
-    sampler = BoardSampler() if int(os.environ.get("RANK", "0")) == 0 and not args.no_board_sampler else None
+    # (not under a profiler: its preloaded library may already have initialised the GPU in this process)
+    profiled = any("ROCPROF" in k.upper() for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+    sampler = BoardSampler() if int(os.environ.get("RANK", "0")) == 0 and not args.no_board_sampler and not profiled else None
     import faulthandler
     wd = int(os.environ.get("GENIE_BENCH_WATCHDOG", "900"))
     if wd > 0:

@@ -4,7 +4,7 @@
 TAG=${1:-r02}; PREC=${2:-f16x3}; CLIPS=${3:-128}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-events --no-secondary --no-train-leg --no-cpu-baseline --precision $PREC --batch $CLIPS"
+ARGS="--steps 1 --warmup 0 --no-events --no-board-sampler --no-secondary --no-train-leg --no-cpu-baseline --precision $PREC --batch $CLIPS"
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_pf --output-format csv -- python3 $R/bench.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_pw --output-format csv -- python3 $R/bench.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_ps --output-format csv -- python3 $R/bench.py $ARGS > /dev/null 2>&1
