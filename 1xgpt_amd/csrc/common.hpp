@@ -98,20 +98,15 @@ __device__ __forceinline__ genie_f2 gelu_erf_fast2(genie_f2 z) {
     return zp - w;
 }
 
-// round-to-nearest-even f32 -> bf16 bits
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// two f32 -> packed bf16 pair (element 0 in the low half) on v_cvt_pk_bf16_f32: round-to-nearest-even like f32_to_bf16, one
-// instruction instead of ~10
+// round-to-nearest-even f32 -> bf16 bits: v_cvt_pk_bf16_f32 (gfx950), one instruction instead of the five of the integer
+// emulation  u += 0x7FFF + ((u >> 16) & 1); u >>= 16  -- the same rounding for every finite value
 typedef __bf16 genie_bf2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float a, float b) {
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float a, float b) {  // element 0 in the low half
     const genie_f2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, genie_bf2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(f32x2_to_bf16x2(f, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // f32 -> (hi, lo) f16 pair with a ~ hi + lo/2048 (GENIE_PREC_F16X3).  hi is flushed to zero below the f16 normal
 // range so that nothing depends on how the matrix core treats f16 subnormals.
