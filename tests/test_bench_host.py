@@ -1,0 +1,55 @@
+"""Host-side pieces of bench.py that run without a GPU: the board power / clock sampler's window logic and the FLOP accounting
+of a pass (the numbers the bench line's `roofline` object is built from)."""
+import importlib.util
+import json
+import os
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)  # __name__ != "__main__": nothing runs
+    return mod
+
+
+def test_board_sampler_window(tmp_path):
+    bench = load_bench()
+    s = bench.BoardSampler.__new__(bench.BoardSampler)  # no helper process: feed the file it would have written
+    s.proc = type("P", (), {"terminate": lambda self: None, "wait": lambda self, timeout=None: 0})()
+    s.path = str(tmp_path / "board.jsonl")
+    t = 1000.0
+    rows = [(t - 1.0, 300.0, 150.0), (t + 0.1, 1390.0, 1600.0), (t + 0.6, 1400.0, 1500.0), (t + 5.0, 280.0, 120.0)]
+    with open(s.path, "w") as f:
+        for ts, p, clk in rows:
+            f.write(json.dumps({"t": ts, "cards": {"card0": (p, clk), "card1": (1.0, 2.0)}}) + "\n")
+        f.write("not json\n")
+    out = s.window(t, t + 1.0, 0)
+    assert out["samples"] == 2
+    assert abs(out["socket_power_w_avg"] - 1395.0) < 1e-9 and out["socket_power_w_max"] == 1400.0
+    assert abs(out["sclk_mhz_avg"] - 1550.0) < 1e-9 and out["sclk_mhz_min"] == 1500.0
+    assert not os.path.exists(s.path)
+
+
+def test_board_sampler_without_samples(tmp_path):
+    bench = load_bench()
+    s = bench.BoardSampler.__new__(bench.BoardSampler)
+    s.proc = None
+    s.path = str(tmp_path / "none.jsonl")
+    assert s.window(0.0, time.time(), 0) is None
+
+
+def test_pass_flops_counts_every_linear_and_attention_product():
+    bench = load_bench()
+    import importlib
+    cfgmod = importlib.import_module("1xgpt_amd.config")
+    cfg = cfgmod.GenieConfig(num_layers=2, num_heads=4, d_model=128, T=4, S=16, num_factored_vocabs=2)
+    d, hid, S, T, L = cfg.d_model, cfg.d_model * 4, cfg.S, cfg.T, cfg.num_layers
+    V = cfg.factored_vocab_size * cfg.num_factored_vocabs
+    rows = T * S
+    linear = 2.0 * rows * (L * (3 * d * d + d * d + 3 * d * d + d * d + 2 * d * hid) + d * V)
+    got = bench.pass_flops(cfg, T)
+    assert got >= linear                       # attention products on top of the Linear layers
+    assert got <= linear * 1.5
