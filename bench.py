@@ -410,31 +410,36 @@ def main():
                             "gbps": round(prof[3] / max(prof[1], 1e-9) / 1e6, 1)}
         lib.genie_profile_enable(0)
 
-    # secondary leg: training step (every rank takes part: the gradient all-reduce is the path's one real exchange)
-    train = None
-    if not args.no_train_leg and os.environ.get("GENIE_BENCH_TRAIN", "1") != "0":
-        del ev, model
+    # secondary leg: training step (every rank takes part: the gradient all-reduce is the path's one real exchange).  Rank 0 runs
+    # it AFTER the headline line is assembled and under a timer: a training leg that hangs (a collective that never completes)
+    # must not take the measured headline down with it.
+    want_train = not args.no_train_leg and os.environ.get("GENIE_BENCH_TRAIN", "1") != "0"
+
+    def run_train_leg():
+        nonlocal ev, model
+        ev = model = None
         torch.cuda.empty_cache()
         tb = args.train_batch
         while True:
-            oom = None
+            oom, res = None, None
             try:
-                train = train_leg(cfg, dev, dist_mod, rank, world, args.train_precision, tb, 2)
+                res = train_leg(cfg, dev, dist_mod, rank, world, args.train_precision, tb, 2)
             except torch.OutOfMemoryError as e:  # every rank has the same memory: they all halve together
                 oom = f"{type(e).__name__}: {e}"
             except Exception as e:  # never let the secondary leg take the headline down
-                train = {"error": f"{type(e).__name__}: {e}"}
+                res = {"error": f"{type(e).__name__}: {e}"}
             if oom is None:
-                break
+                return res
             import gc
             gc.collect()  # the failed attempt's tensors are only released once its traceback is gone
             torch.cuda.empty_cache()
             if tb <= 8:
-                train = {"error": oom}
-                break
+                return {"error": oom}
             tb //= 2
 
     if rank != 0:
+        if want_train:
+            run_train_leg()
         return
     m = dist_mod.means_from_sums(sums.tolist())
     frames_per_step = (cfg.T - 1) * B * world
@@ -527,8 +532,22 @@ def main():
             "binary runs 4096^3 at 0.83 (f16x3 issue) / 0.72 (bf16) of the 2.5 PF peak on zero-filled operands and at 0.51-0.52 on "
             "random operands; the vendor GEMM shows the same two levels (profiles/r02_gemm_zero_operands.txt, "
             "r02_gemm_random_operands.txt, r02_vendor_gemm_random_vs_zero.txt; DESIGN.md section 5)")
-    if train:
-        out["train_step"] = train
+    if want_train:
+        import threading
+        limit = int(os.environ.get("GENIE_BENCH_TRAIN_LIMIT", "420"))
+
+        def emergency():
+            out["train_step"] = {"error": f"training leg did not finish within {limit} s; headline line printed by its timer"}
+            print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(limit, emergency)
+        timer.daemon = True
+        timer.start()
+        train = run_train_leg()
+        timer.cancel()
+        if train:
+            out["train_step"] = train
     if breakdown:
         out["breakdown"] = breakdown
     if world == 1 and not args.no_cpu_baseline:
