@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgenie_hip.so")
+# GENIE_HIP_LIBRARY: an explicit path to another build of the same ABI (the -DGENIE_STUDY library of 1xgpt_amd/build.py, an A/B
+# variant under 1xgpt_amd/build/ab/) for tools/; unset = the shipping library beside this file
+LIB_PATH = os.environ.get("GENIE_HIP_LIBRARY") or os.path.join(HERE, "libgenie_hip.so")
 
 PREC_EXACT, PREC_BF16, PREC_F16X3 = 0, 1, 2
 LAYOUT_TOKEN_MAJOR, LAYOUT_BCTHW = 0, 1
@@ -104,6 +106,9 @@ SIGNATURES = {
     "genie_profile_enable": (C.c_int, [C.c_int]),
     "genie_profile_reset": (C.c_int, []),
     "genie_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "genie_profile_kernels": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "genie_study_build": (C.c_int, []),
+    "genie_weight_range_hint": (C.c_int, [c_ptr, C.c_int]),
     "genie_bits_from_tokens": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_rescale_u8_bf16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_rescale_u8_f32": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
@@ -153,6 +158,10 @@ def load():
             fn.restype, fn.argtypes = res, args
         if lib.genie_version() != 1:
             raise RuntimeError(f"libgenie_hip ABI version {lib.genie_version()} != 1")
+        if os.environ.get("GENIE_HIP_LIBRARY") or lib.genie_study_build():
+            import sys
+            print(f"1xgpt_amd: using {LIB_PATH} (study build: {bool(lib.genie_study_build())}) -- not the shipping library",
+                  file=sys.stderr)
         _lib = lib
     return _lib
 

@@ -22,15 +22,27 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, study=None):
+    """study=True (or GENIE_STUDY=1 in the environment of `python 1xgpt_amd/build.py`): compile with -DGENIE_STUDY into
+    libgenie_hip_study.so -- the ablation / scheduling / reduced-precision knobs of the kernels' A/B studies are live there and
+    only there (load it with GENIE_HIP_LIBRARY=<path>); the shipping library reads no environment variable on a launch path."""
+    if study is None:
+        study = os.environ.get("GENIE_STUDY", "0") == "1"
+    if study:
+        return _build(force, verbose, os.path.join(HERE, "libgenie_hip_study.so"), os.path.join(HERE, "build", "study"),
+                      FLAGS + ["-DGENIE_STUDY"])
+    return _build(force, verbose, LIB, os.path.join(HERE, "build"), FLAGS)
+
+
+def _build(force, verbose, LIB, OBJDIR, FLAGS):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "genie_hip.h"))
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
             cmd = [hipcc, "-x", "hip", "-c", s, "-o", o] + FLAGS
             if verbose:

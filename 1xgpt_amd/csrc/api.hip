@@ -26,13 +26,15 @@ static int g_prof_n = 0;
 static hipEvent_t* g_prof_ev = nullptr;  // 2 * GENIE_PROFILE_MAX_LAUNCHES events, created on first enable
 static int g_prof_cls[GENIE_PROFILE_MAX_LAUNCHES];
 static double g_prof_flops[GENIE_PROFILE_MAX_LAUNCHES], g_prof_bytes[GENIE_PROFILE_MAX_LAUNCHES];
+static const char* g_prof_name[GENIE_PROFILE_MAX_LAUNCHES];
 
-ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
+ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s, const char* kernel) : slot(-1), st(s) {
     if (!(g_prof_mask & (1 << cls)) || g_prof_n >= GENIE_PROFILE_MAX_LAUNCHES || !g_prof_ev) return;
     slot = g_prof_n++;
     g_prof_cls[slot] = cls;
     g_prof_flops[slot] = flops;
     g_prof_bytes[slot] = bytes;
+    g_prof_name[slot] = kernel ? kernel : "(unnamed)";
     (void)hipEventRecord(g_prof_ev[2 * slot], st);
 }
 ProfScope::~ProfScope() {
@@ -205,6 +207,7 @@ static int decoder(const genie_cfg& c, const genie_weights& wt, float* x, Worksp
     if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, x, w, B, st));
     for (int i = 0; i < c.num_layers; ++i) {
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
+        GENIE_STUDY_LAYER(i);
         const int rc = st_block(c, wt.layers_host[i], x, w, B, st);
         w.skip_shadow_mlp = false;
         GENIE_TRY(rc);
@@ -392,6 +395,7 @@ static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int
         else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; w.tshift = tshift; }
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
         w.stop_after_tqkv = clean && i + 1 == c.num_layers;  // nothing reads the clean pass's final hidden state
+        GENIE_STUDY_LAYER(i);
         int rc = st_block(c, wt.layers_host[i], w.x, w, B, st);
         w.skip_shadow_mlp = false;
         w.stop_after_tqkv = false;
@@ -629,6 +633,43 @@ int genie_profile_read(int kernel_class, double* out4) {
     }
     return GENIE_OK;
 }
+
+int genie_profile_kernels(int kernel_class, char* buf, size_t buf_bytes) {
+    GENIE_CHECK_ARG(buf && buf_bytes >= 64 && kernel_class >= 0 && kernel_class < GENIE_KC_COUNT, "profile_kernels: bad argument");
+    // distinct kernel names of the class (string literals: compared by content), launches / ms / flops each
+    constexpr int MAXK = 32;
+    const char* names[MAXK];
+    double n[MAXK], ms[MAXK], fl[MAXK];
+    int nk = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (g_prof_cls[i] != kernel_class) continue;
+        int k = 0;
+        while (k < nk && strcmp(names[k], g_prof_name[i]) != 0) ++k;
+        if (k == nk) {
+            if (nk == MAXK) continue;
+            names[nk] = g_prof_name[i]; n[nk] = ms[nk] = fl[nk] = 0.0; ++nk;
+        }
+        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) { set_error("profile: sync failed"); return GENIE_E_LAUNCH; }
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess) { set_error("profile: elapsed failed"); return GENIE_E_LAUNCH; }
+        n[k] += 1.0; ms[k] += t; fl[k] += g_prof_flops[i];
+    }
+    size_t off = 0;
+    buf[0] = 0;
+    for (int k = 0; k < nk; ++k) {
+        const int w = snprintf(buf + off, buf_bytes - off, "%s\t%.0f\t%.6f\t%.6e\n", names[k], n[k], ms[k], fl[k]);
+        if (w < 0 || (size_t)w >= buf_bytes - off) break;
+        off += (size_t)w;
+    }
+    return GENIE_OK;
+}
+
+int genie_weight_range_hint(const void* w16, int wide) {
+    GENIE_CHECK_ARG(w16 != nullptr, "weight_range_hint: NULL weight");
+    return set_weight_wide(w16, wide);
+}
+
+int genie_study_build(void) { return kStudyBuild ? 1 : 0; }
 
 int genie_bits_from_tokens(const int64_t* ids, float* z, int n, int hw, int bits, void* stream) {
     GENIE_CHECK_ARG(ids && z && n >= 0 && hw >= 1 && bits >= 1 && bits <= 62, "bits_from_tokens: bad argument");

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/genie_hip.h"
 
@@ -121,7 +124,7 @@ __device__ __forceinline__ void split_f16(float a, uint16_t& hi, uint16_t& lo) {
 
 // The same split for four values at once, on packed conversions (v_cvt_pk_f16_f32: 3 VALU instructions per element instead of
 // ~10) and WITHOUT the flush of a subnormal hi: gfx950's f16 matrix instructions take subnormal inputs exactly (probed on
-// MI355X: A- and B-side subnormals down to 2^-24 give exact sums, tools/_subnormal_probe.py), so hi + lo/2048 is the same
+// MI355X: A- and B-side subnormals down to 2^-24 give exact sums, tools/probe_f16_subnormals.py), so hi + lo/2048 is the same
 // 22-bit value either way.  Returns hi pairs in h01 / h23 and lo pairs in l01 / l23 (element 0 in the low half).
 __device__ __forceinline__ void split_f16_x4(float a0, float a1, float a2, float a3, uint32_t& h01, uint32_t& h23,
                                              uint32_t& l01, uint32_t& l23) {
@@ -134,6 +137,27 @@ __device__ __forceinline__ void split_f16_x4(float a0, float a1, float a2, float
     h01 = __builtin_bit_cast(uint32_t, hx); h23 = __builtin_bit_cast(uint32_t, hy);
     l01 = __builtin_bit_cast(uint32_t, lx); l23 = __builtin_bit_cast(uint32_t, ly);
 }
+
+// Study knobs (ablations that make results WRONG, reduced-precision GEMM terms, in-launch stamps that allocate and synchronise)
+// exist only in a -DGENIE_STUDY build (GENIE_STUDY=1 python 1xgpt_amd/build.py -> libgenie_hip_study.so).  In the shipping
+// library study_env() is a constant: a leaked environment variable cannot change what a launch computes.
+#ifdef GENIE_STUDY
+inline int study_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    if (e && atoi(e) != dflt) {
+        static thread_local char seen[512] = "";
+        if (!strstr(seen, name)) {
+            fprintf(stderr, "libgenie_hip (STUDY BUILD): %s=%s overrides the default %d -- results of this process are not the product's\n", name, e, dflt);
+            if (strlen(seen) + strlen(name) + 2 < sizeof(seen)) { strcat(seen, name); strcat(seen, ";"); }
+        }
+    }
+    return e ? atoi(e) : dflt;
+}
+constexpr bool kStudyBuild = true;
+#else
+constexpr int study_env(const char*, int dflt) { return dflt; }
+constexpr bool kStudyBuild = false;
+#endif
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

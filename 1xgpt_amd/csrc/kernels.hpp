@@ -37,11 +37,29 @@ struct Workspace {
     bool stop_after_tqkv = false;
 };
 
+// f16x3 weight tensors with |w| >= 32 (kernels_bf16.hip): kept off the 2^11-scaling single-accumulator GEMM
+bool weight_is_wide(const void* W16);
+int set_weight_wide(const void* W16, int wide);
+
+// Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
+// tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.
+#ifdef GENIE_STUDY
+extern int g_study_gemm_class;   // 0 qkv_s, 1 qkv_t, 2 proj_s, 3 proj_t, 4 fc1, 5 fc2, 6 readout
+extern int g_study_layer;
+int study_terms();                // 3, or 2 when GENIE_F16_TERMS2_CLASSES / _LAYER_LO / _LAYER_HI select the current launch
+#define GENIE_STUDY_CLASS(k) (genie::g_study_gemm_class = (k))
+#define GENIE_STUDY_LAYER(i) (genie::g_study_layer = (i))
+#else
+#define GENIE_STUDY_CLASS(k) ((void)0)
+#define GENIE_STUDY_LAYER(i) ((void)0)
+#endif
+
 // Brackets one launch with HIP events when profiling of `cls` is enabled (see genie_profile_* in the ABI).
 struct ProfScope {
     int slot;
     hipStream_t st;
-    ProfScope(int cls, double flops, double bytes, hipStream_t st);
+    // kernel: a string LITERAL naming what is launched inside the scope (reported by genie_profile_kernels)
+    ProfScope(int cls, double flops, double bytes, hipStream_t st, const char* kernel = nullptr);
     ~ProfScope();
 };
 

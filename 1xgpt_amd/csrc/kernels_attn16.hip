@@ -354,7 +354,7 @@ int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, i
     const size_t lds = (size_t)2 * 256 * Dh * 2 + (size_t)2 * Dh * 520 + 2048;  // K planes, V^T planes, key-split statistics
     // few (sequence, head) pairs: spread one pair over several workgroups -- by keys within the workgroup (qw = 0: 8 query
     // blocks per pair) for a handful, by query blocks of 2 or 4 waves for a few dozen
-    static const int ksplit = [] { const char* e = getenv("GENIE_ATTN_KEYSPLIT"); return e ? atoi(e) : 1; }();
+    static const int ksplit = study_env("GENIE_ATTN_KEYSPLIT", 1);
     const int qw = n_seq * H <= 32 ? (ksplit ? 0 : 1) : (n_seq * H <= 64 ? 2 : (n_seq * H <= 128 ? 4 : 8));
     dim3 grid((unsigned)n_seq, H, qw ? 8 / qw : 8);
     ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * Dh * H * (double)n_seq, (double)n_seq * S * H * Dh * 16.0, st);

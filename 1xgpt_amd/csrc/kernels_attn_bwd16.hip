@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd16_kv_kernel(const float* __re
 // GENIE_E_UNSUPPORTED for other geometries (the caller then takes the f32 kernel).
 int launch_attn_spatial_bwd_bf16(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, float* stats, long n_bt,
                                  int S, int d, int H, int Dh, float scale, hipStream_t st) {
-    static const int on = [] { const char* e = getenv("GENIE_ATTN_BWD16"); return e ? atoi(e) : 1; }();
+    static const int on = study_env("GENIE_ATTN_BWD16", 1);
     if (!on || S != 256 || (Dh != 64 && Dh != 32) || qk_ld % 4 || d % 4) return GENIE_E_UNSUPPORTED;
     if (n_bt <= 0) return GENIE_OK;
     ProfScope prof(GENIE_KC_ATTN_SPATIAL, 14.0 * S * S * Dh * (double)n_bt * H, 4.0 * 10 * S * Dh * (double)n_bt * H, st);

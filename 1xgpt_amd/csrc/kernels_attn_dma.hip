@@ -385,7 +385,8 @@ int launch_attn_spatial_dma(int npl, const uint16_t* qkv16, long n_seq, int d, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                       \
         attn_spatial_dma_kernel<DH_, NPL_><<<grid, 512, lds, st>>>(qkv16, P, d, H, items, out16, (long)out_plane);        \
     } while (0)
-    static const int stamp = [] { const char* e = getenv("GENIE_ATTN_STAMPS"); return e ? atoi(e) : 0; }();
+#ifdef GENIE_STUDY   // per-phase s_memtime stamps: allocates and synchronises inside the launch -- study builds only
+    static const int stamp = study_env("GENIE_ATTN_STAMPS", 0);
     if (stamp && Dh == 64 && npl == 2) {
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, 25 * sizeof(unsigned long long));
@@ -404,6 +405,7 @@ int launch_attn_spatial_dma(int npl, const uint16_t* qkv16, long n_seq, int d, i
         GENIE_LAUNCH_CHECK("attn_spatial_dma_stamps");
         return GENIE_OK;
     }
+#endif
     if (Dh == 64 && npl == 2) ATTN_LAUNCH(64, 2);
     else if (Dh == 64) ATTN_LAUNCH(64, 1);
     else if (npl == 2) ATTN_LAUNCH(32, 2);

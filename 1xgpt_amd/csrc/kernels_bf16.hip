@@ -11,6 +11,9 @@
 // fetches) and mirrored on the fragment read:  phys_slot = slot ^ ((row / rows_per_256B) % slots_per_row).
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -527,6 +530,40 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     }
 }
 
+// Weight tensors whose packed hi plane reaches |w| >= 32 (genie_weight_range_hint): the single-accumulator split GEMM
+// (gemm16_pp) multiplies the hi plane by 2^11 in f16, exact below 32 only, so these run on the two-accumulator kernels
+// (gemm16_v2 / gemm16_nt / gemm16_sm: hi.hi and the cross terms in separate accumulators, no operand scaling; limit = the f16 range).
+static std::vector<const void*> g_wide_weights;
+static std::mutex g_wide_mutex;
+bool weight_is_wide(const void* W) {
+    if (g_wide_weights.empty()) return false;
+    std::lock_guard<std::mutex> lk(g_wide_mutex);
+    for (const void* p : g_wide_weights)
+        if (p == W) return true;
+    return false;
+}
+int set_weight_wide(const void* W, int wide) {
+    std::lock_guard<std::mutex> lk(g_wide_mutex);
+    for (size_t i = 0; i < g_wide_weights.size(); ++i)
+        if (g_wide_weights[i] == W) {
+            if (!wide) g_wide_weights.erase(g_wide_weights.begin() + (long)i);
+            return GENIE_OK;
+        }
+    if (wide) g_wide_weights.push_back(W);
+    return GENIE_OK;
+}
+
+#ifdef GENIE_STUDY
+int g_study_gemm_class = 0, g_study_layer = 0;
+int study_terms() {
+    static const int all = study_env("GENIE_F16_TERMS", 3);
+    static const int mask = study_env("GENIE_F16_TERMS2_CLASSES", 0);
+    static const int l0 = study_env("GENIE_F16_TERMS2_LAYER_LO", 0), l1 = study_env("GENIE_F16_TERMS2_LAYER_HI", 1 << 30);
+    if (all != 3) return all;
+    return (((mask >> g_study_gemm_class) & 1) && g_study_layer >= l0 && g_study_layer < l1) ? 2 : 3;
+}
+#endif
+
 // A, W: 16-bit operands (NPL planes each, plane strides in elements); Cf f32 (ACCUM / OUTF32), C16 16-bit out.
 template <int NPL>
 static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
@@ -540,16 +577,20 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
     const double mn = (double)M * N * batch;
     {   // outputs that cannot stay in the 256 MB Infinity Cache anyway are stored non-temporally: +10..18 % on the
         // K = 512 GEMMs at >= 8 clips (they no longer evict the A panel / weights they share the L2 with)
-        static const int nt_mode = [] { const char* e = getenv("GENIE_GEMM16_NT"); return e ? atoi(e) : -1; }();
+        static const int nt_mode = study_env("GENIE_GEMM16_NT", -1);
         const double out_bytes = mn * ((flags & G16_OUTF32 ? 4 : 0) + (flags & G16_OUT16 ? 2 * NPL : 0));
         if (nt_mode == 1 || (nt_mode < 0 && out_bytes >= 192e6)) flags |= G16_NT;
     }
     {   // the 256x256 phase-scheduled kernel (kernels_gemm_pp.hip) takes every problem that fills the chip with its tiles.
         // Its split-f16 form multiplies the W operand's hi plane by 2^11 in registers, so W must be a weight matrix
         // (|w| < 32): the training step's activation-by-activation products keep the two-accumulator kernel below.
-        static const int pp = [] { const char* e = getenv("GENIE_GEMM16_PP"); return e ? atoi(e) : 1; }();
-        static const int terms = [] { const char* e = getenv("GENIE_F16_TERMS"); return e ? atoi(e) : 3; }();
-        if (pp && (NPL == 1 || weights_on_w)) {
+        static const int pp = study_env("GENIE_GEMM16_PP", 1);
+#ifdef GENIE_STUDY
+        const int terms = study_terms();
+#else
+        constexpr int terms = 3;
+#endif
+        if (pp && (NPL == 1 || (weights_on_w && !weight_is_wide(W)))) {
             const int npl = (NPL == 2 && terms == 1) ? 1 : NPL;
             const int rc = launch_gemm16_pp(npl, terms, NPL == 2, A, lda, planeA, W, ldw, planeW, bias, Rf, Cf, C16, plane16,
                                             ldc, M, N, K, flags, alpha, st, batch, strideA, strideW, strideC);
@@ -561,7 +602,7 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
                                         st, batch, strideA, strideW, strideC);
         if (rc != GENIE_E_UNSUPPORTED) return rc;
     }
-    static const int force_v1 = [] { const char* e = getenv("GENIE_GEMM16_V1"); return e ? atoi(e) : 0; }();
+    static const int force_v1 = study_env("GENIE_GEMM16_V1", 0);
     // small problems (batch-1 generate: M = 4096 or 256 rows): 256x128 tiles would leave most of the 256 CUs idle, the
     // 128x128 kernel below makes 2x the workgroups (and runs two of them per CU)
     const long tiles_v2 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
@@ -573,9 +614,9 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
                        2.0 * NPL * ((double)M * K * batch + (double)N * K) +
                            mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) +
                                  (flags & G16_OUT16 ? 2 * NPL : 0)),
-                       st);
-        static const int nwn = [] { const char* e = getenv("GENIE_GEMM16_NWN"); return e ? atoi(e) : 4; }();
-        static const int big = [] { const char* e = getenv("GENIE_GEMM16_BN256"); return e ? atoi(e) : 1; }();
+                       st, NPL == 2 ? "gemm16_v2_kernel<2,...> (256x128 tile, f16x3 two-accumulator form)" : "gemm16_v2_kernel<1,...> (256x128 / 256x256 tile, bf16)");
+        static const int nwn = study_env("GENIE_GEMM16_NWN", 4);
+        static const int big = study_env("GENIE_GEMM16_BN256", 1);
         const long tiles_256 = (long)mt2 * ((N + 255) / 256) * batch;
         if constexpr (NPL == 1) {
             if (big && N % 4 == 0 && tiles_256 >= 224) {
@@ -613,11 +654,11 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
                    2.0 * NPL * ((double)M * K * batch + (double)N * K) +
                        mn * ((flags & G16_ACCUM ? 4 : 0) + (flags & G16_OUTF32 ? 4 : 0) + (flags & G16_OUT16 ? 2 * NPL : 0)),
-                   st);
+                   st, NPL == 2 ? "gemm16_nt_kernel<2,...> (128x128 tile, f16x3)" : "gemm16_nt_kernel<1,...> (128x128 tile, bf16)");
     // Problems this small (batch-1 generate: a GEMM is 21..36 us) are bound by the serial chain of K-steps -- each one a
     // barrier plus an L2 round trip -- not by throughput, and fewer workgroups than CUs are resident anyway: double the
     // K-step (128 KB of LDS, one workgroup per CU) to halve the chain.
-    static const int wide_k = [] { const char* e = getenv("GENIE_GEMM16_WIDEK"); return e ? atoi(e) : 1; }();
+    static const int wide_k = study_env("GENIE_GEMM16_WIDEK", 1);
     if (wide_k && mt * nt * batch <= 256 && K % (2 * BK) == 0) {
         (void)hipFuncSetAttribute((const void*)gemm16_nt_kernel<NPL, 2 * BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(2 * lds));
@@ -662,8 +703,12 @@ __global__ void cast16_kernel(const float* __restrict__ src, uint16_t* __restric
 // runs the f32-qkv path below.
 static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_layer_weights& lw, const uint16_t* u, size_t planeA,
                                    size_t planeW, Workspace& w, int B, uint16_t* out16, size_t out_plane, hipStream_t st) {
-    static const int on = [] { const char* e = getenv("GENIE_ATTN_DMA"); return e ? atoi(e) : 1; }();
+    static const int on = study_env("GENIE_ATTN_DMA", 1);
     const int d = c.d_model;
+#ifdef GENIE_STUDY
+    if (npl == 2 && study_terms() != 3) return GENIE_E_UNSUPPORTED;
+#endif
+    if (npl == 2 && weight_is_wide(lw.spatial.qkv_w16)) return GENIE_E_UNSUPPORTED;  // |w| >= 32: two-accumulator GEMM + f32-qkv attention
     if (!on || c.S != 256 || c.qk_norm || (c.head_dim != 64 && c.head_dim != 32) || d % 256 || d != c.num_heads * c.head_dim)
         return GENIE_E_UNSUPPORTED;
     const long n_seq = (long)B * c.T;
@@ -837,6 +882,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     const float* nwt = c.qk_norm ? lw.temporal.norm_w : nullptr;
     const float* nbt = c.qk_norm ? lw.temporal.norm_b : nullptr;
     // ---- spatial
+    GENIE_STUDY_CLASS(0);
     const uint16_t* u = xs;
     int rc = GENIE_E_UNSUPPORTED;
     bool qkv_done = false;
@@ -868,9 +914,11 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     }
     }
     GENIE_TRY(rc);
+    GENIE_STUDY_CLASS(2);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.spatial.proj_w16, d, pw_proj, c.proj_bias ? lw.spatial.proj_b : nullptr, x,
                                xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
     // ---- temporal
+    GENIE_STUDY_CLASS(1);
     float* tq = w.tqkv ? w.tqkv : qkv;
     if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
         float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
@@ -910,9 +958,11 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     }
     }
     GENIE_TRY(rc);
+    GENIE_STUDY_CLASS(3);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.temporal.proj_w16, d, pw_proj, c.proj_bias ? lw.temporal.proj_b : nullptr,
                                x, xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
     // ---- MLP
+    GENIE_STUDY_CLASS(4);
     u = xs;
     bool fc1_done = false;
     if (!c.qk_norm) {
@@ -929,6 +979,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.fc1_w16, d, pw_fc, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, hs, ph, hid, M,
                                hid, d, G16_GELU | G16_OUT16, 1.0f, st));
     }
+    GENIE_STUDY_CLASS(5);
     GENIE_TRY(launch_gemm16<2>(hs, hid, ph, lw.fc2_w16, hid, pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, xs, pd, d, M, d,
                                hid, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
     return GENIE_OK;
@@ -948,6 +999,7 @@ int readout_f16x3(const genie_cfg& c, const genie_weights& wt, const float* x, W
     const size_t pd = (size_t)B * c.T * c.S * d;
     const uint16_t* xs = (const uint16_t*)w.xn;
     float* dst = (layout == GENIE_LAYOUT_TOKEN_MAJOR) ? logits : w.logits;
+    GENIE_STUDY_CLASS(6);
     GENIE_TRY(launch_gemm16<2>(xs + (size_t)t0 * c.S * d, d, pd, wt.out_w16, d, (size_t)V * d, wt.out_b, dst, nullptr, 0,
                                V, (int)rows, V, d, G16_OUTF32, c.readout_mult, st, B, (long)c.T * c.S * d, rows * V));
     if (layout != GENIE_LAYOUT_TOKEN_MAJOR) GENIE_TRY(launch_transpose(w.logits, logits, B, (int)rows, V, st));

@@ -648,17 +648,16 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
     }
     ProfScope prof(GENIE_KC_OTHER, 2.0 * M * Cout * 9.0 * Cin, 2.0 * (M * (double)Cin + M * (double)Cout + 9.0 * Cin * Cout),
                    st);
-    static const int bk = [] { const char* e = getenv("GENIE_CONV_BK"); return e ? atoi(e) : 64; }();
-    static const int abl = [] { const char* e = getenv("GENIE_CONV_ABL"); return e ? atoi(e) : 0; }();
-    static const int slab = [] { const char* e = getenv("GENIE_CONV_SLAB"); return e ? atoi(e) : 1; }();
+    static const int bk = study_env("GENIE_CONV_BK", 64);
+    static const int abl = study_env("GENIE_CONV_ABL", 0);
+    static const int slab = study_env("GENIE_CONV_SLAB", 1);
     if (slab && stride == 1) {
         const int fl = (d2s ? CONV_D2S : 0) | abl;
         static const int n_cu = [] {
             int dev = 0, n = 0;
             (void)hipGetDevice(&dev);
             (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            const char* e = getenv("GENIE_CONV_PERSIST");  // 0: one workgroup per tile (A/B runs)
-            if (e && !atoi(e)) return 1 << 30;
+            if (!study_env("GENIE_CONV_PERSIST", 1)) return 1 << 30;  // 0: one workgroup per tile (A/B runs)
             return n > 0 ? n : 256;
         }();
         if (Cout <= 32 && !gn_part) {
@@ -833,7 +832,7 @@ __global__ __launch_bounds__(256) void gn_swish_rows_kernel(const uint16_t* __re
 static int launch_gn_apply(const uint16_t* X, const float* stats, const float* gamma, const float* beta, uint16_t* Y, int n_img,
                            int HW, int C, int groups, int apply_swish, hipStream_t st) {
     const int c8 = C / 8;
-    static const int rows = [] { const char* e = getenv("GENIE_GN_ROWS"); return e ? atoi(e) : 1; }();
+    static const int rows = study_env("GENIE_GN_ROWS", 1);
     if (rows && c8 <= 256 && 256 % c8 == 0) {
         const int ppb = 8 * (256 / c8);
         gn_swish_rows_kernel<<<dim3((HW + ppb - 1) / ppb, n_img), 256, 0, st>>>(X, stats, gamma, beta, Y, HW, C, groups, ppb,

@@ -387,7 +387,8 @@ int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long
     dim3 grid(mt * nt, batch);
     const double mnk = (double)M * N * batch;
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mnk * K,
-                   4.0 * ((double)M * K * batch + (double)N * K + mnk * ((flags & GEMM_ACCUM) ? 2 : 1)), st);
+                   4.0 * ((double)M * K * batch + (double)N * K + mnk * ((flags & GEMM_ACCUM) ? 2 : 1)), st,
+                   "gemm_f32_nt_kernel (128x128x16 tile, v_mfma_f32_32x32x2_f32)");
     gemm_f32_nt_kernel<<<grid, 256, 0, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags,
                                              alpha);
     GENIE_LAUNCH_CHECK("gemm_f32");

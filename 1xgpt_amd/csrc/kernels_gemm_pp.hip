@@ -712,12 +712,11 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
             !(flags & G16X_OUT16) || (flags & (G16X_ACCUM | G16X_GELU | G16X_OUTF32 | G16X_GELU16)) || f16 != (npl == 2) ||
             terms != 3)
             return GENIE_E_UNSUPPORTED;
-        const char* e1 = getenv("GENIE_PP_ABL");
-        const char* e2 = getenv("GENIE_PP_EPI");
-        const char* e3 = getenv("GENIE_PP_SCHED");
-        if ((e1 && atoi(e1)) || (e2 && !atoi(e2)) || (e3 && atoi(e3))) return GENIE_E_UNSUPPORTED;  // study knobs: no QKV variant
+        static const bool study_off = study_env("GENIE_PP_ABL", 0) || !study_env("GENIE_PP_EPI", 1) || study_env("GENIE_PP_SCHED", 0);
+        if (study_off) return GENIE_E_UNSUPPORTED;  // study knobs: no QKV variant
         flags |= G16X_NT;
     }
+    if (!kStudyBuild && ((npl == 1 && f16) || (npl == 2 && terms != 3))) return GENIE_E_UNSUPPORTED;  // study-only forms
     if (M < 256 || M % 256 || N % 256 || K % (2 * bk) || K < 2 * bk) return GENIE_E_UNSUPPORTED;
     if (lda % 8 || ldw % 8 || ldc % 4 || ((flags & G16X_OUT16) && !(flags & (G16X_QKV | G16X_OUTF32 | G16X_ACCUM)) && ldc % 8))
         return GENIE_E_UNSUPPORTED;  // (16-byte stores of the 16-bit-only epilogue)
@@ -725,27 +724,27 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     if ((double)(npl - 1) * planeA * 2 + 256.0 * lda * 2 + 2.0 * K >= 4.0e9) return GENIE_E_UNSUPPORTED;
     if ((double)(npl - 1) * planeW * 2 + 256.0 * ldw * 2 + 2.0 * K >= 4.0e9) return GENIE_E_UNSUPPORTED;
     const long tiles = (long)(M / 256) * (N / 256) * batch;
-    static const long min_tiles = [] { const char* e = getenv("GENIE_GEMM16_PP_MIN_TILES"); return e ? atol(e) : 192L; }();
+    static const long min_tiles = study_env("GENIE_GEMM16_PP_MIN_TILES", (int)(192));
     if (tiles < min_tiles) return GENIE_E_UNSUPPORTED;
     const double mn = (double)M * N * batch;
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
                    2.0 * npl * ((double)M * K * batch + (double)N * K) +
                        mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) +
                              (flags & G16X_OUT16 ? (plane16 ? 4 : 2) : 0)),
-                   st);
+                   st, npl == 2 ? (terms == 3 ? "gemm16_pp_kernel<2,3,true,...> (256x256 tile, two-group phase schedule, 3x v_mfma_f32_32x32x16_f16 per algorithmic MFMA into one accumulator)" : "gemm16_pp_kernel<2,2,...> (STUDY: 2 of 3 split terms)")
+                                 : (f16 ? "gemm16_pp_kernel<1,1,true,...> (STUDY: plain f16)" : "gemm16_pp_kernel<1,1,false,...> (256x256 tile, two-group phase schedule, v_mfma_f32_32x32x16_bf16)"));
     // persistent: one workgroup per CU (128 KB of LDS: one fits), each walking tiles bid, bid + grid.x, ...
     static const int n_cu = [] {
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        const char* e = getenv("GENIE_PP_PERSIST");   // 0: one workgroup per tile (the non-persistent launch, for A/B runs)
-        if (e && !atoi(e)) return 1 << 30;
+        if (!study_env("GENIE_PP_PERSIST", 1)) return 1 << 30;   // 0: one workgroup per tile (the non-persistent launch, for A/B runs)
         return n > 0 ? n : 256;
     }();
     const long tiles_x = (long)(M / 256) * (N / 256);
     const dim3 grid((unsigned)(tiles_x < n_cu ? tiles_x : n_cu), (unsigned)batch);
-    static const int stagger = [] { const char* e = getenv("GENIE_PP_STAGGER"); return e ? atoi(e) : 0; }();
-    static const long stagger_min = [] { const char* e = getenv("GENIE_PP_STAGGER_MIN_TILES"); return e ? atol(e) : 1024L; }();
+    static const int stagger = study_env("GENIE_PP_STAGGER", 0);
+    static const long stagger_min = study_env("GENIE_PP_STAGGER_MIN_TILES", (int)(1024));
     if (stagger > 1 && batch == 1 && tiles >= stagger_min) flags |= (stagger & 15) << 8;
     constexpr size_t lds = 2 * PP_BUF;
 #define PP_LAUNCH(NPL_, TERMS_, F16_, ABL_, SCHED_)                                                                       \
@@ -761,14 +760,16 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
         if (npl == 1) PP_LAUNCH(1, 1, false, ABL_, 0);                                                                    \
         else PP_LAUNCH(2, 3, true, ABL_, 0);                                                                              \
     } while (0)
-    static const int abl = [] { const char* e = getenv("GENIE_PP_ABL"); return e ? atoi(e) : 0; }();
-    static const int sched = [] { const char* e = getenv("GENIE_PP_SCHED"); return e ? atoi(e) : 0; }();
-    static unsigned long long* tbuf = nullptr;
+    static const int sched = study_env("GENIE_PP_SCHED", 0);
+#ifdef GENIE_STUDY
+    static const int abl = study_env("GENIE_PP_ABL", 0);
     const size_t n_wg = (size_t)tiles_x;
+    static unsigned long long* tbuf = nullptr;
     if ((abl == 32 || abl == 33) && !tbuf) {
         (void)hipMalloc(&tbuf, sizeof(unsigned long long) * 4 * 65536);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_timing), &tbuf, sizeof(tbuf));
     }
+    if ((abl == 32 || abl == 33) && n_wg > 65536) return GENIE_E_UNSUPPORTED;   // the stamp buffer holds 65536 tiles
     if (abl == 1) PP_LAUNCH_ABL(1);
     else if (abl == 2) PP_LAUNCH_ABL(2);
     else if (abl == 3) PP_LAUNCH_ABL(3);
@@ -782,7 +783,9 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
         else { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim); }
     }
-    else {
+    else
+#endif
+    {
         // compile-time epilogues for the model's Linear flavours (qkv / readout: OUTF32; proj, fc2: ACCUM | OUTF32 [| OUT16];
         // fc1: GELU | OUT16), each with and without non-temporal stores; anything else takes the run-time-flag kernel
         const int e = flags & 127;
@@ -809,7 +812,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
             default: break;                                                                                               \
         }
         bool done = false;
-        static const int epi = [] { const char* e2 = getenv("GENIE_PP_EPI"); return e2 ? atoi(e2) : 1; }();
+        static const int epi = study_env("GENIE_PP_EPI", 1);
         const bool out_kind_ok = !(flags & G16X_OUT16) || (flags & G16X_QKV) || (npl == 2 ? plane16 != 0 : plane16 == 0);
         if (epi && sched == 0 && terms == 3 && out_kind_ok) {
 #define PP_SCHED 0
@@ -820,13 +823,20 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
 #undef PP_EPI_ALL
 #undef PP_EPI
         if (done) {
-        } else if (npl == 1 && !f16) { if (sched == 0) PP_LAUNCH(1, 1, false, 0, 0); else if (sched == 2) PP_LAUNCH(1, 1, false, 0, 2); else PP_LAUNCH(1, 1, false, 0, 1); }
-        else if (npl == 1) PP_LAUNCH(1, 1, true, 0, 0);
-        else if (terms == 2) PP_LAUNCH(2, 2, true, 0, 0);
-        else { if (sched == 0) PP_LAUNCH(2, 3, true, 0, 0); else if (sched == 2) PP_LAUNCH(2, 3, true, 0, 2); else PP_LAUNCH(2, 3, true, 0, 1); }
+        }
+#ifdef GENIE_STUDY
+        else if (npl == 1 && !f16 && sched) { if (sched == 2) PP_LAUNCH(1, 1, false, 0, 2); else PP_LAUNCH(1, 1, false, 0, 1); }
+        else if (npl == 1 && f16) PP_LAUNCH(1, 1, true, 0, 0);
+        else if (npl == 2 && terms == 2) PP_LAUNCH(2, 2, true, 0, 0);
+        else if (npl == 2 && sched) { if (sched == 2) PP_LAUNCH(2, 3, true, 0, 2); else PP_LAUNCH(2, 3, true, 0, 1); }
+#endif
+        else if (npl == 1 && !f16) PP_LAUNCH(1, 1, false, 0, 0);
+        else if (npl == 2 && terms == 3) PP_LAUNCH(2, 3, true, 0, 0);
+        else return GENIE_E_UNSUPPORTED;   // plain-f16 / 2-term forms exist in the study build only
     }
 #undef PP_LAUNCH
 #undef PP_LAUNCH_ABL
+#ifdef GENIE_STUDY
     if ((abl == 32 || abl == 33) && n_wg <= 16384 && batch == 1) {  // debug study: average the stamps of this launch (synchronises!)
         static unsigned long long host[4 * 16384];
         (void)hipStreamSynchronize(st);
@@ -844,6 +854,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
                         "ticks per workgroup, 100 MHz clock?)  span %.0f\n",
                 npl, M, N, K, n_wg, pro / n_wg, loop / n_wg, epi / n_wg, (double)(t1 - t0));
     }
+#endif
     GENIE_LAUNCH_CHECK("gemm16_pp");
     return GENIE_OK;
 }

@@ -277,8 +277,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
 int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                      const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N, int K,
                      int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC) {
-    static const int on = [] { const char* e = getenv("GENIE_GEMM16_SM"); return e ? atoi(e) : 1; }();
-    static const long max_out = [] { const char* e = getenv("GENIE_GEMM16_SM_MAX"); return e ? atol(e) : 1L << 20; }();
+    static const int on = study_env("GENIE_GEMM16_SM", 1);
+    static const long max_out = study_env("GENIE_GEMM16_SM_MAX", (int)(1L << 20));
     if (!on || (long)M * N * batch > max_out) return GENIE_E_UNSUPPORTED;
     if (N % 4 || ldc % 4 || lda % 8 || ldw % 8 || planeA % 8 || planeW % 8) return GENIE_E_UNSUPPORTED;
     if (npl == 2 && (flags & G16X_OUT16) && plane16 == 0) return GENIE_E_UNSUPPORTED;
@@ -291,7 +291,7 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
                    2.0 * npl * ((double)M * K * batch + (double)N * K) +
                        mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) +
                              (flags & G16X_OUT16 ? 2 * npl : 0)),
-                   st);
+                   st, "gemm16_sm_kernel (32x64 / 32x32 tile, in-workgroup split-K, no LDS ring)");
     // tile 32x64 unless that leaves most CUs idle (N = 512 at M = 256: 64 tiles) or the ring would not fit (K/8 > 64 with
     // split operands) -> 32x32
     const long t64 = (long)((M + 31) / 32) * ((N + 63) / 64) * batch;
@@ -326,9 +326,9 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
 int launch_gemm16_sm_ln(int npl, const float* x, long ldx, const float* ln_g, const float* ln_b, float eps, const uint16_t* W,
                         long ldw, long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc,
                         int M, int N, int K, int flags, float alpha, hipStream_t st) {
-    static const int on = [] { const char* e = getenv("GENIE_GEMM16_SM_LN"); return e ? atoi(e) : 1; }();
-    static const int sm_on = [] { const char* e = getenv("GENIE_GEMM16_SM"); return e ? atoi(e) : 1; }();
-    static const long max_out = [] { const char* e = getenv("GENIE_GEMM16_SM_MAX"); return e ? atol(e) : 1L << 20; }();
+    static const int on = study_env("GENIE_GEMM16_SM_LN", 1);
+    static const int sm_on = study_env("GENIE_GEMM16_SM", 1);
+    static const long max_out = study_env("GENIE_GEMM16_SM_MAX", (int)(1L << 20));
     if (!on || !sm_on || (long)M * N > max_out || (K != 512 && K != 256)) return GENIE_E_UNSUPPORTED;
     if (N % 4 || ldc % 4 || ldx % 4 || ldw % 8 || planeW % 8) return GENIE_E_UNSUPPORTED;
     if (npl == 2 && (flags & G16X_OUT16) && plane16 == 0) return GENIE_E_UNSUPPORTED;
@@ -336,7 +336,7 @@ int launch_gemm16_sm_ln(int npl, const float* x, long ldx, const float* ln_g, co
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mn * K,
                    4.0 * (double)M * K + 2.0 * npl * (double)N * K +
                        mn * ((flags & G16X_ACCUM ? 4 : 0) + (flags & G16X_OUTF32 ? 4 : 0) + (flags & G16X_OUT16 ? 2 * npl : 0)),
-                   st);
+                   st, "gemm16_sm_ln_kernel (LayerNorm in the fragment path, in-workgroup split-K)");
     const long t64 = (long)((M + 31) / 32) * ((N + 63) / 64);
     const int tn = t64 >= 96 ? 64 : 32;
     const dim3 grid((unsigned)(((M + 31) / 32) * ((N + tn - 1) / tn)), 1);

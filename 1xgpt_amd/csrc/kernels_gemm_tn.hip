@@ -143,7 +143,7 @@ int launch_wgrad16_tn(const uint16_t* dY, long ldy, const uint16_t* X, long ldx,
     if ((size_t)N * K > slab_floats) return GENIE_E_UNSUPPORTED;
     GENIE_CHECK_ARG(beta == 0.f || beta == 1.f, "wgrad: beta must be 0 or 1");
     const int tiles = (N / 128) * (K / 128);
-    static const int want = [] { const char* e = getenv("GENIE_TN_WGS"); return e ? atoi(e) : 512; }();  // 2 per CU: 256 / 1024 / 2048 measured 5 / 2 / 8 % slower
+    static const int want = study_env("GENIE_TN_WGS", 512);  // 2 per CU: 256 / 1024 / 2048 measured 5 / 2 / 8 % slower
     int ns = 1;
     while (ns < 64 && tiles * ns < want && Mtok % (64 * ns * 2) == 0 && (size_t)(ns * 2) * N * K <= slab_floats) ns *= 2;
     const size_t lds = 2 * 2 * 64 * 256;

@@ -224,7 +224,7 @@ static TrainWs16 train_ws16(const genie_cfg& c, int B, int npl, void* base, size
 // bf16: the weight gradient runs on the TN kernel (kernels_gemm_tn.hip) from row-major operands when the shapes allow, and then
 // neither the gradient nor the saved activation needs a transposed copy (GENIE_WGRAD_TN=0: the transposed-copy path, for A/B)
 static bool use_tn(int npl, int M, int N, int K) {
-    static const int tn = [] { const char* e = getenv("GENIE_WGRAD_TN"); return e ? atoi(e) : 1; }();
+    static const int tn = study_env("GENIE_WGRAD_TN", 1);
     return tn && npl == 1 && M % 64 == 0 && N % 256 == 0 && K % 128 == 0;
 }
 // 16-bit copies of a gradient matrix (row-major, and transposed unless its weight gradient takes the TN kernel: Kw = the K of

@@ -64,13 +64,16 @@ class GenieEvaluator:
     # ------------------------------------------------------------------ teacher-forced prefix reuse
     @torch.no_grad()
     def predict_zframe_logits_reuse(self, input_ids: torch.LongTensor, noise=None, return_logits=True,
-                                    unmask_mode="random"):
+                                    unmask_mode="random", step0_hook=None):
         """Same contract and same per-row arithmetic as ``predict_zframe_logits`` in (1 + steps) passes over T-1 frames
         instead of 15 * steps forwards over T: the ground-truth frames < t of every timeline t are identical to one clean
         pass (temporal attention is causal, everything else per-frame), so they are computed once (frames 0..T-2: no
         timeline has the last frame as context) and their temporal keys/values cached; "frame t of timeline t" is then
         decoded for t = 1..T-1 together (genie_clean_pass / genie_masked_frames_logits with frame0 = 1).
-        Returns (samples (B,T-1,H,W), logits (B,512,2,T-1,H,W))."""
+        Returns (samples (B,T-1,H,W), logits (B,512,2,T-1,H,W)).
+        step0_hook(logits_token_major (B,T-1,S,V)): called right after the step-0 pass is enqueued, while the logits buffer
+        still holds the step-0 logits (later steps overwrite it in place); with a hook and return_logits=False no copy of the
+        (2 GB at 128 clips) logits is kept."""
         import math
         lib = _lib.load()
         m = self.model
@@ -103,7 +106,10 @@ class GenieEvaluator:
                                                       logits.data_ptr(), ws.data_ptr(), ws.numel(), st),
                        "genie_masked_frames_logits")
             if step == 0:
-                logits0 = logits.clone() if steps > 1 else logits
+                if step0_hook is not None:
+                    step0_hook(logits)
+                if return_logits or step0_hook is None:
+                    logits0 = logits.clone() if steps > 1 else logits
             uni = None
             if temperature > 1e-8:
                 uni = torch.rand(m.config.num_factored_vocabs, B * n, S, device=dev)
@@ -140,17 +146,19 @@ class GenieEvaluator:
         ids = input_ids.to(self.device).to(torch.int64).view(-1, T, S)
         lab = ids if labels is None else labels.to(self.device).to(torch.int64).view(-1, T, S)
         B = ids.shape[0]
-        samples, _ = self.predict_zframe_logits_reuse(ids, noise=noise, return_logits=False)
-        lg0 = self._last_token_major_logits0  # (B,T-1,S,V) token-major: clip frames 1..T-1
         lab = lab.contiguous()
         ids = ids.contiguous()
         st = torch.cuda.current_stream().cuda_stream
         ce = torch.zeros(3, dtype=torch.float64, device=ids.device)
         sums = torch.zeros(6, dtype=torch.float64, device=ids.device)
         cfg = m._weights()[0]
-        # logits hold frames [1, T) of the clip; targets are indexed in the full (B,T,S) clip
-        _lib.check(lib.genie_factored_ce(cfg, lg0.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, lab.data_ptr(), 0, B, 1, T,
-                                         ce.data_ptr(), st), "genie_factored_ce")
+
+        def ce_of_step0(lg0):  # (B,T-1,S,V) token-major, clip frames 1..T-1; targets are indexed in the full (B,T,S) clip
+            _lib.check(lib.genie_factored_ce(cfg, lg0.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, lab.data_ptr(), 0, B, 1, T,
+                                             ce.data_ptr(), st), "genie_factored_ce")
+
+        # the CE is taken from the step-0 logits on the stream BEFORE the next MaskGIT step overwrites them: no 2 GB copy
+        samples, _ = self.predict_zframe_logits_reuse(ids, noise=noise, return_logits=False, step0_hook=ce_of_step0)
         # (ground truth frames 1..T-1 == samples).sum() and the vector's sizes, on the device (no torch arithmetic)
         _lib.check(lib.genie_metric_hits(ids.data_ptr() + S * 8, T * S, samples.data_ptr(), (T - 1) * S, B, (T - 1) * S,
                                          ce.data_ptr(), float(B * (T - 1) * S), float(B * (T - 1)), float(B), sums.data_ptr(), st),

@@ -69,8 +69,9 @@ class STMaskGIT(nn.Module):
         # output_mult/width_mult (reference :316-323) is applied inside the readout GEMM (cfg.readout_mult).
         self.out_x_proj = nn.Linear(config.d_model, config.factored_vocab_size * config.num_factored_vocabs)
         self.config = config
-        self.set_precision(precision)
         self._table = None
+        self._wide = []
+        self.set_precision(precision)
         self._ws = None
         self.requires_grad_(False)
 
@@ -80,16 +81,16 @@ class STMaskGIT(nn.Module):
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
         self.precision = precision
         self._prec = _PRECISIONS[precision]
-        self._table = None
+        self._invalidate()
         return self
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move parameters: cached pointers are stale
-        self._table = None
+        self._invalidate()
         self._ws = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._table = None
+        self._invalidate()
         return super().load_state_dict(*a, **k)
 
     def _device(self):
@@ -100,7 +101,23 @@ class STMaskGIT(nn.Module):
 
     def refresh_weights(self):
         """Rebuild the device pointer table (and bf16 copies).  Call after mutating parameters in place."""
+        self._invalidate()
+
+    def _invalidate(self):
+        """Forget the cached pointer table (and the library's range hints for its packed tensors)."""
+        self._drop_wide_hints()
         self._table = None
+
+    def _drop_wide_hints(self):
+        for ptr in getattr(self, "_wide", None) or []:
+            try:
+                _lib.load().genie_weight_range_hint(ptr, 0)
+            except Exception:
+                pass
+        self._wide = []
+
+    def __del__(self):
+        self._drop_wide_hints()
 
     def _weights(self):
         if self._table is not None:
@@ -113,6 +130,7 @@ class STMaskGIT(nn.Module):
         cfg = _lib.make_cfg(self.config, self._prec)
         _lib.check(lib.genie_check_config(cfg), "genie_check_config")
         keep = []
+        wide = []   # packed pointers registered with genie_weight_range_hint (unregistered when the table is rebuilt / dropped)
         packed = None
         st = torch.cuda.current_stream().cuda_stream
         if self._prec == _lib.PREC_BF16:
@@ -129,11 +147,19 @@ class STMaskGIT(nn.Module):
                 _lib.check(lib.genie_pack_split_f16(wt.data_ptr(), t.data_ptr(), wt.numel(), st),
                            "genie_pack_split_f16")
                 # the 256x256 GEMM multiplies the weight's hi plane by 2^11 in registers (gemm16_pp): exact below 32 only.
-                # Checked on the packed plane at load time (inf / > 31.98 would overflow f16): a checkpoint with such a
-                # weight must run in `exact` or `bf16`.
-                if not bool(torch.isfinite(t[0]).all()) or float(t[0].abs().max()) >= 31.98:
-                    raise ValueError("f16x3 precision needs |weight| < 32 (the split GEMM scales the weight's hi plane by 2^11 in "
-                                     "f16); this checkpoint has a larger or non-finite weight -- use precision='exact' or 'bf16'")
+                # Checked on the packed plane at load time.  A tensor that reaches 32 (but is finite in f16) is registered with the
+                # library, which then runs every Linear reading it on the two-accumulator kernels (no operand scaling; same
+                # f32-class result, slower for that tensor only).  Beyond the f16 range the precision cannot represent it.
+                if not bool(torch.isfinite(t[0]).all()):
+                    raise ValueError("f16x3 precision needs finite |weight| < 65504 (the f16 range of the split's hi plane); this "
+                                     "checkpoint has a larger or non-finite weight -- use precision='exact' or 'bf16'")
+                if float(t[0].abs().max()) >= 31.98:
+                    import warnings
+                    _lib.check(lib.genie_weight_range_hint(t.data_ptr(), 1), "genie_weight_range_hint")
+                    wide.append(t.data_ptr())
+                    warnings.warn(f"f16x3: a weight tensor of shape {tuple(wt.shape)} has |w| >= 32 (max {float(wt.abs().max()):.3g}): "
+                                  "its Linear runs on the two-accumulator split GEMM instead of the 256x256 kernel (same results, "
+                                  "lower throughput for that layer)")
                 keep.append(t)
                 return t.data_ptr()
 
@@ -149,6 +175,7 @@ class STMaskGIT(nn.Module):
             w.out_w16 = packed(self.out_x_proj.weight)
         w.layers_host = layers
         self._table = (cfg, w, layers, keep)
+        self._wide = wide
         return self._table
 
     def _workspace(self, B):
@@ -351,7 +378,7 @@ class STMaskGIT(nn.Module):
                     module.bias.data.zero_()
             elif isinstance(module, nn.Embedding):
                 module.weight.data.normal_(mean=0.0, std=std)
-        self._table = None
+        self._invalidate()
 
     def set_mup_shapes(self, rescale_params=False):
         """The reference attaches muP infshapes for training (:298-304).  At inference the only effect is the

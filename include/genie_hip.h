@@ -113,6 +113,13 @@ int genie_pack_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 /* f32 -> f16 split planes for GENIE_PREC_F16X3: dst[0..n) = hi, dst[n..2n) = lo with src ~ hi + lo/2048.
  * In that precision the *_w16 pointers of the weight tables point at such 2n-element buffers. */
 int genie_pack_split_f16(const float* src, uint16_t* dst, size_t n, void* stream);
+/* GENIE_PREC_F16X3 range contract per weight tensor.  The chip-filling split GEMM scales the weight's hi plane by 2^11 in f16
+ * registers, which is exact for |w| < 32 only.  A caller that packs a tensor whose hi plane reaches 32 (finite in f16, i.e.
+ * |w| < 65504) registers its packed pointer here (wide = 1) BEFORE the first forward; every Linear reading that pointer then
+ * runs on the two-accumulator kernels, which scale nothing (same f32-class result, lower rate for that tensor only).
+ * wide = 0 removes the entry (call it before freeing or re-packing the buffer).  Process-global, thread-safe.
+ * Reference counterpart: none (the reference's Linear layers are f32: st_transformer.py:16-25, attention.py:27-29). */
+int genie_weight_range_hint(const void* w16, int wide);
 
 /* ---- unit entry points (one reference op each; used by the parity tests) -------------------------- */
 
@@ -262,6 +269,13 @@ enum { GENIE_KC_GEMM = 0, GENIE_KC_ATTN_SPATIAL = 1, GENIE_KC_ATTN_TEMPORAL = 2,
 int genie_profile_enable(int class_mask); /* 0 disables */
 int genie_profile_reset(void);
 int genie_profile_read(int kernel_class, double* out4);
+/* Which kernels the timed launches of one class actually were: one line per distinct kernel,
+ * "name\tlaunches\tmilliseconds\tflops\n", written NUL-terminated into buf (truncated at buf_bytes).  bench.py derives
+ * roofline.kernel from this instead of assuming the dispatch (a small batch or an override routes elsewhere). */
+int genie_profile_kernels(int kernel_class, char* buf, size_t buf_bytes);
+/* 1 when the library was compiled with -DGENIE_STUDY (ablation / reduced-precision knobs are live: measurements of such a
+ * build are study data, never the product's), 0 for the shipping build, whose launch paths read no such knob. */
+int genie_study_build(void);
 
 /* LFQ.get_codebook_entry(...).flip(1) (lookup_free_quantize.py:181-194, visualize.py:115):
  * ids (n, hw) int64 -> z (n, bits, hw) float32 in {-1,+1}, channel c = bit c (LSB first). */

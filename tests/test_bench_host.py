@@ -22,15 +22,25 @@ def test_board_sampler_window(tmp_path):
     s.path = str(tmp_path / "board.jsonl")
     t = 1000.0
     rows = [(t - 1.0, 300.0, 150.0), (t + 0.1, 1390.0, 1600.0), (t + 0.6, 1400.0, 1500.0), (t + 5.0, 280.0, 120.0)]
-    with open(s.path, "w") as f:
-        for ts, p, clk in rows:
-            f.write(json.dumps({"t": ts, "cards": {"card0": (p, clk), "card1": (1.0, 2.0)}}) + "\n")
-        f.write("not json\n")
-    out = s.window(t, t + 1.0, 0)
-    assert out["samples"] == 2
+    # the busy GPU is rocm-smi's card3 (a one-GPU lease on a multi-GPU box: torch calls it cuda:0), card0 idles
+    def write():
+        with open(s.path, "w") as f:
+            f.write(json.dumps({"bus": {"card0": "0000:05:00.0", "card3": "0000:85:00.0"}}) + "\n")
+            for ts, p, clk in rows:
+                f.write(json.dumps({"t": ts, "cards": {"card3": (p, clk), "card0": (1.0, 2.0)}}) + "\n")
+            f.write("not json\n")
+    write()
+    out = s.window(t, t + 1.0, "0000:85:00.0")            # matched by PCI bus id
+    assert out["samples"] == 2 and out["card"] == "card3" and "pci" in out["card_matched_by"]
     assert abs(out["socket_power_w_avg"] - 1395.0) < 1e-9 and out["socket_power_w_max"] == 1400.0
     assert abs(out["sclk_mhz_avg"] - 1550.0) < 1e-9 and out["sclk_mhz_min"] == 1500.0
     assert not os.path.exists(s.path)
+    write()
+    out = s.window(t, t + 1.0, None)                      # no bus id: the card that draws the power
+    assert out["card"] == "card3" and "power" in out["card_matched_by"] and out["samples"] == 2
+    write()
+    out = s.window(t, t + 1.0, "0000:05:00.0")            # the idle card, if that IS the device
+    assert out["card"] == "card0" and out["socket_power_w_max"] == 1.0
 
 
 def test_board_sampler_without_samples(tmp_path):
@@ -38,7 +48,7 @@ def test_board_sampler_without_samples(tmp_path):
     s = bench.BoardSampler.__new__(bench.BoardSampler)
     s.proc = None
     s.path = str(tmp_path / "none.jsonl")
-    assert s.window(0.0, time.time(), 0) is None
+    assert s.window(0.0, time.time(), None) is None
 
 
 def test_pass_flops_counts_every_linear_and_attention_product():

@@ -1,0 +1,141 @@
+"""GPU (-m gpu): the EXACT configuration bench.py reports -- GENIE_138M shape (L=32, d=512; H=8 and the H=16 variant),
+f16x3, teacher-forced evaluate with prefix reuse at chip-filling batches (every GEMM on gemm16_pp_kernel, the QKV operand-plane
+epilogue, attn_spatial_dma_kernel, attn_temporal_prefix_f32_mfma_kernel together) -- against
+
+  * the REFERENCE's own run of that workload on bench.py's weights and clip 0 (tests/golden/ev_c138*.npz, made by
+    tools/make_goldens.py c138_ev / c138_ev_h16 from genie/evaluate.py:82-122 + eval_utils.compute_loss),
+  * this library's full-forward schedule (the reference's 15 x maskgit_steps forwards) on the same clips and draws,
+  * itself at other batch sizes (64 clips = BASELINE config 4's per-GPU shard: batch independence, CE = mean of per-clip CEs).
+
+ids are held bit-exact on every timestep whose smallest top-2 logit gap in the reference run (ev_frame_gap) exceeds the f32
+accumulation-order noise; the fragile timesteps (a gap of 1e-5 cannot survive ANY reordering of an f32 sum) to near-equality."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROBUST = 6e-5   # top-2 gap of the reference run below which f32 accumulation order may flip an argmax (as test_hip_configs.py)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def make_ev(cfg, sd, precision, steps=2):
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+    H = W = math.isqrt(cfg.S)
+    args = SimpleNamespace(maskgit_steps=steps, temperature=0, latent_h=H, latent_w=W)
+    return pkg("evaluate").GenieEvaluator(args, None, "cuda", model=m)
+
+
+def batch_with_golden(z, cfg, B, seed):
+    """B clips: the reference's clip at positions 0 and B-1 (with the reference's unmasking draws), synthetic clips between."""
+    synth = pkg("synthetic")
+    ids = np.concatenate([z["ids"], synth.make_clips(B - 2, cfg, seed=seed), z["ids"]], 0)
+    noise = synth.make_noise((cfg.T - 1, 1, B, cfg.S), seed=seed + 1)
+    noise[:, :, 0] = z["ev_noise"][:, :, 0]
+    noise[:, :, B - 1] = z["ev_noise"][:, :, 0]
+    return ids, noise
+
+
+def check_samples_against_reference(z, samples_clip, what):
+    """samples_clip (T-1, H, W) of the golden clip: exact on robust timesteps, >= 97 % on fragile ones."""
+    ref = z["ev_samples"][0].astype(np.int64)
+    for k, gap in enumerate(z["ev_frame_gap"]):
+        same = samples_clip[k] == ref[k]
+        if gap > ROBUST:
+            assert same.all(), (what, "timestep", k + 1, int((~same).sum()), "mismatches at gap", gap)
+        else:
+            assert same.mean() > 0.97, (what, "timestep", k + 1, same.mean(), gap)
+
+
+@pytest.mark.parametrize("name,precision", [("ev_c138", "f16x3"), ("ev_c138_h16", "f16x3"), ("ev_c138", "exact")])
+def test_bench_config_against_reference_and_full_schedule(golden, name, precision):
+    z, cfg, sd = golden(name)
+    B = 12 if precision == "f16x3" else 4   # 12 clips x 15 frames: >= 192 tiles of 256x256 in every GEMM of the masked passes
+    ids, noise = batch_with_golden(z, cfg, B, seed=9100)
+    ev = make_ev(cfg, sd, precision)
+    eu = pkg("eval_utils")
+    d_ids, d_noise = dev(ids), dev(noise)
+    s_reuse, fl_reuse = ev.predict_zframe_logits_reuse(d_ids, noise=d_noise)
+    s_full, fl_full = ev.predict_zframe_logits(d_ids, noise=d_noise)
+    # (1) the two schedules agree on every clip: logits to f32 accumulation-order noise, ids up to fragile gaps
+    dl = (fl_full - fl_reuse).abs().max().item()
+    assert dl < 5e-5, dl
+    assert (s_full != s_reuse).float().mean().item() < 2e-3
+    # (2) the reference's clip, first and last in the batch, through both schedules, against the reference's own run
+    W = 16
+    for b in (0, B - 1):
+        for nm_, s_, fl_ in (("reuse", s_reuse, fl_reuse), ("full", s_full, fl_full)):
+            check_samples_against_reference(z, s_[b].cpu().numpy(), (name, precision, nm_, b))
+            ce = eu.compute_loss(d_ids[b:b + 1], fl_[b:b + 1].contiguous())
+            assert abs(ce - float(z["ev_loss"])) < 1e-4, (nm_, b, ce, float(z["ev_loss"]))
+            probe = np.stack([fl_[b, :, :, k, s // W, s % W].cpu().numpy() for k, s in zip(z["probe_k"], z["probe_s"])], 0)
+            assert np.abs(probe - z["probe_logits"]).max() < 5e-5, (nm_, b, np.abs(probe - z["probe_logits"]).max())
+        # per-timestep CE (localises a deviation that the 15-frame mean would dilute)
+        lab = d_ids[b].view(cfg.T, cfg.S)
+        for k in range(cfg.T - 1):
+            two = torch.cat([lab[:1], lab[k + 1:k + 2]], 0).reshape(1, -1)
+            ce_k = eu.compute_loss(two, fl_reuse[b:b + 1, :, :, k:k + 1].contiguous())
+            assert abs(ce_k - float(z["ev_loss_per_t"][k])) < 2e-4, (b, k, ce_k, float(z["ev_loss_per_t"][k]))
+    # (3) evaluate_metric_sums_reuse (what bench.py times) = the same numbers as sums
+    sums = ev.evaluate_metric_sums_reuse(d_ids, noise=d_noise).tolist()
+    ce_all = eu.compute_loss(d_ids, fl_reuse.contiguous())
+    assert abs(sums[0] / sums[1] - ce_all) < 1e-5
+    assert sums[5] == B and sums[4] == B * (cfg.T - 1)
+
+
+def test_bench_config_64_clip_shard(golden):
+    """BASELINE config 4's per-GPU shard (512 clips / 8 GPUs = 64 clips per rank) on one GPU, f16x3 + prefix reuse: the
+    reference's clip at both ends of the shard reproduces the reference's ids / CE, the shard's CE is the mean of its parts'
+    CEs (the six f64 sums add: what the RCCL all-reduce relies on), and a clip's result does not depend on its batch."""
+    z, cfg, sd = golden("ev_c138")
+    B = 64
+    ids, noise = batch_with_golden(z, cfg, B, seed=9200)
+    ev = make_ev(cfg, sd, "f16x3")
+    d_ids, d_noise = dev(ids), dev(noise)
+    total = ev.evaluate_metric_sums_reuse(d_ids, noise=d_noise)
+    samples, _ = ev.predict_zframe_logits_reuse(d_ids, noise=d_noise, return_logits=False)
+    for b in (0, B - 1):
+        check_samples_against_reference(z, samples[b].cpu().numpy(), ("shard64", b))
+    parts = torch.zeros_like(total)
+    ce_clip = {}
+    for lo, hi in ((0, 1), (1, 16), (16, 32), (32, 63), (63, 64)):
+        s = ev.evaluate_metric_sums_reuse(d_ids[lo:hi], noise=d_noise[:, :, lo:hi].contiguous())
+        parts += s
+        if hi - lo == 1:
+            ce_clip[lo] = (s[0] / s[1]).item()
+    t, p = total.tolist(), parts.tolist()
+    assert t[1] == p[1] and t[3] == p[3] and t[4] == p[4] == B * 15 and t[5] == p[5] == B
+    assert abs(t[0] / t[1] - p[0] / p[1]) < 1e-5, (t[0] / t[1], p[0] / p[1])     # different GEMM tilings at 1 / 15 / 31 / 64 clips
+    assert abs(t[2] - p[2]) <= 2e-3 * max(1.0, t[3] / 256)                        # sampled-token hits (ids up to fragile gaps)
+    for b in (0, B - 1):                                                           # the reference's clip alone
+        assert abs(ce_clip[b] - float(z["ev_loss"])) < 1e-4, (b, ce_clip[b], float(z["ev_loss"]))
+
+
+def test_bench_config_bf16_schedules_agree(golden):
+    """The throughput precision reported beside the headline: reuse and full-forward schedules agree with each other to bf16
+    noise, and sit within bf16 noise of the f32 reference (CE 5e-2; DESIGN.md section 2 -- not a parity mode)."""
+    z, cfg, sd = golden("ev_c138")
+    B = 12
+    ids, noise = batch_with_golden(z, cfg, B, seed=9300)
+    ev = make_ev(cfg, sd, "bf16")
+    eu = pkg("eval_utils")
+    d_ids, d_noise = dev(ids), dev(noise)
+    s_reuse, fl_reuse = ev.predict_zframe_logits_reuse(d_ids, noise=d_noise)
+    s_full, fl_full = ev.predict_zframe_logits(d_ids, noise=d_noise)
+    ce_r, ce_f = eu.compute_loss(d_ids, fl_reuse.contiguous()), eu.compute_loss(d_ids, fl_full.contiguous())
+    assert abs(ce_r - ce_f) < 2e-3, (ce_r, ce_f)
+    err = (fl_full - fl_reuse).abs()
+    assert err.median().item() < 1e-2 and err.max().item() < 0.5, (err.median().item(), err.max().item())
+    assert (s_full == s_reuse).float().mean().item() > 0.85
+    ce0 = eu.compute_loss(d_ids[:1], fl_reuse[:1].contiguous())
+    assert abs(ce0 - float(z["ev_loss"])) < 5e-2, (ce0, float(z["ev_loss"]))
+    # clip 0 and clip B-1 are the same clip with the same draws: identical results whatever sits between them
+    assert abs(eu.compute_loss(d_ids[-1:], fl_reuse[-1:].contiguous()) - ce0) < 2e-3

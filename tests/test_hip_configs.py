@@ -30,12 +30,14 @@ def _probe(lg, ts, ss):
 # batched shapes: 12 clips x 4096 tokens fill the chip with 256x256 GEMM tiles (kernels_gemm_pp.hip, every epilogue
 # flavour of the block: qkv OUTF32, proj ACCUM|OUTF32|OUT16, fc1 GELU|OUT16, fc2 ACCUM|OUTF32)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision,nm,tol,width", [("f16x3", O.F32, 5e-5, 512), ("bf16", O.BF16_MFMA, None, 512),
-                                                    ("f16x3", O.F32, 5e-5, 256)])
-def test_batched_forward_vs_oracle(precision, nm, tol, width):
-    """width 512 = 8 heads of 64 (GENIE_138M shape), width 256 = 8 heads of 32 (the shipped 35M config): both geometries of
-    the fused spatial-attention path (QKV GEMM writing [Q | K | V^T] operand planes -> kernels_attn_dma.hip)."""
-    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=8, d_model=width, T=16, S=256, num_factored_vocabs=2,
+@pytest.mark.parametrize("precision,nm,tol,width,heads", [("f16x3", O.F32, 5e-5, 512, 8), ("bf16", O.BF16_MFMA, None, 512, 8),
+                                                          ("f16x3", O.F32, 5e-5, 256, 8), ("f16x3", O.F32, 5e-5, 512, 16),
+                                                          ("bf16", O.BF16_MFMA, None, 512, 16)])
+def test_batched_forward_vs_oracle(precision, nm, tol, width, heads):
+    """width 512 = 8 heads of 64 (GENIE_138M shape as inferred), width 256 = 8 heads of 32 (the shipped 35M config), width 512
+    = 16 heads of 32 (GENIE_138M if its config.json says H = 16: the head count is not recoverable from the parameter count):
+    every geometry of the fused spatial-attention path (QKV GEMM writing [Q | K | V^T] operand planes -> kernels_attn_dma.hip)."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=heads, d_model=width, T=16, S=256, num_factored_vocabs=2,
                                     qk_norm=False, use_mup=False)
     synth = pkg("synthetic")
     sd = synth.make_state_dict(cfg, seed=41, law="conditioned")
@@ -109,6 +111,43 @@ def test_split_gemm_range_edges():
     back = x16[0].double() + x16[1].double() / 2048
     big = x.abs() > 1e-3
     assert ((back - x.double()).abs()[big] / x.abs().double()[big]).max().item() < 2.0 ** -21
+
+
+def test_f16x3_weight_beyond_32_falls_back_per_tensor():
+    """A checkpoint with |w| >= 32 in some tensor: that tensor's Linear leaves the 2^11-scaling 256x256
+    kernel for the two-accumulator split GEMM (genie_weight_range_hint), everything else stays where it was, and the logits
+    remain f32-class against the oracle.  Rows of the readout, of fc1 and of the spatial V projection are scaled up."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=8, d_model=512, T=16, S=256, num_factored_vocabs=2,
+                                    qk_norm=False, use_mup=False)
+    synth = pkg("synthetic")
+    sd = synth.make_state_dict(cfg, seed=41, law="conditioned")
+    sd["out_x_proj.weight"][3] *= 300.0
+    sd["decoder.layers.1.mlp.fc1.weight"][7] *= 300.0
+    sd["decoder.layers.0.spatial_attn.qkv.weight"][2 * 512 + 5] *= 300.0
+    assert max(np.abs(sd[k]).max() for k in ("out_x_proj.weight", "decoder.layers.1.mlp.fc1.weight",
+                                             "decoder.layers.0.spatial_attn.qkv.weight")) > 32
+    B = 12
+    ids = synth.make_clips(B, cfg, seed=43)
+    x = ids.reshape(B, 16, 16, 16).copy()
+    x[:, 8:] = cfg.image_vocab_size
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision="f16x3").load_numpy_state_dict(sd).to("cuda")
+    with pytest.warns(UserWarning, match="two-accumulator"):
+        lg = m.compute_logits(dev(x)).cpu().numpy()
+    assert len(m._wide) == 3
+    g = np.random.default_rng(3)
+    ts, ss = g.integers(0, 16, 48), g.integers(0, 256, 48)
+    for b in (0, B - 1):
+        ref = O.compute_logits(x[b:b + 1], sd, cfg, O.F32)
+        a, r = _probe(lg[b:b + 1], ts, ss), _probe(ref, ts, ss)
+        err = np.abs(a - r) / np.maximum(1.0, np.abs(r) / 4.0)      # channel 3 of the readout is 300x the others
+        assert err.max() < 5e-5, (b, err.max())
+    # an |w| beyond the f16 range cannot be represented by the split at all: refused at load time
+    sd["out_x_proj.weight"][3, 0] = 1.0e5
+    m2 = pkg("st_mask_git").STMaskGIT(cfg, precision="f16x3").load_numpy_state_dict(sd).to("cuda")
+    with pytest.raises(ValueError, match="65504"):
+        m2.compute_logits(dev(x[:1]))
+    m._invalidate()
+    assert m._wide == []
 
 
 # ---------------------------------------------------------------------------------------------------------------

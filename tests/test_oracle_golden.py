@@ -178,3 +178,27 @@ def test_torch_port_matches_oracle(golden):
         lg = TP.compute_logits(x, TP.to_torch(sd), cfg)
         assert np.abs(lg - z["logits"]).max() < 2e-5 * max(1.0, float(np.abs(z["logits"]).max()) / 8)
         assert np.abs(lg - O.compute_logits(x, sd, cfg)).max() < 2e-5 * max(1.0, float(np.abs(z["logits"]).max()) / 8)
+
+
+@pytest.mark.parametrize("name", ["ev_c138", "ev_c138_h16"])
+def test_bench_workload_golden(golden, name):
+    """The benchmarked workload at full size (bench.py's weights and clip 0 through the reference's teacher-forced evaluate,
+    tools/make_goldens.py c138_ev): the oracle's MaskGIT loop over the torch-CPU port of the forward reproduces the reference's
+    ids and per-timestep CE on the first and the last timestep (all 15 take ~2 minutes of CPU; the GPU suite checks all)."""
+    TP = importlib.import_module("oracle.genie_torch_port")
+    z, cfg, sd = golden(name)
+    sdt = TP.to_torch(sd)
+    x = z["ids"].reshape(1, 16, 16, 16)
+    for t in (1, 15):
+        p = x.copy()
+        p[:, t:] = cfg.image_vocab_size
+        s, fl = O.maskgit_generate(p, t, sd, cfg, 2, 0.0, "random", noise=z["ev_noise"][t - 1],
+                                   logits_fn=lambda q: TP.compute_logits(q, sdt, cfg))
+        same = s[0] == z["ev_samples"][0, t - 1]
+        if z["ev_frame_gap"][t - 1] > 6e-5:
+            assert same.all(), (t, int((~same).sum()))
+        else:
+            assert same.mean() > 0.97, (t, same.mean())
+        lab = np.concatenate([z["ids"].reshape(1, 16, 256)[:, :1], z["ids"].reshape(1, 16, 256)[:, t:t + 1]], 1).reshape(1, -1)
+        ce = O.compute_loss(lab, fl[:, :, :, None], cfg)
+        assert abs(ce - float(z["ev_loss_per_t"][t - 1])) < 1e-4, (t, ce, float(z["ev_loss_per_t"][t - 1]))

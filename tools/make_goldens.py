@@ -509,11 +509,82 @@ def generate_fixture(name, cfg_kwargs, wseed, clip_seed=300):
     print(f"{name}: frame gaps s2 {out['gen_s2_frame_gap']} s8 {out['gen_s8_frame_gap']}")
 
 
+def evaluate_fixture(name, cfg_kwargs, wseed, clip_seed=1234, noise_seed=4242):
+    """The BENCHMARKED workload at full size (bench.py: teacher-forced evaluate, genie/evaluate.py:82-122, 2 MaskGIT steps,
+    temperature 0) on bench.py's own weights (seed 0) and its clip 0 (synthetic.make_clips(.., seed=1234)[0]): the reference's
+    predict_zframe_logits + compute_loss on that clip.  The "random" unmasking draws are INJECTED (torch.rand_like returns
+    synthetic.make_noise(seed=noise_seed) slices) so that a batched GPU run can replay them for this clip beside other clips.
+    30 forwards x 512 argmax decisions: the smallest top-2 gap is recorded per timestep (robust timesteps are held to
+    bit-exact ids, fragile ones to near-equality), and the per-timestep CE so that a test can localise a deviation."""
+    model, cfg = build_ref_model(cfg_kwargs, wseed)
+    H = W = math.isqrt(cfg.S)
+    ids = synthetic.make_clips(1, cfg, seed=clip_seed)
+    noise = synthetic.make_noise((cfg.T - 1, 1, 1, cfg.S), seed=noise_seed)
+    x = torch.from_numpy(ids).reshape(1, cfg.T, H, W)
+    ref_evaluate.WINDOW_SIZE = cfg.T
+    ev = object.__new__(ref_evaluate.GenieEvaluator)
+    ev.model, ev.device, ev.decode_latents = model, "cpu", None
+    ev.args = SimpleNamespace(maskgit_steps=2, temperature=0, latent_h=H, latent_w=W)
+    gaps, draws = [], iter(noise[:, 0])
+    orig_rand_like, orig_mg, orig_logits = torch.rand_like, model.maskgit_generate, model.compute_logits
+    state = {"t": None, "gap": float("inf")}
+
+    def rand_like(t, *a, **k):
+        return torch.from_numpy(next(draws).reshape(tuple(t.shape)).copy())
+
+    def compute_logits(xx):
+        lg = orig_logits(xx)
+        f = lg[:, :, state["t"]].reshape(1, 2, 512, -1)
+        top2 = f.topk(2, dim=2).values
+        state["gap"] = min(state["gap"], float((top2[:, :, 0] - top2[:, :, 1]).min()))
+        return lg
+
+    def mg(prompt, out_t, **kw):
+        state["t"], state["gap"] = out_t, float("inf")
+        r = orig_mg(prompt, out_t, **kw)
+        gaps.append(state["gap"])
+        print(f"  {name}: timestep {out_t} min top-2 gap {state['gap']:.3e}", flush=True)
+        return r
+
+    torch.rand_like, model.maskgit_generate, model.compute_logits = rand_like, mg, compute_logits
+    try:
+        samples, fl = ev.predict_zframe_logits(torch.from_numpy(ids))
+    finally:
+        torch.rand_like, model.maskgit_generate, model.compute_logits = orig_rand_like, orig_mg, orig_logits
+    out = {"clip_seed": clip_seed, "weight_seed": wseed, "noise_seed": noise_seed, "ids": ids,
+           "ev_samples": samples.numpy().astype(np.int32), "ev_noise": noise,
+           "ev_loss": np.float64(ref_eval_utils.compute_loss(torch.from_numpy(ids), fl)),
+           "ev_acc": np.float64((x[:, 1:] == samples).float().mean().item()),
+           "ev_frame_gap": np.array(gaps, np.float64)}
+    # CE of each timestep on its own: the reference's compute_loss on a two-frame slice [frame 0, frame k+1] (it reads
+    # labels[:, 1:] and takes T from the logits, eval_utils.py:66-73)
+    per_t = []
+    clip = ids.reshape(1, cfg.T, -1)
+    for k in range(cfg.T - 1):
+        lab = torch.from_numpy(np.concatenate([clip[:, :1], clip[:, k + 1:k + 2]], 1).reshape(1, -1))
+        per_t.append(ref_eval_utils.compute_loss(lab, fl[:, :, :, k:k + 1]))
+    out["ev_loss_per_t"] = np.array(per_t, np.float64)
+    g = np.random.default_rng(5)
+    pk, ps = g.integers(0, cfg.T - 1, 64), g.integers(0, cfg.S, 64)
+    out["probe_k"], out["probe_s"] = pk, ps
+    out["probe_logits"] = np.stack([fl[0, :, :, k, s // W, s % W].numpy() for k, s in zip(pk, ps)], 0)  # (64, 512, 2)
+    out["mup_pinned"] = np.int64(1)
+    out["cfg"] = np.array(repr(cfg_kwargs))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: ev_loss={out['ev_loss']:.6f} ev_acc={out['ev_acc']:.6f} gaps {out['ev_frame_gap']}")
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["tiny", "shape", "c35", "c138", "harness", "magvit", "magvit_full", "c138_gen"]
     if "magvit_full" in which:
         magvit_full_fixture()
+    c138 = dict(num_layers=32, d_model=512, T=16, S=256, num_factored_vocabs=2, qk_norm=False, use_mup=False)
+    if "c138_ev" in which:      # not in the default list: ~2 minutes of reference forwards each
+        evaluate_fixture("ev_c138", dict(c138, num_heads=8), 0)
+    if "c138_ev_h16" in which:
+        evaluate_fixture("ev_c138_h16", dict(c138, num_heads=16), 0)
     if "c138_gen" in which:
         generate_fixture("gen_c138", dict(num_layers=32, num_heads=8, d_model=512, T=16, S=256,
                                           num_factored_vocabs=2, qk_norm=False, use_mup=False), 0)

@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Probe (GPU): do gfx950's f16 matrix instructions take SUBNORMAL f16 inputs exactly?  The packed operand split of the GEMM
+epilogues (csrc/common.hpp split_f16_x4) does not flush a subnormal hi plane, which is only correct if they do.  Prints the f16x3
+Linear of a constant subnormal operand (A side, then W side) next to the exact value; measured on MI355X: exact down to 2^-24."""
 import importlib, sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 _lib = importlib.import_module("1xgpt_amd._lib"); lib = _lib.load()
 M, N, K = 16384, 1536, 512
 st = torch.cuda.current_stream().cuda_stream
