@@ -12,21 +12,87 @@ import torch
 import torch.distributed as dist
 
 
+HIP_INIT_STALL_RC = 17   # exit code of a rank whose FIRST GPU touch did not return in time (see init_device)
+RDZV_TIMEOUT_RC = 18     # exit code of a rank whose rendezvous did not complete in time (a peer never arrived)
+
+
+def _stall_exit(what, code):
+    """Runs on a timer thread while the main thread is stuck: dump every thread's stack and leave with `code`.  The process
+    has not completed a GPU call yet (or is waiting in the rendezvous), so ending it is safe; its supervisor -- bench.py's
+    per-rank parent, which never touches the GPU -- starts a FRESH process once.  Nothing is ever re-exec'ed in place."""
+    import faulthandler
+    import sys
+    print(f"1xgpt_amd.distributed: rank {os.environ.get('RANK', '0')}: {what} -- giving up this process (exit {code})",
+          file=sys.stderr, flush=True)
+    try:
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+    except Exception:
+        pass
+    os._exit(code)
+
+
+def init_device(local_rank: int, world: int = 1):
+    """First GPU touch of this process, made robust for multi-rank starts (one of six 2-rank starts on a
+    fresh box hung before the second rank's HIP initialisation returned):
+      * staggered: rank r waits r * GENIE_HIP_INIT_STAGGER seconds (default 0.5) so that the ranks of a node do not open
+        the driver at the same instant;
+      * watched: if the touch (device query, set_device, a 1-element allocation, a synchronise) has not returned after
+        GENIE_HIP_INIT_TIMEOUT seconds (default 180; the minutes-long first `import torch` on a fresh box happens before the
+        clock starts) the process dumps its stacks and exits with HIP_INIT_STALL_RC instead of hanging its peers until a
+        collective timeout.
+    Returns the device index, or None when no GPU is visible (CPU / gloo test runs)."""
+    import threading
+    import time
+    if world > 1:
+        time.sleep(float(os.environ.get("GENIE_HIP_INIT_STAGGER", "0.5")) * local_rank)
+    limit = float(os.environ.get("GENIE_HIP_INIT_TIMEOUT", "180"))
+    timer = threading.Timer(limit, _stall_exit, (f"GPU initialisation did not return within {limit:.0f} s", HIP_INIT_STALL_RC))
+    timer.daemon = True
+    if limit > 0:
+        timer.start()
+    try:
+        if not torch.cuda.is_available():
+            return None
+        dev_index = local_device_index(local_rank)
+        torch.cuda.set_device(dev_index)
+        torch.empty(1, device=torch.device("cuda", dev_index))
+        torch.cuda.synchronize(dev_index)
+        return dev_index
+    finally:
+        timer.cancel()
+
+
 def init_distributed(backend=None):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, world_size, local_rank)."""
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world_size, local_rank).
+    Order: this rank's GPU first (init_device: staggered, watched), then the rendezvous with a bounded timeout
+    (GENIE_RDZV_TIMEOUT seconds, default 600; on expiry the rank exits with RDZV_TIMEOUT_RC rather than waiting for the
+    backend's 30-minute default)."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend != "gloo" or os.environ.get("GENIE_FORCE_DEVICE") is not None:
+        init_device(local_rank, world)   # (a pure-CPU gloo run has nothing to initialise)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("GENIE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        kwargs = {}
+        limit = float(os.environ.get("GENIE_RDZV_TIMEOUT", "600"))
+        kwargs = {"timeout": datetime.timedelta(seconds=limit)}
         if backend == "nccl":
             dev_index = local_device_index(local_rank)
             torch.cuda.set_device(dev_index)
             kwargs["device_id"] = torch.device("cuda", dev_index)
+
+        def rendezvous():
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+            except Exception as e:  # store / rendezvous timeout: a peer never arrived
+                if "imeout" in f"{type(e).__name__} {e}":
+                    _stall_exit(f"rendezvous did not complete within {limit:.0f} s ({type(e).__name__}: {e})", RDZV_TIMEOUT_RC)
+                raise
+
         if backend == "gloo":
             # gloo announces its connections on STDOUT; callers (bench.py) print exactly one JSON line there
             import sys
@@ -34,13 +100,13 @@ def init_distributed(backend=None):
             saved = os.dup(1)
             os.dup2(2, 1)
             try:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+                rendezvous()
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+            rendezvous()
     return rank, world, local_rank
 
 

@@ -202,12 +202,15 @@ class GenieEvaluator:
 
 @torch.no_grad()
 def evaluate_clips(evaluator: GenieEvaluator, clips: torch.LongTensor, batch_size=16, noise_seed=None,
-                   distributed=False, reuse=True):
+                   distributed=False, reuse=True, clip_offset=0):
     """Metric loop over ``clips`` (N, T*H*W) with the reference's AvgMetric weighting (eval_utils.py:16-25).
 
     With ``distributed=True`` every rank passes ITS shard of the clips; the six sums are all-reduced (SUM)
     once at the end -- a <= 48-byte message, latency-bound on xGMI -- so the returned means are whole-job
-    means, identical on every rank.  Returns dict(loss, acc, frames, clips, seconds, frames_per_sec)."""
+    means, identical on every rank.  Returns dict(loss, acc, frames, clips, seconds, frames_per_sec).
+    clip_offset: index of this shard's first clip in the whole job; the "random" unmasking draws of a batch are keyed by
+    (noise_seed, global index of its first clip), so a job gives the same draws however it is sharded over ranks (given
+    shard boundaries that are multiples of batch_size)."""
     dev = evaluator.device
     total = torch.zeros(6, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
@@ -217,7 +220,7 @@ def evaluate_clips(evaluator: GenieEvaluator, clips: torch.LongTensor, batch_siz
         batch = clips[i:i + batch_size]
         noise = None
         if noise_seed is not None and evaluator.args.maskgit_steps > 1:
-            g = torch.Generator(device="cpu").manual_seed(noise_seed + i)
+            g = torch.Generator(device="cpu").manual_seed(noise_seed + clip_offset + i)
             noise = torch.rand(m.config.T - 1, evaluator.args.maskgit_steps - 1, batch.shape[0], m.config.S,
                                generator=g).to(dev)
         fn = evaluator.evaluate_metric_sums_reuse if reuse else evaluator.evaluate_metric_sums

@@ -65,6 +65,42 @@ if __name__ == "__main__" and len(sys.argv) == 3 and sys.argv[1] == "--_board_sa
     _board_sampler_main(sys.argv[2])
     sys.exit(0)
 
+HIP_INIT_STALL_RC, RDZV_TIMEOUT_RC = 17, 18  # = 1xgpt_amd.distributed.HIP_INIT_STALL_RC / RDZV_TIMEOUT_RC
+
+
+def _supervise_rank(child_cmd=None):
+    """Multi-rank runs: the process the launcher started for a rank does NOT touch the GPU.  It runs the rank's work in a child
+    process and, if that child ends with HIP_INIT_STALL_RC (its first GPU touch never returned: 1xgpt_amd.distributed.init_device
+    -- seen once in six 2-rank starts on a fresh box) starts a FRESH child once; its peers meanwhile wait in their bounded
+    rendezvous.  Never an exec of a process that has initialised the GPU.  SIGTERM / SIGINT (torchrun tearing the group down)
+    are forwarded to the child.  Exits with the child's code."""
+    import signal
+    import subprocess
+    env = dict(os.environ, GENIE_BENCH_CHILD="1")
+    child = {"p": None}
+
+    def forward(signum, _frame):
+        p = child["p"]
+        if p is not None and p.poll() is None:
+            p.send_signal(signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, forward)
+    rc = 1
+    for attempt in (0, 1):
+        child["p"] = subprocess.Popen(child_cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+        rc = child["p"].wait()
+        if rc != HIP_INIT_STALL_RC or attempt == 1:
+            break
+        print(f"bench.py: rank {os.environ.get('RANK', '?')}: GPU initialisation stalled in the first process; starting a fresh "
+              "one (once)", file=sys.stderr, flush=True)
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+if (__name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("GENIE_BENCH_CHILD") != "1"
+        and os.environ.get("GENIE_BENCH_SUPERVISE", "1") != "0"):
+    _supervise_rank()
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
@@ -277,10 +313,24 @@ def spawn_ranks(n):
     if ndev < n and os.environ.get("GENIE_FORCE_DEVICE") is None:
         sys.exit(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible (set GENIE_FORCE_DEVICE=<i> and "
                  f"GENIE_DIST_BACKEND=gloo to run all ranks on one device as a plumbing check)")
+    os.environ["GENIE_BENCH_STARTED_MARKER"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"genie_bench_started_{os.getpid()}")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    sys.exit(subprocess.call(cmd, env=env))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0 and os.environ.get("GENIE_BENCH_RELAUNCH", "1") != "0":
+        # a start-up failure (a rank's GPU initialisation stalled twice, or the rendezvous timed out: the ranks exit with
+        # HIP_INIT_STALL_RC / RDZV_TIMEOUT_RC and torchrun tears the group down) gets ONE fresh launcher -- a new child of this
+        # process, which has not touched the GPU; a failure inside the measurement is not retried
+        marker = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"genie_bench_started_{os.getpid()}")
+        if not os.path.exists(marker):
+            print(f"bench.py: launcher exited with {rc} before the timed region started; starting a fresh launcher (once)",
+                  file=sys.stderr, flush=True)
+            cmd[cmd.index("--master-port") + 1] = str(_free_port())
+            rc = subprocess.call(cmd, env=env)
+        else:
+            os.remove(marker)
+    sys.exit(rc)
 
 
 def main():
@@ -380,6 +430,8 @@ def main():
         lib.genie_profile_reset()
     dist_mod.barrier()
     torch.cuda.synchronize()
+    if rank == 0 and os.environ.get("GENIE_BENCH_STARTED_MARKER"):  # start-up is over: spawn_ranks must not relaunch after this
+        open(os.environ["GENIE_BENCH_STARTED_MARKER"], "w").close()
     t0 = time.perf_counter()
     wall0 = time.time()
     sums = None

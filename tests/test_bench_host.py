@@ -63,3 +63,34 @@ def test_pass_flops_counts_every_linear_and_attention_product():
     got = bench.pass_flops(cfg, T)
     assert got >= linear                       # attention products on top of the Linear layers
     assert got <= linear * 1.5
+
+
+def test_rank_supervisor_restarts_a_stalled_first_process_once(tmp_path):
+    """bench.py's per-rank parent (multi-rank runs): a child that ends with HIP_INIT_STALL_RC (its first GPU touch never
+    returned) is replaced by ONE fresh process; any other exit code is passed through; a second stall is final."""
+    import sys
+    import pytest
+    bench = load_bench()
+    marker = tmp_path / "attempts"
+    script = ("import os,sys; p=sys.argv[1]; n=int(open(p).read()) if os.path.exists(p) else 0; open(p,'w').write(str(n+1)); "
+              "sys.exit(int(sys.argv[2 + min(n, len(sys.argv) - 3)]))")
+    for codes, want_rc, want_attempts in ((["17", "0"], 0, 2), (["17", "17"], 17, 2), (["0"], 0, 1), (["5"], 5, 1)):
+        if marker.exists():
+            marker.unlink()
+        with pytest.raises(SystemExit) as e:
+            bench._supervise_rank([sys.executable, "-c", script, str(marker)] + codes)
+        assert e.value.code == want_rc, (codes, e.value.code)
+        assert int(marker.read_text()) == want_attempts, codes
+
+
+def test_device_init_watchdog_exits_with_the_stall_code():
+    """1xgpt_amd.distributed.init_device: a first GPU touch that does not return ends the process with HIP_INIT_STALL_RC (and a
+    stack dump) instead of hanging the peers; exercised on CPU by making the device query sleep."""
+    import subprocess
+    import sys
+    code = ("import importlib, sys, time, torch; sys.path.insert(0, %r); D = importlib.import_module('1xgpt_amd.distributed'); "
+            "torch.cuda.is_available = lambda: time.sleep(60); D.init_device(0, 1)" % REPO)
+    env = dict(os.environ, GENIE_HIP_INIT_TIMEOUT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 17, (r.returncode, r.stderr[-500:])
+    assert "GPU initialisation did not return" in r.stderr

