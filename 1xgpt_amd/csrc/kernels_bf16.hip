@@ -556,9 +556,11 @@ int set_weight_wide(const void* W, int wide) {
 #ifdef GENIE_STUDY
 int g_study_gemm_class = 0, g_study_layer = 0;
 int study_terms() {
-    static const int all = study_env("GENIE_F16_TERMS", 3);
-    static const int mask = study_env("GENIE_F16_TERMS2_CLASSES", 0);
-    static const int l0 = study_env("GENIE_F16_TERMS2_LAYER_LO", 0), l1 = study_env("GENIE_F16_TERMS2_LAYER_HI", 1 << 30);
+    // re-read on every launch (study build only): tools/precision_study.py sweeps the settings inside one process
+    auto env = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+    const int all = env("GENIE_F16_TERMS", 3);
+    const int mask = env("GENIE_F16_TERMS2_CLASSES", 0);
+    const int l0 = env("GENIE_F16_TERMS2_LAYER_LO", 0), l1 = env("GENIE_F16_TERMS2_LAYER_HI", 1 << 30);
     if (all != 3) return all;
     return (((mask >> g_study_gemm_class) & 1) && g_study_layer >= l0 && g_study_layer < l1) ? 2 : 3;
 }
