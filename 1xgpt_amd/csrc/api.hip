@@ -68,6 +68,7 @@ static Workspace carve(const genie_cfg& c, int B, void* base) {
     w.fcache = nullptr;
     w.frame_t = -1;
     w.frame_T = 0;
+    w.model_T = c.T;
     return w;
 }
 
@@ -440,6 +441,7 @@ int genie_clean_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_
         return GENIE_E_UNSUPPORTED;
     }
     Workspace w = carve(c2, B, workspace);
+    w.model_T = cfg->T;
     return prefix_forward(c2, w2, ids, B, cache, true, 0, w, as_stream(stream), cache_frames);
 }
 
@@ -454,6 +456,7 @@ int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* wt, co
     genie_weights w2;
     GENIE_TRY(prefix_view(cfg, wt, B, frame0, nframes, cache_bytes, c2, w2));
     Workspace w = carve(c2, B, workspace);
+    w.model_T = cfg->T;
     hipStream_t st = as_stream(stream);
     GENIE_TRY(prefix_forward(c2, w2, frames, B, const_cast<float*>(cache), false, frame0, w, st));
     return readout(c2, w2, w.x, w, B, 0, nframes, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
@@ -469,6 +472,7 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_
     genie_cfg c1 = *cfg;
     c1.T = 1;  // every buffer of this pass is a dense (B, 1, S, *) tensor
     Workspace w = carve(c1, B, workspace);
+    w.model_T = cfg->T;
     hipStream_t st = as_stream(stream);
     genie_weights w1 = *wt;
     w1.pos_embed = wt->pos_embed + (size_t)t * cfg->S * cfg->d_model;  // pos_embed_TSC[0, t]

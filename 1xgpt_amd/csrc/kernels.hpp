@@ -19,6 +19,8 @@ struct Workspace {
     void* aux;         // (M, d) x 4 bytes: f16x3 = split planes of the LayerNorm / attention output
     size_t total;
     // teacher-forced prefix reuse (set per layer by the prefix entry points, NULL otherwise):
+    int model_T = 0;     // T of the MODEL's config (the passes below run on private copies with fewer frames): decides, once per
+                         // model, whether GENIE_PREC_BF16 keeps its temporal qkv / KV cache in bf16 (temporal_qkv16)
     float* tqkv;         // where the temporal qkv GEMM writes (clean pass: this layer's slice of the cache)
     int tq_frames = 0;   // frames per clip in the layout of `tqkv` (0 = dense: cfg.T); > cfg.T when a short clean pass fills a
                          // full-length cache (generate: prompt frames into the T-frame KV cache)
@@ -36,6 +38,14 @@ struct Workspace {
     // clean pass, last layer: only the temporal qkv (the cache entry) is needed -- the block returns right after that GEMM
     bool stop_after_tqkv = false;
 };
+
+// GENIE_PREC_BF16: the temporal qkv buffer and the temporal KV cache hold bf16 values (half the bytes of the HBM-bound temporal
+// attention kernels and of the qkv GEMM's output) whenever the bf16-input kernels cover every pass the model can run: T <= 16
+// frames, head_dim 32 / 64.  The cache slices keep their f32-sized strides (a caller sizes the cache with
+// genie_prefix_cache_bytes either way); only the first half of a slice is used.
+inline bool temporal_qkv16(const genie_cfg& c, int model_T) {
+    return c.precision == GENIE_PREC_BF16 && (model_T > 0 ? model_T : c.T) <= 16 && (c.head_dim == 32 || c.head_dim == 64);
+}
 
 // f16x3 weight tensors with |w| >= 32 (kernels_bf16.hip): kept off the 2^11-scaling single-accumulator GEMM
 bool weight_is_wide(const void* W16);
@@ -85,16 +95,16 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
                                  size_t plane = 0);
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
                                   const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
-                                  size_t plane = 0, int Tq = 0);
+                                  size_t plane = 0, int Tq = 0, bool in16 = false);
 int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
                               const float* nw, const float* nb, hipStream_t st, uint16_t* out16 = nullptr,
                               size_t plane = 0);
 int launch_attn_temporal_single(const float* cache, float* out, int B, int T, int S, int t, int d, int H, int Dh,
                                 float scale, const float* nw, const float* nb, hipStream_t st,
-                                uint16_t* out16 = nullptr, size_t plane = 0);
+                                uint16_t* out16 = nullptr, size_t plane = 0, bool in16 = false);
 int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
                                 int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
-                                uint16_t* out16 = nullptr, size_t plane = 0, int sh = 0);
+                                uint16_t* out16 = nullptr, size_t plane = 0, int sh = 0, bool in16 = false);
 int launch_layer_norm_split(const float* x, const float* g, const float* b, uint16_t* y, size_t plane, long rows, int C,
                             float eps, hipStream_t st);
 int launch_split_f16(const float* src, uint16_t* dst, size_t plane, size_t n, hipStream_t st);

@@ -774,37 +774,43 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     GENIE_TRY(rc);
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.spatial.proj_w16, d, 0, c.proj_bias ? lw.spatial.proj_b : nullptr, x, x16,
                                0, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
-    // temporal (no pre-norm): operand = bf16 shadow of x
+    // temporal (no pre-norm): operand = bf16 shadow of x.  t16: the temporal qkv (and the KV cache slices) hold bf16 -- the qkv
+    // GEMM stores 2 bytes per value instead of 4 and the attention kernels (HBM-bound) read half the bytes; softmax and both
+    // products stay f32 inside them
+    const bool t16 = temporal_qkv16(c, w.model_T);
+    const int oflag = t16 ? G16_OUT16 : G16_OUTF32;
     float* tq = w.tqkv ? w.tqkv : qkv;
+    uint16_t* tq16 = reinterpret_cast<uint16_t*>(tq);
     if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
         float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
-        GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, slot,
-                                   nullptr, 0, 3 * d, c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.S * d,
+        uint16_t* slot16 = reinterpret_cast<uint16_t*>(w.fcache) + (size_t)w.frame_t * c.S * 3 * d;
+        GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, t16 ? nullptr : slot,
+                                   t16 ? slot16 : nullptr, 0, 3 * d, c.S, 3 * d, d, oflag, 1.0f, st, B, (long)c.S * d,
                                    (long)w.frame_T * c.S * 3 * d));
         rc = launch_attn_temporal_single(w.fcache, nullptr, B, w.frame_T, c.S, w.frame_t, d, c.num_heads, c.head_dim,
-                                         c.attn_scale, nwt, nbt, st, xn16, 0);
+                                         c.attn_scale, nwt, nbt, st, xn16, 0, t16);
     } else {
     const int Tq = (w.tqkv && w.tq_frames > c.T) ? w.tq_frames : c.T;  // frames per clip in tq's layout
     if (Tq != c.T && B > 1)  // a short clean pass into a longer cache: one GEMM batch entry per clip
-        GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq, nullptr, 0,
-                                   3 * d, c.T * c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.T * c.S * d,
+        GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, t16 ? nullptr : tq,
+                                   t16 ? tq16 : nullptr, 0, 3 * d, c.T * c.S, 3 * d, d, oflag, 1.0f, st, B, (long)c.T * c.S * d,
                                    (long)Tq * c.S * 3 * d));
     else
-    GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
-                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+    GENIE_TRY(launch_gemm16<1>(x16, d, 0, lw.temporal.qkv_w16, d, 0, c.qkv_bias ? lw.temporal.qkv_b : nullptr, t16 ? nullptr : tq,
+                               t16 ? tq16 : nullptr, 0, 3 * d, M, 3 * d, d, oflag, 1.0f, st));
     if (w.stop_after_tqkv) return GENIE_OK;
     if (w.tcache) {
         rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
-                                         nwt, nbt, st, xn16, 0, w.tshift);
-        if (rc == GENIE_E_UNSUPPORTED) {
+                                         nwt, nbt, st, xn16, 0, w.tshift, t16);
+        if (rc == GENIE_E_UNSUPPORTED && !t16) {
             GENIE_TRY(launch_attn_temporal_prefix(tq, w.tcache, w.logits, B, c.T, c.S, d, c.num_heads, c.head_dim,
                                                   c.attn_scale, nwt, nbt, st, nullptr, 0, w.tshift));
             rc = launch_pack_bf16(w.logits, xn16, (size_t)M * d, st);
         }
     } else {
         rc = launch_attn_temporal_f32_mfma(tq, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale, nwt, nbt,
-                                           st, xn16, 0, Tq);
-        if (rc == GENIE_E_UNSUPPORTED) {
+                                           st, xn16, 0, Tq, t16);
+        if (rc == GENIE_E_UNSUPPORTED && !t16) {
             GENIE_CHECK_ARG(Tq == c.T || B == 1, "strided temporal qkv needs the MFMA temporal kernel (8 <= frames <= 16)");
             GENIE_TRY(launch_attn_generic(tq, w.logits, c.T, (long)B * c.S, c.S, (long)c.T * c.S, 1, c.S, d, c.num_heads,
                                           c.head_dim, c.attn_scale, 1, nwt, nbt, st));

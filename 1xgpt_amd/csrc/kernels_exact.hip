@@ -1121,6 +1121,46 @@ int launch_attn_spatial_f32_mfma(const float* qkv, float* out, int S, long n_seq
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// N contiguous values of a temporal qkv row as f32: from an f32 buffer (exact, f16x3) or from a bf16 one (GENIE_PREC_BF16 keeps
+// its temporal qkv / KV cache in bf16: half the bytes of these HBM-bound kernels; the arithmetic below stays f32)
+template <int N>
+__device__ __forceinline__ void load_vals(const float* p, float* v) {
+    if constexpr (N >= 4) {
+#pragma unroll
+        for (int c = 0; c < N / 4; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(p + 4 * c);
+            v[4 * c] = a.x; v[4 * c + 1] = a.y; v[4 * c + 2] = a.z; v[4 * c + 3] = a.w;
+        }
+    } else {
+        const float2 a = *reinterpret_cast<const float2*>(p);
+        v[0] = a.x; v[1] = a.y;
+    }
+}
+template <int N>
+__device__ __forceinline__ void load_vals(const uint16_t* p, float* v) {
+    if constexpr (N >= 8) {
+#pragma unroll
+        for (int c = 0; c < N / 8; ++c) {
+            const uint4 a = *reinterpret_cast<const uint4*>(p + 8 * c);
+            const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[8 * c + 2 * j] = __uint_as_float(w[j] << 16);
+                v[8 * c + 2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+            }
+        }
+    } else if constexpr (N == 4) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xFFFF0000u);
+    } else {
+        const uint32_t a = *reinterpret_cast<const uint32_t*>(p);
+        v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ float load_val(const float* p) { return *p; }
+__device__ __forceinline__ float load_val(const uint16_t* p) { return bf16_to_f32(*p); }
+
 // NV (2 or 4) contiguous outputs of one row: f32, bf16 (plane == 0) or split-f16 planes
 template <int NV>
 __device__ __forceinline__ void store_row_chunk(float* out, uint16_t* out16, size_t plane, size_t oi, const float* v) {
@@ -1147,8 +1187,8 @@ __device__ __forceinline__ void store_row_chunk(float* out, uint16_t* out16, siz
     }
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float* __restrict__ qkv,
+template <int DH, typename TI>
+__global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const TI* __restrict__ qkv,
                                                                      float* __restrict__ out, long n_bs, int S,
                                                                      int d, int H, int T, int Tq, float scale,
                                                                      const float* __restrict__ nw,
@@ -1165,16 +1205,11 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     if (bs >= n_bs) return;
     const long b = bs / S, s = bs - b * S;
     const long tok_stride = (long)S * 3 * d;                       // frame t -> t+1
-    const float* base = qkv + ((size_t)(b * Tq) * S + s) * 3 * d + head * DH;
-    const float* qp = base + (size_t)(r < T ? r : T - 1) * tok_stride + g * PER;     // row t = r
+    const TI* base = qkv + ((size_t)(b * Tq) * S + s) * 3 * d + head * DH;
+    const TI* qp = base + (size_t)(r < T ? r : T - 1) * tok_stride + g * PER;     // row t = r
     float q[PER], k[PER];
-#pragma unroll
-    for (int c = 0; c < PER / 4; ++c) {
-        float4 a = *reinterpret_cast<const float4*>(qp + 4 * c);
-        float4 bb = *reinterpret_cast<const float4*>(qp + d + 4 * c);
-        q[4 * c] = a.x; q[4 * c + 1] = a.y; q[4 * c + 2] = a.z; q[4 * c + 3] = a.w;
-        k[4 * c] = bb.x; k[4 * c + 1] = bb.y; k[4 * c + 2] = bb.z; k[4 * c + 3] = bb.w;
-    }
+    load_vals<PER>(qp, q);
+    load_vals<PER>(qp + d, k);
     if (nw) {  // qk-norm, f32, one shared affine (attention.py:42-47); row spread over the 4 lane groups
         float sq = 0.f, sk = 0.f;
 #pragma unroll
@@ -1216,18 +1251,10 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
     // O = P V.  Feature permutation: MFMA column r of "d-tile" c is feature NV*r + c, so a lane fetches NV
     // CONTIGUOUS features of V[4g+e] (16 lanes = one 4*DH-byte row segment) and later stores NV contiguous outputs.
     constexpr int NV = DH / 16;
-    const float* vp = base + 2 * d + NV * r;
+    const TI* vp = base + 2 * d + NV * r;
     float vv[4][NV];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if constexpr (NV == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(vp + (size_t)(4 * g + e < T ? 4 * g + e : T - 1) * tok_stride);
-            vv[e][0] = t.x; vv[e][1] = t.y; vv[e][2] = t.z; vv[e][3] = t.w;
-        } else {
-            const float2 t = *reinterpret_cast<const float2*>(vp + (size_t)(4 * g + e < T ? 4 * g + e : T - 1) * tok_stride);
-            vv[e][0] = t.x; vv[e][1] = t.y;
-        }
-    }
+    for (int e = 0; e < 4; ++e) load_vals<NV>(vp + (size_t)(4 * g + e < T ? 4 * g + e : T - 1) * tok_stride, vv[e]);
     f32x4 o[NV];
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -1249,15 +1276,24 @@ __global__ __launch_bounds__(256) void attn_temporal_f32_mfma_kernel(const float
 }
 
 // Temporal attention over 8 <= T <= 16 frames on a (B,T,S,3d) buffer; GENIE_E_UNSUPPORTED for other geometries.
+// in16: `qkv` holds bf16 values (GENIE_PREC_BF16's temporal qkv); any 1 <= T <= 16 then (there is no other bf16-input kernel:
+// rows >= T of the 16x16 tile are padding whatever T is).
 int launch_attn_temporal_f32_mfma(const float* qkv, float* out, int B, int T, int S, int d, int H, int Dh, float scale,
-                                  const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane, int Tq) {
-    if (T > 16 || T < 8 || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
+                                  const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane, int Tq,
+                                  bool in16) {
+    if (T > 16 || T < (in16 ? 1 : 8) || (Dh != 32 && Dh != 64)) return GENIE_E_UNSUPPORTED;
     if (Tq <= 0) Tq = T;
     const long n_bs = (long)B * S, waves = n_bs * H;
-    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 16.0, st);
+    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves,
+                   (double)waves * T * Dh * (in16 ? 8.0 : 16.0), st);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (Dh == 64) attn_temporal_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
-    else attn_temporal_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
+    if (in16) {
+        const uint16_t* q16 = reinterpret_cast<const uint16_t*>(qkv);
+        if (Dh == 64) attn_temporal_f32_mfma_kernel<64, uint16_t><<<blocks, 256, 0, st>>>(q16, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
+        else attn_temporal_f32_mfma_kernel<32, uint16_t><<<blocks, 256, 0, st>>>(q16, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
+    }
+    else if (Dh == 64) attn_temporal_f32_mfma_kernel<64, float><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
+    else attn_temporal_f32_mfma_kernel<32, float><<<blocks, 256, 0, st>>>(qkv, out, n_bs, S, d, H, T, Tq, scale, nw, nb, out16, plane);
     GENIE_LAUNCH_CHECK("attn_temporal_f32_mfma");
     return GENIE_OK;
 }
@@ -1315,9 +1351,9 @@ int launch_tokens_from_bits(const float* h, int64_t* ids, int n, int hw, int bit
 //   scores_j<i = scale q_i . kc_j   (MFMA, as attn_temporal_f32_mfma_kernel)      diag = scale q_i . k_i
 //   o_i = sum_j<i p_ij vc_j  +  p_ii v_i
 // ------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, typename TI>
 __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
-    const float* __restrict__ cur, const float* __restrict__ cache, float* __restrict__ out, long n_bs, int S, int d,
+    const TI* __restrict__ cur, const TI* __restrict__ cache, float* __restrict__ out, long n_bs, int S, int d,
     int H, int T, int sh, float scale, const float* __restrict__ nw, const float* __restrict__ nb,
     uint16_t* __restrict__ out16, size_t plane) {
     // T <= 16 frame slots in `cur` and in `cache` (tile rows / columns >= T are padding: loads repeat slot T-1, nothing is
@@ -1334,18 +1370,12 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     const long tok_stride = (long)S * 3 * d;
     const size_t off0 = ((size_t)(b * T) * S + s) * 3 * d + head * DH;
     const int rr = r < T ? r : T - 1;
-    const float* qp = cur + off0 + (size_t)rr * tok_stride + g * PER;
-    const float* kcp = cache + off0 + (size_t)rr * tok_stride + d + g * PER;
+    const TI* qp = cur + off0 + (size_t)rr * tok_stride + g * PER;
+    const TI* kcp = cache + off0 + (size_t)rr * tok_stride + d + g * PER;
     float q[PER], k[PER], kc[PER];
-#pragma unroll
-    for (int c = 0; c < PER / 4; ++c) {
-        float4 a = *reinterpret_cast<const float4*>(qp + 4 * c);
-        float4 bb = *reinterpret_cast<const float4*>(qp + d + 4 * c);
-        float4 cc = *reinterpret_cast<const float4*>(kcp + 4 * c);
-        q[4 * c] = a.x; q[4 * c + 1] = a.y; q[4 * c + 2] = a.z; q[4 * c + 3] = a.w;
-        k[4 * c] = bb.x; k[4 * c + 1] = bb.y; k[4 * c + 2] = bb.z; k[4 * c + 3] = bb.w;
-        kc[4 * c] = cc.x; kc[4 * c + 1] = cc.y; kc[4 * c + 2] = cc.z; kc[4 * c + 3] = cc.w;
-    }
+    load_vals<PER>(qp, q);
+    load_vals<PER>(qp + d, k);
+    load_vals<PER>(kcp, kc);
     if (nw) {
         float sq = 0.f, sk = 0.f, sc = 0.f;
 #pragma unroll
@@ -1400,22 +1430,14 @@ __global__ __launch_bounds__(256) void attn_temporal_prefix_f32_mfma_kernel(
     const float inv = 1.0f / (sum + pd);
     const float pdn = pd * inv;  // weight of the query's own (current) frame, held by every lane with r == i
     constexpr int NV = DH / 16;  // feature permutation as in attn_temporal_f32_mfma_kernel
-    const float* vcp = cache + off0 + 2 * d + NV * r;
-    const float* vp = cur + off0 + 2 * d + NV * r;
+    const TI* vcp = cache + off0 + 2 * d + NV * r;
+    const TI* vp = cur + off0 + 2 * d + NV * r;
     float vc[4][NV], vs[4][NV];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const size_t fo = (size_t)(4 * g + e < T ? 4 * g + e : T - 1) * tok_stride;
-        if constexpr (NV == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(vcp + fo);
-            const float4 u = *reinterpret_cast<const float4*>(vp + fo);
-            vc[e][0] = t.x; vc[e][1] = t.y; vc[e][2] = t.z; vc[e][3] = t.w;
-            vs[e][0] = u.x; vs[e][1] = u.y; vs[e][2] = u.z; vs[e][3] = u.w;
-        } else {
-            const float2 t = *reinterpret_cast<const float2*>(vcp + fo);
-            const float2 u = *reinterpret_cast<const float2*>(vp + fo);
-            vc[e][0] = t.x; vc[e][1] = t.y; vs[e][0] = u.x; vs[e][1] = u.y;
-        }
+        load_vals<NV>(vcp + fo, vc[e]);
+        load_vals<NV>(vp + fo, vs[e]);
     }
     float pself[4];
 #pragma unroll
@@ -1502,23 +1524,34 @@ __global__ void attn_temporal_prefix_generic_kernel(const float* __restrict__ cu
 // (returns GENIE_E_UNSUPPORTED if a 16-bit output is requested for a geometry without an MFMA instantiation).
 int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out, int B, int T, int S, int d, int H,
                                 int Dh, float scale, const float* nw, const float* nb, hipStream_t st,
-                                uint16_t* out16, size_t plane, int sh) {
+                                uint16_t* out16, size_t plane, int sh, bool in16) {
     // T frame slots in both buffers; query slot i sees cached slots j < i + sh and itself (sh in {0, 1})
+    // in16: both buffers hold bf16 values (GENIE_PREC_BF16); MFMA kernel only, any 1 <= T <= 16
     GENIE_CHECK_SHAPE(sh == 0 || sh == 1, "prefix attention: shift %d", sh);
     const long n_bs = (long)B * S, waves = n_bs * H;
-    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves, (double)waves * T * Dh * 28.0, st);
-    if (T <= 16 && T >= 8 && (Dh == 32 || Dh == 64)) {
+    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * T * T * Dh * (double)waves,
+                   (double)waves * T * Dh * (in16 ? 14.0 : 28.0), st);
+    if (T <= 16 && T >= (in16 ? 1 : 8) && (Dh == 32 || Dh == 64)) {
         const unsigned blocks = (unsigned)((waves + 3) / 4);
-        if (Dh == 64)
-            attn_temporal_prefix_f32_mfma_kernel<64><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, T, sh, scale, nw,
-                                                                             nb, out16, plane);
+        if (in16) {
+            const uint16_t* c16 = reinterpret_cast<const uint16_t*>(cur);
+            const uint16_t* k16 = reinterpret_cast<const uint16_t*>(cache);
+            if (Dh == 64)
+                attn_temporal_prefix_f32_mfma_kernel<64, uint16_t><<<blocks, 256, 0, st>>>(c16, k16, out, n_bs, S, d, H, T, sh, scale,
+                                                                                           nw, nb, out16, plane);
+            else
+                attn_temporal_prefix_f32_mfma_kernel<32, uint16_t><<<blocks, 256, 0, st>>>(c16, k16, out, n_bs, S, d, H, T, sh, scale,
+                                                                                           nw, nb, out16, plane);
+        } else if (Dh == 64)
+            attn_temporal_prefix_f32_mfma_kernel<64, float><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, T, sh, scale, nw,
+                                                                                    nb, out16, plane);
         else
-            attn_temporal_prefix_f32_mfma_kernel<32><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, T, sh, scale, nw,
-                                                                             nb, out16, plane);
+            attn_temporal_prefix_f32_mfma_kernel<32, float><<<blocks, 256, 0, st>>>(cur, cache, out, n_bs, S, d, H, T, sh, scale, nw,
+                                                                                    nb, out16, plane);
         GENIE_LAUNCH_CHECK("attn_temporal_prefix_mfma");
         return GENIE_OK;
     }
-    if (out16) return GENIE_E_UNSUPPORTED;
+    if (out16 || in16) return GENIE_E_UNSUPPORTED;
     GENIE_CHECK_SHAPE(T <= 64, "prefix attention: T=%d > 64", T);
     const long n = waves * T;
     const unsigned blocks = (unsigned)((n + 127) / 128);
@@ -1539,8 +1572,8 @@ int launch_attn_temporal_prefix(const float* cur, const float* cache, float* out
 // (b, s, head), lane = feature; T <= 64 scores live in registers of lane 0..t after wave reductions.
 // out: dense (B, S, d) f32 / bf16 / split-f16.
 // ------------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* __restrict__ cache,
+template <int DH, typename TI>
+__global__ __launch_bounds__(256) void attn_temporal_single_kernel(const TI* __restrict__ cache,
                                                                    float* __restrict__ out, long n_items, int T, int S,
                                                                    int t, int d, int H, float scale,
                                                                    const float* __restrict__ nw,
@@ -1554,7 +1587,7 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* 
     const long b = bs / S, s = bs - b * S;
     const bool act = lane < DH;
     const size_t tok_stride = (size_t)S * 3 * d;
-    const float* base = cache + ((size_t)(b * T) * S + s) * 3 * d + head * DH + (act ? lane : 0);
+    const TI* base = cache + ((size_t)(b * T) * S + s) * 3 * d + head * DH + (act ? lane : 0);
     auto norm = [&](float v) {  // qk-norm over the DH active lanes
         if (!nw) return v;
         const float mu = wave_sum(act ? v : 0.f) / DH;
@@ -1562,7 +1595,7 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* 
         const float var = wave_sum(c * c) / DH;
         return c * (1.0f / sqrtf(var + 1e-5f)) * nw[act ? lane : 0] + nb[act ? lane : 0];
     };
-    float q = norm(base[(size_t)t * tok_stride]) * scale;
+    float q = norm(load_val(base + (size_t)t * tok_stride)) * scale;
     if (!act) q = 0.f;
     if (t < 16) {
         // the shipped window (T = 16): every cached key / value of the (position, head) is fetched up front -- 2 (t + 1)
@@ -1572,7 +1605,7 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             kj[j] = 0.f; vj[j] = 0.f;
-            if (j <= t) { kj[j] = base[(size_t)j * tok_stride + d]; vj[j] = base[(size_t)j * tok_stride + 2 * d]; }
+            if (j <= t) { kj[j] = load_val(base + (size_t)j * tok_stride + d); vj[j] = load_val(base + (size_t)j * tok_stride + 2 * d); }
         }
         float mx16 = -INFINITY;
 #pragma unroll
@@ -1602,7 +1635,7 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* 
     float sc[64];
     float mx = -INFINITY;
     for (int j = 0; j <= t; ++j) {
-        const float kj = norm(base[(size_t)j * tok_stride + d]);
+        const float kj = norm(load_val(base + (size_t)j * tok_stride + d));
         const float a = wave_sum(act ? q * kj : 0.f);
         sc[j] = a;
         mx = fmaxf(mx, a);
@@ -1611,7 +1644,7 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* 
     for (int j = 0; j <= t; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
     const float inv = 1.0f / sum;
     float o = 0.f;
-    for (int j = 0; j <= t; ++j) o = fmaf(sc[j] * inv, base[(size_t)j * tok_stride + 2 * d], o);
+    for (int j = 0; j <= t; ++j) o = fmaf(sc[j] * inv, load_val(base + (size_t)j * tok_stride + 2 * d), o);
     if (!act) return;
     const size_t oi = (size_t)bs * d + head * DH + lane;
     if (!out16) out[oi] = o;
@@ -1621,18 +1654,22 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const float* 
 
 int launch_attn_temporal_single(const float* cache, float* out, int B, int T, int S, int t, int d, int H, int Dh,
                                 float scale, const float* nw, const float* nb, hipStream_t st, uint16_t* out16,
-                                size_t plane) {
+                                size_t plane, bool in16) {
     GENIE_CHECK_SHAPE(T <= 64 && t >= 0 && t < T, "temporal_single: bad frame %d of %d", t, T);
     const long n = (long)B * S * H;
-    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * (t + 1) * Dh * (double)n, (double)n * Dh * 4.0 * (2 * t + 4), st);
+    ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * (t + 1) * Dh * (double)n, (double)n * Dh * (in16 ? 2.0 : 4.0) * (2 * t + 4), st);
     const unsigned blocks = (unsigned)((n + 3) / 4);
+    const uint16_t* c16 = reinterpret_cast<const uint16_t*>(cache);
+#define SINGLE(DH_)                                                                                                          \
+    case DH_:                                                                                                                \
+        if (in16) attn_temporal_single_kernel<DH_, uint16_t><<<blocks, 256, 0, st>>>(c16, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); \
+        else attn_temporal_single_kernel<DH_, float><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane);     \
+        break;
     switch (Dh) {
-        case 8: attn_temporal_single_kernel<8><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
-        case 16: attn_temporal_single_kernel<16><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
-        case 32: attn_temporal_single_kernel<32><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
-        case 64: attn_temporal_single_kernel<64><<<blocks, 256, 0, st>>>(cache, out, n, T, S, t, d, H, scale, nw, nb, out16, plane); break;
+        SINGLE(8) SINGLE(16) SINGLE(32) SINGLE(64)
         default: set_error("temporal_single: head_dim %d unsupported", Dh); return GENIE_E_SHAPE;
     }
+#undef SINGLE
     GENIE_LAUNCH_CHECK("attn_temporal_single");
     return GENIE_OK;
 }

@@ -138,8 +138,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
         if constexpr (ABL & 1) { if (in_loop) return; }
         const int soff = kt * BK * 2 + (ht == 1 ? lateA : ht == 3 ? lateB : 0);
         unsigned char* dst = smem + buf * PP_BUF + ht * PP_HT + wid * 2048 + j * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ht < 2 ? rsA : rsW, (__attribute__((address_space(3))) void*)dst, 16,
-                                                 ht < 2 ? voffA[j] : voffB[j], soff, 0, 0);
+        // ABL & 64 / & 128 (study): non-temporal policy (aux = 2) on the A / W stream
+        constexpr int AUXA = (ABL & 64) ? 2 : 0, AUXW = (ABL & 128) ? 2 : 0;
+        if (ht < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voffA[j], soff, 0, AUXA);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voffB[j], soff, 0, AUXW);
     };
     auto stage = [&](int ht, int buf, int kt) {
         piece(ht, 0, buf, kt);
@@ -765,11 +769,11 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     static const int abl = study_env("GENIE_PP_ABL", 0);
     const size_t n_wg = (size_t)tiles_x;
     static unsigned long long* tbuf = nullptr;
-    if ((abl == 32 || abl == 33) && !tbuf) {
+    if ((abl & 32) && !tbuf) {
         (void)hipMalloc(&tbuf, sizeof(unsigned long long) * 4 * 65536);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_timing), &tbuf, sizeof(tbuf));
     }
-    if ((abl == 32 || abl == 33) && n_wg > 65536) return GENIE_E_UNSUPPORTED;   // the stamp buffer holds 65536 tiles
+    if ((abl & 32) && n_wg > 65536) return GENIE_E_UNSUPPORTED;   // the stamp buffer holds 65536 tiles
     if (abl == 1) PP_LAUNCH_ABL(1);
     else if (abl == 2) PP_LAUNCH_ABL(2);
     else if (abl == 3) PP_LAUNCH_ABL(3);
@@ -777,6 +781,9 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     else if (abl == 16) PP_LAUNCH_ABL(16);
     else if (abl == 11) PP_LAUNCH_ABL(11);
     else if (abl == 32) PP_LAUNCH_ABL(32);
+    else if (abl == 96) PP_LAUNCH_ABL(96);     // stamps + nt on the A stream
+    else if (abl == 160) PP_LAUNCH_ABL(160);   // stamps + nt on the W stream
+    else if (abl == 224) PP_LAUNCH_ABL(224);   // stamps + nt on both
     else if (abl == 33) {  // stamps with the compile-time OUTF32 | NT epilogue
         if (npl == 1) { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim); }
@@ -787,7 +794,8 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
 #endif
     {
         // compile-time epilogues for the model's Linear flavours (qkv / readout: OUTF32; proj, fc2: ACCUM | OUTF32 [| OUT16];
-        // fc1: GELU | OUT16), each with and without non-temporal stores; anything else takes the run-time-flag kernel
+        // fc1: GELU | OUT16; bf16 temporal qkv: OUT16), each with and without non-temporal stores; anything else takes the
+        // run-time-flag kernel
         const int e = flags & 127;
 #define PP_EPI(NPL_, F16_, E_)                                                                                            \
         case E_: {                                                                                                        \
@@ -806,6 +814,8 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
             PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32 | G16X_NT)                                                        \
             PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32 | G16X_OUT16)                                                     \
             PP_EPI(NPL_, F16_, G16X_ACCUM | G16X_OUTF32 | G16X_OUT16 | G16X_NT)                                           \
+            PP_EPI(NPL_, F16_, G16X_OUT16)                                                                                \
+            PP_EPI(NPL_, F16_, G16X_OUT16 | G16X_NT)                                                                      \
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16)                                                                    \
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16 | G16X_NT)                                                          \
             PP_EPI(NPL_, F16_, G16X_OUT16 | G16X_QKV | G16X_NT)                                                           \
@@ -837,7 +847,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
 #undef PP_LAUNCH
 #undef PP_LAUNCH_ABL
 #ifdef GENIE_STUDY
-    if ((abl == 32 || abl == 33) && n_wg <= 16384 && batch == 1) {  // debug study: average the stamps of this launch (synchronises!)
+    if ((abl & 32) && n_wg <= 16384 && batch == 1) {  // debug study: average the stamps of this launch (synchronises!)
         static unsigned long long host[4 * 16384];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, tbuf, sizeof(unsigned long long) * 4 * n_wg, hipMemcpyDeviceToHost);

@@ -190,7 +190,10 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int
  *     same nframes; frame0 is 1 (slots = clip frames 1..nframes, the evaluator's case) or 0 (slot 0 = frame 0 seeing
  *     only itself).  logits: token-major (B, nframes, S, V).
  * Same per-row arithmetic as the full forwards: (1 + steps) passes over T-1 frames instead of 15*steps over T.
- * genie_prefix_cache_bytes is the size for nframes = T (an upper bound). */
+ * genie_prefix_cache_bytes is the size for nframes = T (an upper bound).
+ * The cache is opaque to the caller and only valid for the precision that wrote it: GENIE_PREC_EXACT / _F16X3 store f32;
+ * GENIE_PREC_BF16 stores bf16 values (models with T <= 16 and head_dim 32 / 64) in the first half of each layer's slice --
+ * the slice strides stay those of the f32 layout, so the size above holds for every precision. */
 size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B);
 int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int nframes, int cache_frames,
                      float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);

@@ -37,11 +37,12 @@ def round_bf16(a: np.ndarray) -> np.ndarray:
 class Numerics:
     """dtype + optional operand rounding applied at every GEMM/attention-matmul input."""
 
-    def __init__(self, dtype=np.float32, gemm_in=None, attn_in=False):
+    def __init__(self, dtype=np.float32, gemm_in=None, attn_in=False, temporal_qkv=None):
         self.dtype = np.dtype(dtype)
         self.gemm_in = gemm_in  # rounding of every nn.Linear operand (e.g. round_bf16)
         self.attn_in = attn_in  # True: the attention matmuls also take rounded operands (bf16 contract);
         #                         False: attention is f32 in the reference's order (exact / f16x3 contract)
+        self.temporal_qkv = temporal_qkv  # rounding of the STORED temporal qkv (HIP bf16 keeps it, and the KV cache, in bf16)
 
     def r(self, a):
         return a if self.gemm_in is None else self.gemm_in(a).astype(self.dtype, copy=False)
@@ -52,8 +53,9 @@ class Numerics:
 
 F32 = Numerics(np.float32)
 F64 = Numerics(np.float64)
-BF16_MFMA = Numerics(np.float32, round_bf16)  # Linear operands bf16; attention core f32 (HIP bf16 contract)
-BF16_ALL = Numerics(np.float32, round_bf16, attn_in=True)  # attention matmuls on bf16 operands as well
+# HIP bf16 contract: Linear operands bf16, the temporal qkv buffer / KV cache stored in bf16, attention arithmetic f32
+BF16_MFMA = Numerics(np.float32, round_bf16, temporal_qkv=round_bf16)
+BF16_ALL = Numerics(np.float32, round_bf16, attn_in=True, temporal_qkv=round_bf16)  # attention matmuls on bf16 operands as well
 
 
 # ----------------------------------------------------------------------------------------------
@@ -126,6 +128,8 @@ def self_attention(x_BNC, sd, prefix, cfg, causal, nm=F32, chunk=64):
         if cfg.qkv_bias:
             qkv = qkv + sd[prefix + "qkv.bias"].astype(dt)
         qkv = nm.ra(qkv)  # bf16 contract: the qkv buffer itself is stored rounded (f32 otherwise)
+        if causal and nm.temporal_qkv is not None:
+            qkv = nm.temporal_qkv(qkv).astype(dt, copy=False)
         qkv = qkv.reshape(b, N, 3, H, Dh).transpose(2, 0, 3, 1, 4)  # (3,b,H,N,Dh)  attention.py:38
         q, k, v = qkv[0], qkv[1], qkv[2]
         if cfg.qk_norm:  # one shared affine for q and k  (attention.py:42-47)

@@ -66,10 +66,14 @@ if __name__ == "__main__":
     ap.add_argument("--gelu", type=int, default=0, help="fused erf-GELU epilogue (16-bit precisions)")
     ap.add_argument("--acc", type=int, default=0, help="residual accumulate (y += ...) epilogue (16-bit precisions)")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power study, not a throughput figure)")
+    ap.add_argument("--shapes", nargs="*", default=None, help="N:K pairs instead of the model's shapes, e.g. 1280:512 1792:512")
+    ap.add_argument("--rows", type=int, default=None, help="M (default 4096 * batch)")
     a = ap.parse_args()
-    M = 4096 * a.batch
+    M = a.rows or 4096 * a.batch
     shapes = [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), ("fc2", 512, 2048), ("readout", 1024, 512),
               ("sq4096", 4096, 4096)]
+    if a.shapes:
+        shapes = [(f"n{s}", int(s.split(":")[0]), int(s.split(":")[1])) for s in a.shapes]
     for prec in a.prec:
         for name, N, K in shapes:
             m = 4096 if name == "sq4096" else M
