@@ -1019,6 +1019,18 @@ int launch_pack_split(const float* src, uint16_t* dst, size_t n, hipStream_t st)
 int launch_linear_lowp(int precision, const uint16_t* x16, const uint16_t* W16, const float* b, float* y, int M, int N,
                        int K, int gelu, int accumulate, hipStream_t st) {
     const int flags = G16_OUTF32 | (gelu ? G16_GELU : 0) | (accumulate ? G16_ACCUM : 0);
+#ifdef GENIE_STUDY
+    {   // leading-dimension study (tools/bench_gemm.py --pad-a / --pad-c allocate the padded buffers): does a power-of-two
+        // row stride of the activation planes / of the output cost memory-channel conflicts?
+        const int pa = study_env("GENIE_STUDY_LDA_PAD", 0), pc = study_env("GENIE_STUDY_LDC_PAD", 0);
+        if (pa || pc) {
+            const long lda = K + pa, ldc = N + pc;
+            if (precision == GENIE_PREC_BF16)
+                return launch_gemm16<1>(x16, lda, 0, W16, K, 0, b, y, nullptr, 0, ldc, M, N, K, flags, 1.0f, st);
+            return launch_gemm16<2>(x16, lda, (size_t)M * lda, W16, K, (size_t)N * K, b, y, nullptr, 0, ldc, M, N, K, flags, 1.0f, st);
+        }
+    }
+#endif
     if (precision == GENIE_PREC_BF16)
         return launch_gemm16<1>(x16, K, 0, W16, K, 0, b, y, nullptr, 0, N, M, N, K, flags, 1.0f, st);
     if (precision == GENIE_PREC_F16X3)

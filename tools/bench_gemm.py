@@ -14,7 +14,7 @@ sys.path.insert(0, REPO)
 _lib = importlib.import_module("1xgpt_amd._lib")
 
 
-def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False, acc=0):
+def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False, acc=0, pad_a=0, pad_c=0):
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
@@ -22,7 +22,7 @@ def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False, acc=0):
     b = torch.randn(N, device="cuda", generator=g)
     if zero:  # power study only: all-zero operands toggle no multiplier inputs (never quote these numbers as throughput)
         x.zero_(); W.zero_()
-    y = torch.empty(M, N, device="cuda")
+    y = torch.empty(M, N + pad_c, device="cuda")[:, :N]   # (study build) padded output rows: GENIE_STUDY_LDC_PAD
     st = torch.cuda.current_stream().cuda_stream
     if prec == "exact":
         def call():
@@ -35,6 +35,10 @@ def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False, acc=0):
         pack = lib.genie_pack_bf16 if prec == "bf16" else lib.genie_pack_split_f16
         _lib.check(pack(x.data_ptr(), x16.data_ptr(), x.numel(), st), "pack")
         _lib.check(pack(W.data_ptr(), W16.data_ptr(), W.numel(), st), "pack")
+        if pad_a:  # (study build) activation planes with padded rows: GENIE_STUDY_LDA_PAD
+            xp = torch.zeros(npl, M, K + pad_a, dtype=torch.float16, device="cuda")
+            xp[:, :, :K] = x16
+            x16 = xp
 
         def call():
             _lib.check(lib.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, gelu, acc,
@@ -68,7 +72,13 @@ if __name__ == "__main__":
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power study, not a throughput figure)")
     ap.add_argument("--shapes", nargs="*", default=None, help="N:K pairs instead of the model's shapes, e.g. 1280:512 1792:512")
     ap.add_argument("--rows", type=int, default=None, help="M (default 4096 * batch)")
+    ap.add_argument("--pad-a", type=int, default=0, help="study build: extra elements per activation row (sets GENIE_STUDY_LDA_PAD)")
+    ap.add_argument("--pad-c", type=int, default=0, help="study build: extra floats per output row (sets GENIE_STUDY_LDC_PAD)")
     a = ap.parse_args()
+    if a.pad_a:
+        os.environ["GENIE_STUDY_LDA_PAD"] = str(a.pad_a)
+    if a.pad_c:
+        os.environ["GENIE_STUDY_LDC_PAD"] = str(a.pad_c)
     M = a.rows or 4096 * a.batch
     shapes = [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), ("fc2", 512, 2048), ("readout", 1024, 512),
               ("sq4096", 4096, 4096)]
@@ -77,6 +87,7 @@ if __name__ == "__main__":
     for prec in a.prec:
         for name, N, K in shapes:
             m = 4096 if name == "sq4096" else M
-            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0, zero=a.zero, acc=a.acc if prec != "exact" else 0)
+            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0, zero=a.zero, acc=a.acc if prec != "exact" else 0,
+                              pad_a=a.pad_a if prec != "exact" else 0, pad_c=a.pad_c if prec != "exact" else 0)
             print(f"{prec:6s} {name:8s} M={m:6d} N={N:5d} K={K:5d}  {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s  max|err| {err:.2e}",
                   flush=True)
