@@ -71,3 +71,31 @@ def test_two_ranks_on_the_hip_path_match_one(tmp_path):
     # noise floor may differ by up to 2 lr; everything else agrees to summation-order noise
     assert np.median(d) < 1e-7 and (d > 1e-5).mean() < 0.01 and d.max() <= 2.5e-3, (np.median(d), (d > 1e-5).mean(), d.max())
     assert abs(t0["param_abs_sum"] - t["param_abs_sum"]) < 1e-5 * t["param_abs_sum"]
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, (args, r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # exactly ONE JSON line on stdout (rank 0's)
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu_matches_one_rank():
+    """bench.py --gpus 2 end to end on the one GPU of the test box (BASELINE config 4's code path at N = 2: per-rank
+    supervisor, rendezvous, sharded clips, all-reduce of the metric sums, the training leg's bucketed gradient exchange) against
+    bench.py --gpus 1 on the same 16 global clips: same CE (step-0 logits do not depend on the unmasking draws)."""
+    common = ["--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline", "--no-board-sampler", "--train-batch", "2"]
+    one = _bench(["--gpus", "1", "--batch", "16"] + common, {})
+    two = _bench(["--gpus", "2", "--batch", "8"] + common, {"GENIE_FORCE_DEVICE": "0", "GENIE_DIST_BACKEND": "gloo",
+                                                             "GENIE_RDZV_TIMEOUT": "240"})
+    assert two["n_gpus"] == 2 and two["config"]["ranks_reported_by_backend"] == 2 and two["config"]["collective_backend"] == "gloo"
+    assert two["config"]["global_clips"] == one["config"]["global_clips"] == 16
+    assert two["scaling"] == "weak" and two["value"] > 0 and one["value"] > 0
+    assert abs(two["ce"] - one["ce"]) < 1e-5, (two["ce"], one["ce"])
+    assert "error" not in two["train_step"] and two["train_step"]["n_gpus"] == 2 and two["train_step"]["value"] > 0
+    assert "bucketed" in two["train_step"]["gradient_exchange"]
