@@ -1,6 +1,8 @@
 // Exact-precision (f32) kernels of the GENIE path for gfx950: embedding gather, LayerNorm, the f32-MFMA
 // "NT" GEMM with fused bias / erf-GELU / residual epilogue, the generic strided attention, factored CE,
 // MaskGIT sampling and mask step, layout transposes.  Every kernel cites the reference op it replaces.
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -377,6 +379,158 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same nn.Linear, LDS-DMA fed (round 3).  gemm_f32_nt_kernel above stages its operands through registers, and the compiler
+// keeps those registers in scratch (runtime-indexed arrays) behind an s_waitcnt vmcnt(0) at the top of every K-step: the global
+// load latency of every K-tile is exposed and the matrix pipe is 54 % busy (PMC, 75-90 TFLOP/s of the 157.3 TFLOP/s f32 MFMA
+// peak).  Here every operand byte goes HBM/L2 -> LDS by buffer_load ... lds (no registers, no ds_write), one K-tile ahead of the
+// multiplies:
+//   * 128x128 tile, 4 waves (2x2), wave tile 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator registers); BK = 32 floats
+//     = 128-byte rows, two stages of 32 KB -> two workgroups per CU (one computes while the other sits at its barrier);
+//   * the 16-byte slot of a row is XOR-swizzled with (row / 2) % 8 on the SOURCE address and on the fragment read (the LDS image of
+//     a DMA piece is lane-linear): conflict-free ds_read_b128;
+//   * one barrier per K-tile of 64 matrix instructions (4,096 cycles) per wave: wait for tile t (issued a whole K-tile ago) ->
+//     barrier (also: everyone is done reading the other buffer) -> issue tile t+1 into it -> multiply tile t.
+// Rows beyond M / N are clamped on the load side (the epilogue never stores them).  Same fmaf-chain arithmetic; the k-order of the
+// sum differs from the kernel above (BK = 32, pairs {8kk+j, 8kk+4+j}), i.e. results agree to f32 rounding, not bitwise.
+// ------------------------------------------------------------------------------------------------
+typedef float gd_f4 __attribute__((ext_vector_type(4)));
+
+// BK = 32: 128-byte rows, 64 KB of LDS per workgroup (2 per CU);  BK = 16: 64-byte rows, 32 KB (4 per CU: more waves to cover
+// each other's barrier waits, finer rounds)
+template <int BK>
+__global__ __launch_bounds__(256, BK == 32 ? 2 : 4) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda, long strideA,
+                                                               const float* __restrict__ W, long ldw, long strideW,
+                                                               const float* __restrict__ bias, float* __restrict__ C,
+                                                               long ldc, long strideC, int M, int N, int K, int flags,
+                                                               float alpha) {
+    constexpr int ROWB = BK * 4, SLOTS = ROWB / 16, RPB = 256 / ROWB, RPP = 1024 / ROWB, NP = 128 / RPP / 4, KK = BK / 8;
+    constexpr int OPB = 128 * ROWB, GD_STAGE = 2 * OPB;   // bytes of one operand tile / of one stage (A tile then B tile)
+    extern __shared__ __attribute__((aligned(16))) unsigned char gd_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tiles = (N + 127) / 128;
+    const int m0 = (blockIdx.x / n_tiles) * 128, n0 = (blockIdx.x % n_tiles) * 128;
+    A += (size_t)blockIdx.y * strideA;
+    W += (size_t)blockIdx.y * strideW;
+    C += (size_t)blockIdx.y * strideC;
+
+    // ---- LDS-DMA: a piece = 8 rows x 128 bytes (one wave instruction); wave w moves pieces w, w+4, ... of each operand tile
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, -1, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, -1, 0x00020000);
+    unsigned voA[4], voB[4];   // (NP <= 4 entries used)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = (wid + 4 * j) * RPP + lane / SLOTS;              // row of the tile this lane fills
+        const int ls = (lane % SLOTS) ^ ((row / RPB) % SLOTS);           // logical 16-byte slot landing in physical slot lane % SLOTS
+        const int ra = m0 + row < M ? row : M - 1 - m0, rb = n0 + row < N ? row : N - 1 - n0;
+        voA[j] = (unsigned)((size_t)ra * lda * 4 + ls * 16);
+        voB[j] = (unsigned)((size_t)rb * ldw * 4 + ls * 16);
+    }
+    // (buffer indices are compile-time constants everywhere below: with a run-time buffer the compiler cannot tell the LDS
+    // destination of the DMA in flight from the fragment reads and puts an s_waitcnt vmcnt(0) in front of them)
+    auto stage = [&](auto bufc, int kt) {
+        constexpr int BUF = decltype(bufc)::value;
+        unsigned char* base = gd_smem + BUF * GD_STAGE;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + (wid + 4 * j) * 1024), 16,
+                                                     voA[j], kt * ROWB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + OPB + (wid + 4 * j) * 1024),
+                                                     16, voB[j], kt * ROWB, 0, 0);
+        }
+    };
+    // fragment read offsets: lane (r, h) reads slot 2 kk + h of its row, swizzled; rows wm*64 + i*32 + r / wn*64 + j*32 + r
+    unsigned offA[4], offB[4];   // (KK <= 4 entries used)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const unsigned o = (unsigned)(r * ROWB + (((2 * kk + h) ^ ((r / RPB) % SLOTS)) << 4));
+        offA[kk] = o + wm * 64 * ROWB;
+        offB[kk] = o + OPB + wn * 64 * ROWB;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    const int nk = K / BK;
+    auto ktile = [&](auto bufc, auto nextc, int kt) {
+        constexpr int BUF = decltype(bufc)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt (the only loads in flight) have landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's have, and everyone is done with the other buffer
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) stage(nextc, kt + 1);
+        const unsigned char* base = gd_smem + BUF * GD_STAGE;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            // (ext_vector loads, NOT HIP's float4 struct: with the struct's TBAA the compiler's waitcnt pass puts an
+            // s_waitcnt vmcnt(0) in front of the first ds_read after every DMA issue -- the whole pipeline drained per K-tile)
+            gd_f4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const gd_f4*>(base + offA[kk] + i * 32 * ROWB);
+                b[i] = *reinterpret_cast<const gd_f4*>(base + offB[kk] + i * 32 * ROWB);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    stage(B0{}, 0);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        ktile(B0{}, B1{}, kt);
+        ktile(B1{}, B0{}, kt + 1);
+    }
+    if (kt < nk) ktile(B0{}, B1{}, kt);
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5): a store instruction covers
+    // two rows x 128 contiguous bytes.  Residual accumulate: the 16 residual values of a 32x32 tile are requested TOGETHER, ahead of
+    // its stores -- C may be the residual buffer itself, so the compiler keeps every read behind the previous store otherwise (one
+    // exposed memory round trip per element: 64 per wave); the 16 rows of a tile are distinct, so reading them first is safe in place.
+    const bool do_gelu = flags & GEMM_GELU, do_acc = flags & GEMM_ACCUM, bias_m = flags & GEMM_BIAS_ALONG_M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+            if (col >= N) continue;
+            const float bcol = (bias && !bias_m) ? bias[col] : 0.f;
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * h;
+            float res[16];
+            if (do_acc) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = rbase + (e & 3) + 8 * (e >> 2);
+                    res[e] = row < M ? C[(size_t)row * ldc + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + (e & 3) + 8 * (e >> 2);
+                if (row >= M) continue;
+                float v = acc[i][j][e] * alpha + ((bias && bias_m) ? bias[row] : bcol);
+                if (do_gelu) v = gelu_erf(v);
+                if (do_acc) v += res[e];
+                C[(size_t)row * ldc + col] = v;
+            }
+        }
+}
+
 int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, const float* bias,
                     float* C, long ldc, long strideC, int M, int N, int K, int batch, int flags, float alpha,
                     hipStream_t st) {
@@ -386,6 +540,28 @@ int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long
     int mt = (M + GEMM_BM - 1) / GEMM_BM, nt = (N + GEMM_BN - 1) / GEMM_BN;
     dim3 grid(mt * nt, batch);
     const double mnk = (double)M * N * batch;
+    // the LDS-DMA form needs 128-byte K-tiles, 16-byte aligned rows and 32-bit byte offsets inside a tile's descriptor
+    // K-tile of the LDS-DMA kernel: 16 floats (4 workgroups per CU; 113-131 TFLOP/s at K = 512 against 106-120 for 32) unless the
+    // contraction is long (K >= 2048: 130 vs 124); study build: GENIE_GEMM_F32_DMA = 16 / 32 forces one, 0 = the old kernel
+    static const int dma_env = study_env("GENIE_GEMM_F32_DMA", -1);
+    const int dma = dma_env >= 0 ? dma_env : (K >= 2048 && K % 32 == 0 ? 32 : 16);
+    if (dma && K % dma == 0 && 128.0 * 4.0 * (lda > ldw ? lda : ldw) + 4.0 * K < 4.0e9 &&
+        (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (strideA % 4 == 0) && (strideW % 4 == 0)) {
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * mnk * K,
+                       4.0 * ((double)M * K * batch + (double)N * K + mnk * ((flags & GEMM_ACCUM) ? 2 : 1)), st,
+                       "gemm_f32_dma_kernel (128x128 tile, LDS-DMA, v_mfma_f32_32x32x2_f32)");
+        if (dma == 32) {
+            constexpr int lds = 2 * 2 * 128 * 32 * 4;
+            (void)hipFuncSetAttribute((const void*)gemm_f32_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            gemm_f32_dma_kernel<32><<<grid, 256, lds, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags, alpha);
+        } else {
+            constexpr int lds = 2 * 2 * 128 * 16 * 4;
+            (void)hipFuncSetAttribute((const void*)gemm_f32_dma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            gemm_f32_dma_kernel<16><<<grid, 256, lds, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags, alpha);
+        }
+        GENIE_LAUNCH_CHECK("gemm_f32_dma");
+        return GENIE_OK;
+    }
     ProfScope prof(GENIE_KC_GEMM, 2.0 * mnk * K,
                    4.0 * ((double)M * K * batch + (double)N * K + mnk * ((flags & GEMM_ACCUM) ? 2 : 1)), st,
                    "gemm_f32_nt_kernel (128x128x16 tile, v_mfma_f32_32x32x2_f32)");

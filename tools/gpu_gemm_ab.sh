@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the study build of the library (GENIE_STUDY=1 python 1xgpt_amd/build.py): the shipping library has no study knobs
+export GENIE_HIP_LIBRARY=${GENIE_HIP_LIBRARY:-$(cd "$(dirname "$0")/.." && pwd)/1xgpt_amd/libgenie_hip_study.so}
 # A/B of the 16-bit GEMM kernels on the model's shapes (run on the GPU box through gpurun).
 # usage: tools/gpu_gemm_ab.sh <batch> <out-file>
 B=${1:-48}; OUT=${2:-gpurun_out/gemm_ab.log}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the study build of the library (GENIE_STUDY=1 python 1xgpt_amd/build.py): the shipping library has no study knobs
+export GENIE_HIP_LIBRARY=${GENIE_HIP_LIBRARY:-$(cd "$(dirname "$0")/.." && pwd)/1xgpt_amd/libgenie_hip_study.so}
 # SQ counter passes of the default bench step, reduced for the spatial attention kernel.  usage: tools/gpu_pmc_attn.sh <tag>
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the study build of the library (GENIE_STUDY=1 python 1xgpt_amd/build.py): the shipping library has no study knobs
+export GENIE_HIP_LIBRARY=${GENIE_HIP_LIBRARY:-$(cd "$(dirname "$0")/.." && pwd)/1xgpt_amd/libgenie_hip_study.so}
 # A/B of the persistent gemm16_pp launch (GENIE_PP_PERSIST=1, default) against one workgroup per tile (=0), plus stamps
 B=${1:-48}; TAG=${2:-pp}
 mkdir -p gpurun_out

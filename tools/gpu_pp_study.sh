@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the study build of the library (GENIE_STUDY=1 python 1xgpt_amd/build.py): the shipping library has no study knobs
+export GENIE_HIP_LIBRARY=${GENIE_HIP_LIBRARY:-$(cd "$(dirname "$0")/.." && pwd)/1xgpt_amd/libgenie_hip_study.so}
 # Timing-only ablations (GENIE_PP_ABL) and one PMC pass of the phase-scheduled GEMM.  usage: tools/gpu_pp_study.sh <batch> <tag>
 B=${1:-48}; TAG=${2:-pp}
 mkdir -p gpurun_out
