@@ -61,6 +61,16 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// LDS accesses of the epilogue go through ext_vector types, never through HIP's float4 STRUCT: with the struct's TBAA the compiler's
+// waitcnt pass puts an s_waitcnt vmcnt(0) in front of the first such ds_read / ds_write while an LDS-DMA is in flight, and the next
+// tile's K-tile 0 -- requested just before the epilogue -- was drained there (a memory round trip per tile with the matrix pipe idle).
+typedef float pp_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_ld4(const float* p) {
+    const pp_f4 v = *reinterpret_cast<const pp_f4*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<pp_f4*>(p) = pp_f4{a, b, c, d}; }
+
 template <bool F16>
 __device__ __forceinline__ f32x16 mma16(const s16x8& a, const s16x8& b, const f32x16& c) {
     if constexpr (F16)
@@ -359,8 +369,20 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     const bool out16 = fl & G16X_OUT16, outf = fl & G16X_OUTF32, nts = fl & G16X_NT;
     const float ascale = NPL == 2 ? alpha * (1.0f / 2048.0f) : alpha;
 
+    // The tile's 256 bias values travel with its K-tile 0, by LDS-DMA into one of two 1 KB slots behind the ring (wave 0, one piece,
+    // issued first = oldest: every counted wait below covers it): an ordinary global load in the epilogue would make the compiler
+    // wait vmcnt(0) for it, i.e. for the next tile's K-tile 0 requested just before.
+    const auto rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)(bias ? (const void*)bias : (const void*)W), 0, -1, 0x00020000);
+    float* const bias_lds = reinterpret_cast<float*>(smem + 2 * PP_BUF);
+    int bias_slot = 0;
+    auto stage_bias = [&](int slot, int n0_) {
+        if (bias && wid == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (__attribute__((address_space(3))) void*)(bias_lds + slot * 256), 16,
+                                                     (unsigned)(lane * 16), n0_ * 4, 0, 0);
+    };
     // K-tile 0 of the first tile; every later tile's K-tile 0 is staged BEFORE the previous tile's epilogue, so that its
     // loads run ahead of the 256 KB of output stores instead of queueing behind them
+    stage_bias(0, n0);
     stage(0, 0, 0);
     stage(2, 0, 0);
     stage(3, 0, 0);
@@ -400,13 +422,29 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
         // ---- all LDS-DMA has landed and every fragment read has completed before any wave gets here (tail waits above)
         if constexpr (ABL & 32) tstamp[2] = __builtin_amdgcn_s_memtime();
         const int m0e = m0, n0e = n0;            // this tile's origin, for the epilogue
+        const float* const bl = bias_lds + bias_slot * 256 + wn * 64;   // this tile's bias, the wave's 64 columns
         const int tile_id = bid;
+        // residual-accumulate flavours: the FIRST round's residual rows are requested before the next tile's K-tile 0 (loads retire in
+        // order: requested after it, their wait would also be a wait for those 64 KB)
+        constexpr bool kResidualFirst = EPI >= 0 && (EPI & G16X_ACCUM) != 0 && (EPI & G16X_QKV) == 0 &&
+                                        !((EPI & G16X_OUT16) != 0 && (EPI & (G16X_OUTF32 | G16X_ACCUM)) == 0);
+        float4 res0[8];
+        if constexpr (kResidualFirst) {
+            const int colr = n0e + wn * 64 + ((lane & 15) << 2);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = m0e + wm * 128 + it * 4 + (lane >> 4);
+                res0[it] = *reinterpret_cast<const float4*>(Rsrc + (size_t)row * ldc + colr);
+            }
+        }
         bid += gridDim.x;
         const bool more = bid < ntiles;
         if (more) {
             tile_origin(bid, m0, n0);
             rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, -1, 0x00020000);
             rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, -1, 0x00020000);
+            bias_slot ^= 1;
+            stage_bias(bias_slot, n0);
             stage(0, 0, 0);
             stage(2, 0, 0);
             stage(3, 0, 0);
@@ -435,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 const int colq = n0e - which * dm + wn * 64 + c8;
                 const int hq = colq / head_dim, fq = colq - hq * head_dim;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-                if (bias) { b0 = *reinterpret_cast<const float4*>(bias + n0e + wn * 64 + c8); b1 = *reinterpret_cast<const float4*>(bias + n0e + wn * 64 + c8 + 4); }
+                if (bias) { b0 = lds_ld4(bl + c8); b1 = lds_ld4(bl + c8 + 4); }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -453,8 +491,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                         // 256 * head_dim block, which is what the attention kernel's LDS-DMA pieces walk
                         const size_t idx = (((size_t)(m0e >> 8) * (dm / head_dim) + hq) * 256 + (wm * 128 + q * 32 + rl)) * head_dim + fq;
                         const int sw = (rl & 1) << 2;
-                        float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + (c8 ^ sw));
-                        float4 u = *reinterpret_cast<const float4*>(ct + rl * 64 + ((c8 + 4) ^ sw));
+                        float4 v = lds_ld4(ct + rl * 64 + (c8 ^ sw));
+                        float4 u = lds_ld4(ct + rl * 64 + ((c8 + 4) ^ sw));
                         v.x = (v.x * ascale + b0.x) * qs; v.y = (v.y * ascale + b0.y) * qs;
                         v.z = (v.z * ascale + b0.z) * qs; v.w = (v.w * ascale + b0.w) * qs;
                         u.x = (u.x * ascale + b1.x) * qs; u.y = (u.y * ascale + b1.y) * qs;
@@ -492,8 +530,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int c = j * 32 + r, ks = 2 * g + h;
-                            *reinterpret_cast<float4*>(ct + c * 32 + ((ks ^ (c & 7)) << 2)) =
-                                make_float4(acc[q][j][4 * g], acc[q][j][4 * g + 1], acc[q][j][4 * g + 2], acc[q][j][4 * g + 3]);
+                            lds_st4(ct + c * 32 + ((ks ^ (c & 7)) << 2), acc[q][j][4 * g], acc[q][j][4 * g + 1], acc[q][j][4 * g + 2],
+                                    acc[q][j][4 * g + 3]);
                         }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -503,9 +541,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                         // key order inside a 16-key group is the PV operand's own: unit j (16 bytes) = keys {4j..4j+3, 8+4j..8+4j+3},
                         // so the attention kernel fetches a lane's 8 keys with ONE conflict-free ds_read_b128
                         const int ga = 4 * (kq >> 1) + (kq & 1);
-                        const float4 a = *reinterpret_cast<const float4*>(ct + c * 32 + ((ga ^ (c & 7)) << 2));
-                        const float4 b = *reinterpret_cast<const float4*>(ct + c * 32 + (((ga + 2) ^ (c & 7)) << 2));
-                        const float bb = bias ? bias[n0e + wn * 64 + c] : 0.f;
+                        const float4 a = lds_ld4(ct + c * 32 + ((ga ^ (c & 7)) << 2));
+                        const float4 b = lds_ld4(ct + c * 32 + (((ga + 2) ^ (c & 7)) << 2));
+                        const float bb = bias ? bl[c] : 0.f;
                         const int head = cv / head_dim, f = cv - head * head_dim;
                         const size_t idx = (((size_t)seq * Hn + head) * head_dim + f) * 256 + wm * 128 + q * 32 + kq * 8;
                         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -536,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             const int c8 = (lane & 7) << 3;
             const int col8 = n0e + wn * 64 + c8;
             float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-            if (bias) { b0 = *reinterpret_cast<const float4*>(bias + col8); b1 = *reinterpret_cast<const float4*>(bias + col8 + 4); }
+            if (bias) { b0 = lds_ld4(bl + c8); b1 = lds_ld4(bl + c8 + 4); }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -552,8 +590,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     const int rl = it * 8 + (lane >> 3);
                     const int row = m0e + wm * 128 + q * 32 + rl;
                     const int sw = (rl & 1) << 2;
-                    float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + (c8 ^ sw));
-                    float4 u = *reinterpret_cast<const float4*>(ct + rl * 64 + ((c8 + 4) ^ sw));
+                    float4 v = lds_ld4(ct + rl * 64 + (c8 ^ sw));
+                    float4 u = lds_ld4(ct + rl * 64 + ((c8 + 4) ^ sw));
                     v.x = v.x * ascale + b0.x; v.y = v.y * ascale + b0.y; v.z = v.z * ascale + b0.z; v.w = v.w * ascale + b0.w;
                     u.x = u.x * ascale + b1.x; u.y = u.y * ascale + b1.y; u.z = u.z * ascale + b1.z; u.w = u.w * ascale + b1.w;
                     auto gelu4 = [](float4& t) {
@@ -615,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             const int c4 = (lane & 15) << 2;
             const int col = n0e + wn * 64 + c4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+            if (bias) bv = lds_ld4(bl + c4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -628,10 +666,15 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 // round trip per row); the rows of a round are distinct, so reading them all first is safe in place too
                 float4 res[8];
                 if (do_acc) {
+                    if (kResidualFirst && q == 0) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int row = m0e + wm * 128 + q * 32 + it * 4 + (lane >> 4);
-                        res[it] = *reinterpret_cast<const float4*>(Rsrc + (size_t)row * ldc + col);
+                        for (int it = 0; it < 8; ++it) res[it] = res0[it];
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int row = m0e + wm * 128 + q * 32 + it * 4 + (lane >> 4);
+                            res[it] = *reinterpret_cast<const float4*>(Rsrc + (size_t)row * ldc + col);
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -639,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 for (int it = 0; it < 8; ++it) {
                     const int rl = it * 4 + (lane >> 4);
                     const int row = m0e + wm * 128 + q * 32 + rl;
-                    float4 v = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
+                    float4 v = lds_ld4(ct + rl * 64 + c4);
                     v.x = v.x * ascale + bv.x; v.y = v.y * ascale + bv.y; v.z = v.z * ascale + bv.z; v.w = v.w * ascale + bv.w;
                     if (do_gelu) {
                         const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
@@ -750,7 +793,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     static const int stagger = study_env("GENIE_PP_STAGGER", 0);
     static const long stagger_min = study_env("GENIE_PP_STAGGER_MIN_TILES", (int)(1024));
     if (stagger > 1 && batch == 1 && tiles >= stagger_min) flags |= (stagger & 15) << 8;
-    constexpr size_t lds = 2 * PP_BUF;
+    constexpr size_t lds = 2 * PP_BUF + 2048;   // ring + two 1 KB bias slots
 #define PP_LAUNCH(NPL_, TERMS_, F16_, ABL_, SCHED_)                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, TERMS_, F16_, ABL_, SCHED_>,                        \
