@@ -273,6 +273,8 @@ __global__ __launch_bounds__(512, OCC) void conv3x3_igemm_kernel(const uint16_t*
 // tools/gpu_conv_abl.sh).  Rows whose horizontal neighbour lies outside the image get their fragment zeroed in registers.
 //   slab rows: L = 0: pixel -1, L = 1: pixel 256, L = 8 + q: pixel q of the tile; XOR swizzle keyed on L.
 //   BN = 128: 4 x 2 waves of 64 x 64;  BN = 32: 8 x 1 waves of 32 x 32 for the narrow head (conv_out, 3 -> 8 padded columns).
+typedef float cv_f4 __attribute__((ext_vector_type(4)));
+
 template <int BN>
 __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                               const float* __restrict__ bias,
@@ -448,6 +450,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        // The tile's bias is requested HERE and consumed (as far as the compiler can tell) right behind the first stage's vmcnt(0),
+        // where everything is drained anyway: an ordinary load whose first use sits in the epilogue makes the compiler put an
+        // s_waitcnt vmcnt(0) there -- and drain the next tile's first slab and weight stages, requested just before the epilogue.
+        const int col = n0 + wn_off + c8;
+        cv_f4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = bq0;
+        if (bias && col < Cout) {
+            bq0 = *reinterpret_cast<const cv_f4*>(bias + col);
+            bq1 = *reinterpret_cast<const cv_f4*>(bias + col + 4);
+        }
+        // ResBlock skip: ALL residual rows this lane will add are requested together, right after the main loop, and are complete at
+        // the __syncthreads() that ends the tile (it drains vmcnt anyway): ONE memory round trip per tile, and no ordinary load is
+        // outstanding in the epilogue.  Requested inside the store loop -- as before -- each one was an exposed round trip behind the
+        // next tile's 40-50 KB prefetch, one per 8 / 16 rows, and its vmcnt(0) also waited for the previous rows' stores.  (Requested
+        // inside the main loop's last stage instead, the ordinary loads made the compiler wait vmcnt(0) all over the K loop.)
+        constexpr int NRES = TI * 2 * (16 / RPI);
+        typedef unsigned int cv_u4 __attribute__((ext_vector_type(4)));
+        cv_u4 resv[NRES];
+        auto out_index = [&](int p) -> size_t {
+            if (!d2s) return (size_t)p * Cout + col;
+            int img, y, x;   // DCR: conv channel (i*2 + j)*Cq + c -> pixel (2y+i, 2x+j), channel c
+            pix_of(p, img, y, x);
+            const int d2_grp = col / Cq, d2_c = col - d2_grp * Cq;
+            return (((size_t)img * (2 * H) + (2 * y + (d2_grp >> 1))) * (2 * Wd) + (2 * x + (d2_grp & 1))) * Cq + d2_c;
+        };
         for (int a = 0; a < nslab; ++a) {
             const unsigned char* sa = smem + (a & 1) * SLAB_B;
             const bool more = a + 1 < nslab;
@@ -457,6 +483,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
                 // outstanding DMAs younger than W(s): W(s+1) and, behind stage d = 0, the next slab (4 chunks, 5 for wave 0);
                 // the first stage of a tile also waits for the previous tile's epilogue stores
                 if (s + 1 >= nk || s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (s == 0) asm volatile("" : "+v"(bq0), "+v"(bq1));   // the bias has landed (see above)
                 else if (d == 1 && more) {
                     if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 5) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 4) : "memory");
@@ -491,6 +518,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
         }
         const int next = tile + (int)gridDim.x;
         const bool has_next = next < ntiles;
+        if (residual) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int eh = 0; eh < 2; ++eh)
+#pragma unroll
+                    for (int it = 0; it < 16 / RPI; ++it) {
+                        const int p = m0 + wm_off + i * 32 + eh * 16 + it * RPI + lane / LPR;
+                        cv_u4 z = {0u, 0u, 0u, 0u};
+                        resv[(i * 2 + eh) * (16 / RPI) + it] =
+                            (p < M && col < Cout) ? *reinterpret_cast<const cv_u4*>(residual + out_index(p)) : z;
+                    }
+        }
         __syncthreads();  // every wave is done with this tile's slabs and weight stages
         if (has_next) {
             tile_of(next, m_tile, n_tile);
@@ -502,15 +542,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
         // ---- epilogue through LDS: each wave transposes its tile 16 rows at a time through a 4 KB slice; 8 consecutive output
         // channels per lane, 16-byte stores
         if (!((flags & 256) && acc[0][0][0] != 12345.f)) {
-            const int col = n0 + wn_off + c8;
-            float bvv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bvv[e] = 0.f;
-            if (bias && col < Cout) {
-                const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
-                bvv[0] = b0.x; bvv[1] = b0.y; bvv[2] = b0.z; bvv[3] = b0.w; bvv[4] = b1.x; bvv[5] = b1.y; bvv[6] = b1.z; bvv[7] = b1.w;
-            }
-            const int d2_grp = d2s ? col / Cq : 0, d2_c = d2s ? col - d2_grp * Cq : 0;
+            const float bvv[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
             float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -525,21 +557,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
                     for (int it = 0; it < 16 / RPI; ++it) {
                         const int rl = it * RPI + lane / LPR;
                         const int p = m0 + wm_off + i * 32 + eh * 16 + rl;
-                        const float4 v0 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8);
-                        const float4 v1 = *reinterpret_cast<const float4*>(ct + rl * WCOLS + c8 + 4);
+                        // (ext_vector LDS reads: HIP's float4 struct would make the compiler wait vmcnt(0) here, for the prefetch)
+                        const cv_f4 v0 = *reinterpret_cast<const cv_f4*>(ct + rl * WCOLS + c8);
+                        const cv_f4 v1 = *reinterpret_cast<const cv_f4*>(ct + rl * WCOLS + c8 + 4);
                         if (p >= M || col >= Cout) continue;
                         float v[8] = {v0.x + bvv[0], v0.y + bvv[1], v0.z + bvv[2], v0.w + bvv[3],
                                       v1.x + bvv[4], v1.y + bvv[5], v1.z + bvv[6], v1.w + bvv[7]};
-                        size_t oidx;
-                        if (!d2s) {
-                            oidx = (size_t)p * Cout + col;
-                        } else {  // DCR: conv channel (i*2 + j)*Cq + c -> pixel (2y+i, 2x+j), channel c
-                            int img, y, x;
-                            pix_of(p, img, y, x);
-                            oidx = (((size_t)img * (2 * H) + (2 * y + (d2_grp >> 1))) * (2 * Wd) + (2 * x + (d2_grp & 1))) * Cq + d2_c;
-                        }
+                        const size_t oidx = out_index(p);
                         if (residual) {
-                            const uint4 rr = *reinterpret_cast<const uint4*>(residual + oidx);
+                            const cv_u4 rr = resv[(i * 2 + eh) * (16 / RPI) + it];
                             const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -571,8 +597,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
                 }
             if (BN == 128 && gn_part) {  // same fixed-order reduction and partial layout as conv3x3_igemm_kernel
                 float* ps = reinterpret_cast<float*>(smem + PS_OFF);
-                *reinterpret_cast<float4*>(ps + (wid * 64 + lane) * 4) = make_float4(gs0, gq0, gs1, gq1);
-                __syncthreads();
+                *reinterpret_cast<cv_f4*>(ps + (wid * 64 + lane) * 4) = cv_f4{gs0, gq0, gs1, gq1};
+                // (not __syncthreads(): with LDS-DMA in flight it carries an s_waitcnt vmcnt(0) -- the next tile's prefetch AND this
+                // tile's output stores would be drained here instead of under the next main loop)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
                 const int ngrp = BN / gn_cpg;
                 if (tid < ngrp * 2) {
                     const int g = tid >> 1, which = tid & 1;
