@@ -398,7 +398,7 @@ typedef float gd_f4 __attribute__((ext_vector_type(4)));
 
 // BK = 32: 128-byte rows, 64 KB of LDS per workgroup (2 per CU);  BK = 16: 64-byte rows, 32 KB (4 per CU: more waves to cover
 // each other's barrier waits, finer rounds)
-template <int BK>
+template <int BK, bool GELU, bool ACC, bool BIASM>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 4) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda, long strideA,
                                                                const float* __restrict__ W, long ldw, long strideW,
                                                                const float* __restrict__ bias, float* __restrict__ C,
@@ -499,36 +499,80 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 4) void gemm_f32_dma_kernel(con
     if (kt < nk) ktile(B0{}, B1{}, kt);
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5): a store instruction covers
-    // two rows x 128 contiguous bytes.  Residual accumulate: the 16 residual values of a 32x32 tile are requested TOGETHER, ahead of
-    // its stores -- C may be the residual buffer itself, so the compiler keeps every read behind the previous store otherwise (one
-    // exposed memory round trip per element: 64 per wave); the 16 rows of a tile are distinct, so reading them first is safe in place.
-    const bool do_gelu = flags & GEMM_GELU, do_acc = flags & GEMM_ACCUM, bias_m = flags & GEMM_BIAS_ALONG_M;
+    // two rows x 128 contiguous bytes.  Per 32x32 tile, three straight sections: every load (the 16 residual values -- C may be the
+    // residual buffer itself -- and, for a bias along M, the 16 row biases), then the arithmetic, then the 16 stores back to back.
+    // Written element by element (load, add, store) the compiler drains vmcnt before every element, and vmcnt counts the previous
+    // element's STORE as well: 64 serial store round trips per wave.  The 16 rows of a tile are distinct, so reading first is safe
+    // in place.
+    // Tile t + 1's residual values are requested BEFORE tile t's stores (vmcnt retires in order: a load issued behind a store
+    // waits for the store's round trip); whole tiles inside the matrix (all but the last row / column of workgroups) take a path
+    // without per-element bounds masks, which the compiler schedules as straight-line code with counted waits.
+    // GELU, the residual accumulate and the bias orientation are compile-time (the erf code of 16 elements beside 32 live residual
+    // values spilled; a run-time bias branch joining the straight-line path made the compiler drain vmcnt in every tile).
+    constexpr bool do_gelu = GELU, do_acc = ACC;
+    constexpr bool bias_m = BIASM;   // (bias along M: the operand-swapped readout; never with GELU / accumulate)
+    // Addresses: one buffer descriptor at the tile's origin, one 32-bit lane offset, the row of an element as a SCALAR offset
+    // (uniform: (32 i + ro) * ldc) -- sixteen 64-bit lane addresses per tile were what spilled under the 128-register budget.
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(C + (size_t)m0 * ldc + n0), 0, -1, 0x00020000);
+    const int lane_off = (int)(((size_t)(wm * 64 + 4 * h) * ldc + wn * 64 + r) * 4);
+    const int ldc4 = (int)(ldc * 4);
+    auto epilogue = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
+        auto rbase_of = [&](int t) { return m0 + wm * 64 + (t >> 1) * 32 + 4 * h; };
+        auto col_of = [&](int t) { return n0 + wn * 64 + (t & 1) * 32 + r; };
+        auto soff = [&](int t, int ro) { return ((t >> 1) * 32 + ro) * ldc4 + (t & 1) * 128; };
+        auto load_res = [&](int t, float* dst) {
+            const int rbase = rbase_of(t), col = col_of(t);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < 16; ++e) {
+                const int ro = (e & 3) + 8 * (e >> 2);
+                dst[e] = (FULL || (col < N && rbase + ro < M))
+                             ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, lane_off, soff(t, ro), 0))
+                             : 0.f;
+            }
+        };
+        float bcols[2];   // the lane's two column biases, ahead of everything: a load issued later sits behind the stores
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + r;
-            if (col >= N) continue;
-            const float bcol = (bias && !bias_m) ? bias[col] : 0.f;
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * h;
-            float res[16];
-            if (do_acc) {
+        for (int j = 0; j < 2; ++j) bcols[j] = (bias && !bias_m && (FULL || col_of(j) < N)) ? bias[col_of(j)] : 0.f;
+        float res[2][16];
+        if (do_acc) load_res(0, res[0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int rbase = rbase_of(t), col = col_of(t);
+            if (do_acc && FULL && t + 1 < 4) load_res(t + 1, res[(t + 1) & 1]);
+            if (do_acc && !FULL && t > 0) load_res(t, res[t & 1]);   // (edge tiles: no look-ahead, fewer live registers)
+            float add[16], v[16];
+            const float bcol = bcols[t & 1];
+            if (bias_m) {   // (the operand-swapped readout only)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = rbase + (e & 3) + 8 * (e >> 2);
-                    res[e] = row < M ? C[(size_t)row * ldc + col] : 0.f;
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    add[e] = (FULL || rbase + ro < M) ? bias[rbase + ro] : 0.f;
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) add[e] = bcol;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = acc[t >> 1][t & 1][e] * alpha + add[e];
+            if (do_gelu) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (do_acc) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] += res[t & 1][e];
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = rbase + (e & 3) + 8 * (e >> 2);
-                if (row >= M) continue;
-                float v = acc[i][j][e] * alpha + ((bias && bias_m) ? bias[row] : bcol);
-                if (do_gelu) v = gelu_erf(v);
-                if (do_acc) v += res[e];
-                C[(size_t)row * ldc + col] = v;
+                const int ro = (e & 3) + 8 * (e >> 2);
+                if (FULL || (col < N && rbase + ro < M))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsC, lane_off, soff(t, ro), 0);
             }
         }
+    };
+    if (m0 + 128 <= M && n0 + 128 <= N) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, const float* bias,
@@ -545,20 +589,32 @@ int launch_gemm_f32(const float* A, long lda, long strideA, const float* W, long
     // contraction is long (K >= 2048: 130 vs 124); study build: GENIE_GEMM_F32_DMA = 16 / 32 forces one, 0 = the old kernel
     static const int dma_env = study_env("GENIE_GEMM_F32_DMA", -1);
     const int dma = dma_env >= 0 ? dma_env : (K >= 2048 && K % 32 == 0 ? 32 : 16);
-    if (dma && K % dma == 0 && 128.0 * 4.0 * (lda > ldw ? lda : ldw) + 4.0 * K < 4.0e9 &&
+    const bool bias_along_m = (flags & GEMM_BIAS_ALONG_M) && bias;
+    // (GELU with accumulate, or either with a bias along M: no such caller; the register-staged kernel takes them)
+    const bool epi_ok = !(bias_along_m && (flags & (GEMM_GELU | GEMM_ACCUM))) && !((flags & GEMM_GELU) && (flags & GEMM_ACCUM));
+    if (dma && epi_ok && K % dma == 0 && 128.0 * 4.0 * (lda > ldw ? lda : ldw) + 4.0 * K < 4.0e9 && 129.0 * 4.0 * ldc < 2.0e9 &&
         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (strideA % 4 == 0) && (strideW % 4 == 0)) {
         ProfScope prof(GENIE_KC_GEMM, 2.0 * mnk * K,
                        4.0 * ((double)M * K * batch + (double)N * K + mnk * ((flags & GEMM_ACCUM) ? 2 : 1)), st,
                        "gemm_f32_dma_kernel (128x128 tile, LDS-DMA, v_mfma_f32_32x32x2_f32)");
-        if (dma == 32) {
-            constexpr int lds = 2 * 2 * 128 * 32 * 4;
-            (void)hipFuncSetAttribute((const void*)gemm_f32_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            gemm_f32_dma_kernel<32><<<grid, 256, lds, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags, alpha);
-        } else {
-            constexpr int lds = 2 * 2 * 128 * 16 * 4;
-            (void)hipFuncSetAttribute((const void*)gemm_f32_dma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            gemm_f32_dma_kernel<16><<<grid, 256, lds, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags, alpha);
-        }
+        auto go = [&](auto bkc, auto geluc, auto accc, auto bmc) {
+            constexpr int BKc = decltype(bkc)::value;
+            constexpr bool G = decltype(geluc)::value, AC = decltype(accc)::value, BM = decltype(bmc)::value;
+            constexpr int lds = 2 * 2 * 128 * BKc * 4;
+            auto kern = gemm_f32_dma_kernel<BKc, G, AC, BM>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            kern<<<grid, 256, lds, st>>>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, flags, alpha);
+        };
+        auto go_bk = [&](auto bkc) {
+            const bool g = flags & GEMM_GELU, ac = flags & GEMM_ACCUM;
+            std::false_type F; std::true_type T;
+            if (bias_along_m) go(bkc, F, F, T);
+            else if (g) go(bkc, T, F, F);
+            else if (ac) go(bkc, F, T, F);
+            else go(bkc, F, F, F);
+        };
+        if (dma == 32) go_bk(std::integral_constant<int, 32>{});
+        else go_bk(std::integral_constant<int, 16>{});
         GENIE_LAUNCH_CHECK("gemm_f32_dma");
         return GENIE_OK;
     }

@@ -26,7 +26,7 @@ def run(prec, M, N, K, iters=20, check=True, gelu=0, zero=False, acc=0, pad_a=0,
     st = torch.cuda.current_stream().cuda_stream
     if prec == "exact":
         def call():
-            _lib.check(lib.genie_linear(x.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, 0, 0, st), "lin")
+            _lib.check(lib.genie_linear(x.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, gelu, acc, st), "lin")
     else:
         code = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F16X3
         npl = 1 if prec == "bf16" else 2
@@ -67,8 +67,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--prec", nargs="+", default=["exact", "f16x3", "bf16"])
-    ap.add_argument("--gelu", type=int, default=0, help="fused erf-GELU epilogue (16-bit precisions)")
-    ap.add_argument("--acc", type=int, default=0, help="residual accumulate (y += ...) epilogue (16-bit precisions)")
+    ap.add_argument("--gelu", type=int, default=0, help="fused erf-GELU epilogue")
+    ap.add_argument("--acc", type=int, default=0, help="residual accumulate (y += ...) epilogue")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power study, not a throughput figure)")
     ap.add_argument("--shapes", nargs="*", default=None, help="N:K pairs instead of the model's shapes, e.g. 1280:512 1792:512")
     ap.add_argument("--rows", type=int, default=None, help="M (default 4096 * batch)")
@@ -87,7 +87,7 @@ if __name__ == "__main__":
     for prec in a.prec:
         for name, N, K in shapes:
             m = 4096 if name == "sq4096" else M
-            ms, tf, err = run(prec, m, N, K, gelu=a.gelu if prec != "exact" else 0, zero=a.zero, acc=a.acc if prec != "exact" else 0,
+            ms, tf, err = run(prec, m, N, K, gelu=a.gelu, zero=a.zero, acc=a.acc,
                               pad_a=a.pad_a if prec != "exact" else 0, pad_c=a.pad_c if prec != "exact" else 0)
             print(f"{prec:6s} {name:8s} M={m:6d} N={N:5d} K={K:5d}  {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s  max|err| {err:.2e}",
                   flush=True)
