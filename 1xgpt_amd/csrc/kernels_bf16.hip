@@ -200,36 +200,76 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
     const bool vec = ((N | (int)ldc) & 3) == 0;
     const int c4 = (lane & 15) << 2;
     const int col = n0 + wn * 64 + c4;
-    for (int it = 0; it < 16; ++it) {
-        const int rl = it * 4 + (lane >> 4);
-        const int row = m0 + wm * 64 + rl;
-        if (row >= M) continue;
-        float vv[4];
-        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(ct + rl * 64 + c4);
-        if (vec && col + 3 < N) {
-            float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 v = make_float4(vv[0] * alpha + bv.x, vv[1] * alpha + bv.y, vv[2] * alpha + bv.z, vv[3] * alpha + bv.w);
-            if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
-            const size_t idx = (size_t)row * ldc + col;
-            if (do_acc) {
-                const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
+    typedef float ef4 __attribute__((ext_vector_type(4)));
+    const bool fast = vec && col + 3 < N;
+    ef4 bv4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias && fast) bv4 = *reinterpret_cast<const ef4*>(bias + col);   // read once, not per row
+    auto row_of = [&](int it) { return m0 + wm * 64 + it * 4 + (lane >> 4); };
+    auto value_of = [&](int it) {
+        const ef4 cv = *reinterpret_cast<const ef4*>(ct + (it * 4 + (lane >> 4)) * 64 + c4);
+        float4 v = make_float4(cv.x * alpha + bv4.x, cv.y * alpha + bv4.y, cv.z * alpha + bv4.z, cv.w * alpha + bv4.w);
+        if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+        return v;
+    };
+    auto store_row = [&](int row, float4 v) {
+        const size_t idx = (size_t)row * ldc + col;
+        if (outf) {
+            if (flags & G16_NT) {
+                ef4 t = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(t, reinterpret_cast<ef4*>(Cf + idx));
+            } else {
+                *reinterpret_cast<float4*>(Cf + idx) = v;
+            }
+        }
+        if (out16) {
+            if (flags & G16_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+            store16<NPL>(C16, (size_t)plane16, idx, v.x); store16<NPL>(C16, (size_t)plane16, idx + 1, v.y);
+            store16<NPL>(C16, (size_t)plane16, idx + 2, v.z); store16<NPL>(C16, (size_t)plane16, idx + 3, v.w);
+        }
+    };
+    if (fast && do_acc) {
+        // residual accumulate: groups of four wave-instructions in three straight sections, the next group's residual rows
+        // requested before this group's stores (see gemm16_v2_kernel's epilogue)
+        ef4 rsd[2][4];
+        auto load_group = [&](int g, ef4* dst) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = row_of(g * 4 + u);
+                dst[u] = *reinterpret_cast<const ef4*>(Rsrc + (size_t)(row < M ? row : M - 1) * ldc + col);
+            }
+        };
+        load_group(0, rsd[0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) load_group(g + 1, rsd[(g + 1) & 1]);
+            float4 vals[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 v = value_of(g * 4 + u);
+                const ef4 o = rsd[g & 1][u];
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                vals[u] = v;
             }
-            if (outf) {
-                if (flags & G16_NT) {
-                    typedef float nt4 __attribute__((ext_vector_type(4)));
-                    nt4 t = {v.x, v.y, v.z, v.w};
-                    __builtin_nontemporal_store(t, reinterpret_cast<nt4*>(Cf + idx));
-                } else {
-                    *reinterpret_cast<float4*>(Cf + idx) = v;
-                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = row_of(g * 4 + u);
+                if (row < M) store_row(row, vals[u]);
             }
-            if (out16) {
-                if (flags & G16_GELU16) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
-                store16<NPL>(C16, (size_t)plane16, idx, v.x); store16<NPL>(C16, (size_t)plane16, idx + 1, v.y);
-                store16<NPL>(C16, (size_t)plane16, idx + 2, v.z); store16<NPL>(C16, (size_t)plane16, idx + 3, v.w);
-            }
-        } else {
+        }
+    } else if (fast) {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = row_of(it);
+            const float4 v = value_of(it);
+            if (row < M) store_row(row, v);
+        }
+    } else {   // ragged N / unaligned rows: element by element
+        for (int it = 0; it < 16; ++it) {
+            const int rl = it * 4 + (lane >> 4);
+            const int row = m0 + wm * 64 + rl;
+            if (row >= M) continue;
+            const ef4 cv = *reinterpret_cast<const ef4*>(ct + rl * 64 + c4);
+            const float vv[4] = {cv.x, cv.y, cv.z, cv.w};
             for (int c = 0; c < 4; ++c) {
                 if (col + c >= N) break;
                 float v = vv[c] * alpha + (bias ? bias[col + c] : 0.f);
@@ -486,19 +526,17 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
                 ct[(rowt - q * RR) * WN_COLS + j * 32 + r] = v;
             }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-    for (int it = 0; it < RR / RPI; ++it) {
-        const int rl = it * RPI + lane / LPR;
-        const int row = m0 + wm * 64 + q * RR + rl;
-        float4 v = *reinterpret_cast<const float4*>(ct + rl * WN_COLS + c4);
-        if (row >= M || col >= N) continue;
-        v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
+    typedef float ef4 __attribute__((ext_vector_type(4)));
+    constexpr int NIT = RR / RPI;
+    auto row_of = [&](int it) { return m0 + wm * 64 + q * RR + it * RPI + lane / LPR; };
+    auto value_of = [&](int it) {   // alpha * tile + bias (+ GELU) of wave-instruction `it`
+        const ef4 cv = *reinterpret_cast<const ef4*>(ct + (it * RPI + lane / LPR) * WN_COLS + c4);
+        float4 v = make_float4(cv.x * alpha + bv.x, cv.y * alpha + bv.y, cv.z * alpha + bv.z, cv.w * alpha + bv.w);
         if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+        return v;
+    };
+    auto store_row = [&](int row, float4 v) {
         const size_t idx = (size_t)row * ldc + col;
-        if (do_acc) {
-            const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
         if (outf) {
             if (flags & G16_NT) {
                 typedef float nt4 __attribute__((ext_vector_type(4)));
@@ -524,6 +562,48 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
                 store_u2(C16 + idx, ph, flags & G16_NT);
                 store_u2(C16 + (size_t)plane16 + idx, pl, flags & G16_NT);
             }
+        }
+    };
+    if (do_acc) {
+        // Residual accumulate: rows in groups of EG wave-instructions, each group in three straight sections -- request the NEXT
+        // group's residual rows, finish this group's values in registers, store them.  The residual may alias the output, so a
+        // read written after a store stays behind it, and vmcnt retires in order: row by row (read, add, store) every row
+        // exposed a store + load round trip (proj at 4,096 rows: 23.2 -> 20.9 us).  The rows of a tile are distinct, so reading
+        // ahead is safe in place; rows past M read row M - 1 (never stored).
+        constexpr int EG = NIT % 4 == 0 ? 4 : (NIT % 2 == 0 ? 2 : 1);
+        ef4 rsd[2][EG];
+        const int colc = col < N ? col : 0;
+        auto load_group = [&](int g, ef4* dst) {
+#pragma unroll
+            for (int u = 0; u < EG; ++u) {
+                const int row = row_of(g * EG + u);
+                dst[u] = *reinterpret_cast<const ef4*>(Rsrc + (size_t)(row < M ? row : M - 1) * ldc + colc);
+            }
+        };
+        load_group(0, rsd[0]);
+#pragma unroll
+        for (int g = 0; g < NIT / EG; ++g) {
+            if (g + 1 < NIT / EG) load_group(g + 1, rsd[(g + 1) & 1]);
+            float4 vals[EG];
+#pragma unroll
+            for (int u = 0; u < EG; ++u) {
+                float4 v = value_of(g * EG + u);
+                const ef4 o = rsd[g & 1][u];
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                vals[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < EG; ++u) {
+                const int row = row_of(g * EG + u);
+                if (row < M && col < N) store_row(row, vals[u]);
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int it = 0; it < NIT; ++it) {
+            const int row = row_of(it);
+            const float4 v = value_of(it);
+            if (row < M && col < N) store_row(row, v);
         }
     }
     __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next round
