@@ -461,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
             //   V^T as [(sequence, head)][feature][256 keys] (keys of a 16-group stored {0-3, 8-11, 4-7, 12-15}): what
             //   kernels_attn_dma.hip streams straight into LDS.
             const int dm = N / 3;
+            const int hd_shift = __builtin_ctz((unsigned)head_dim);   // (the launcher admits head_dim | 64 only)
             const int which = n0e / dm;                      // 0 Q, 1 K, 2 V  (block-uniform)
             const size_t P = (size_t)plane16;               // = M * d
             uint16_t* base = C16 + (size_t)which * NPL * P;
@@ -468,10 +469,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 // rows of 8 lanes x 8 columns: one 16-byte store per 16-bit plane and lane (the 8-byte form issued twice as
                 // many store instructions for the same bytes, and the epilogue is store-ISSUE bound).  The transpose scratch
                 // XORs its 16-byte slot with (row & 1) so that the two rows a 16-lane pass reads use disjoint banks.
+                // Addresses: one buffer descriptor per tile at the sequence's block of the plane, ONE 32-bit lane offset, the
+                // (round, row group) part as a scalar offset.  (Sixteen 64-bit lane addresses per branch, hoisted out of the
+                // persistent loop, spilled -- and a scratch reload is a vmcnt wait behind the next tile's prefetch and every
+                // earlier store.)  head_dim is a power of two (32 / 64 on this path): shifts, no integer division.
                 const float qs = which == 0 ? qscale : 1.0f;
                 const int c8 = (lane & 7) << 3;
                 const int colq = n0e - which * dm + wn * 64 + c8;
-                const int hq = colq / head_dim, fq = colq - hq * head_dim;
+                const int hq = colq >> hd_shift, fq = colq & (head_dim - 1);
+                const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)(m0e >> 8) * 256 * dm), 0, -1, 0x00020000);
+                const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(base + P + (size_t)(m0e >> 8) * 256 * dm), 0, -1, 0x00020000);
+                const int voff = ((((hq << 8) + wm * 128 + (lane >> 3)) << hd_shift) + fq) * 2;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (bias) { b0 = lds_ld4(bl + c8); b1 = lds_ld4(bl + c8 + 4); }
 #pragma unroll
@@ -489,7 +497,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                         const int rl = it * 8 + (lane >> 3);
                         // head-major: [(sequence, head)][row of the sequence][feature] -- a head's 256 rows are one contiguous
                         // 256 * head_dim block, which is what the attention kernel's LDS-DMA pieces walk
-                        const size_t idx = (((size_t)(m0e >> 8) * (dm / head_dim) + hq) * 256 + (wm * 128 + q * 32 + rl)) * head_dim + fq;
+                        // (element index ((sequence * heads + hq) * 256 + row) * head_dim + fq, row = wm * 128 + q * 32 + rl)
+                        const int soff = ((q * 32 + it * 8) << hd_shift) * 2;
                         const int sw = (rl & 1) << 2;
                         float4 v = lds_ld4(ct + rl * 64 + (c8 ^ sw));
                         float4 u = lds_ld4(ct + rl * 64 + ((c8 + 4) ^ sw));
@@ -503,14 +512,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                                            (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16),
                                            (uint32_t)f32_to_bf16(u.x) | ((uint32_t)f32_to_bf16(u.y) << 16),
                                            (uint32_t)f32_to_bf16(u.z) | ((uint32_t)f32_to_bf16(u.w) << 16)};
-                            __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(base + idx));
+                            __builtin_amdgcn_raw_buffer_store_b128(t, rsH, voff, soff, 2 /* nt */);
                         } else {
                             uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
                             split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
                             split_f16_x4(u.x, u.y, u.z, u.w, h45, h67, l45, l67);
                             const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
-                            __builtin_nontemporal_store(th, reinterpret_cast<u4v*>(base + idx));
-                            __builtin_nontemporal_store(tl, reinterpret_cast<u4v*>(base + P + idx));
+                            __builtin_amdgcn_raw_buffer_store_b128(th, rsH, voff, soff, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(tl, rsL, voff, soff, 2);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -520,9 +529,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 // register group, so they go to LDS as [feature][32 keys] with float4 writes (16-byte slot XOR (feature & 7):
                 // conflict-free on both sides) and come back as 8 consecutive keys of one feature per lane = one 16-byte
                 // store per 16-bit plane.
-                const int seq = m0e >> 8;
-                const int Hn = dm / head_dim;
+                // element index ((sequence * heads + head) * head_dim + f) * 256 + key = (sequence * d + feature column) * 256 + key
                 const int fl4 = lane >> 2, kq = lane & 3;
+                const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)(m0e >> 8) * 256 * dm), 0, -1, 0x00020000);
+                const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(base + P + (size_t)(m0e >> 8) * 256 * dm), 0, -1, 0x00020000);
+                const int voff = (((n0e - 2 * dm + wn * 64 + fl4) << 8) + wm * 128 + kq * 8) * 2;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -537,15 +548,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int c = it * 16 + fl4;                                 // feature column inside the wave's 64
-                        const int cv = n0e - 2 * dm + wn * 64 + c;                   // feature column inside d
                         // key order inside a 16-key group is the PV operand's own: unit j (16 bytes) = keys {4j..4j+3, 8+4j..8+4j+3},
                         // so the attention kernel fetches a lane's 8 keys with ONE conflict-free ds_read_b128
                         const int ga = 4 * (kq >> 1) + (kq & 1);
                         const float4 a = lds_ld4(ct + c * 32 + ((ga ^ (c & 7)) << 2));
                         const float4 b = lds_ld4(ct + c * 32 + (((ga + 2) ^ (c & 7)) << 2));
                         const float bb = bias ? bl[c] : 0.f;
-                        const int head = cv / head_dim, f = cv - head * head_dim;
-                        const size_t idx = (((size_t)seq * Hn + head) * head_dim + f) * 256 + wm * 128 + q * 32 + kq * 8;
+                        const int soff = (((it * 16) << 8) + q * 32) * 2;
                         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
                         const float v0 = a.x * ascale + bb, v1 = a.y * ascale + bb, v2 = a.z * ascale + bb, v3 = a.w * ascale + bb;
                         const float v4 = b.x * ascale + bb, v5 = b.y * ascale + bb, v6 = b.z * ascale + bb, v7 = b.w * ascale + bb;
@@ -554,14 +563,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                                            (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16),
                                            (uint32_t)f32_to_bf16(v4) | ((uint32_t)f32_to_bf16(v5) << 16),
                                            (uint32_t)f32_to_bf16(v6) | ((uint32_t)f32_to_bf16(v7) << 16)};
-                            __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(base + idx));
+                            __builtin_amdgcn_raw_buffer_store_b128(t, rsH, voff, soff, 2 /* nt */);
                         } else {
                             uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
                             split_f16_x4(v0, v1, v2, v3, h01, h23, l01, l23);
                             split_f16_x4(v4, v5, v6, v7, h45, h67, l45, l67);
                             const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
-                            __builtin_nontemporal_store(th, reinterpret_cast<u4v*>(base + idx));
-                            __builtin_nontemporal_store(tl, reinterpret_cast<u4v*>(base + P + idx));
+                            __builtin_amdgcn_raw_buffer_store_b128(th, rsH, voff, soff, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(tl, rsL, voff, soff, 2);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -837,8 +846,8 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
 #endif
     {
         // compile-time epilogues for the model's Linear flavours (qkv / readout: OUTF32; proj, fc2: ACCUM | OUTF32 [| OUT16];
-        // fc1: GELU | OUT16; bf16 temporal qkv: OUT16), each with and without non-temporal stores; anything else takes the
-        // run-time-flag kernel
+        // fc1: GELU | OUT16; bf16 temporal qkv: OUT16; the training forward's fc1: OUTF32 | OUT16 | GELU16), each with and without
+        // non-temporal stores; anything else takes the run-time-flag kernel (which spills: 80-236 bytes per lane)
         const int e = flags & 127;
 #define PP_EPI(NPL_, F16_, E_)                                                                                            \
         case E_: {                                                                                                        \
@@ -862,6 +871,8 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16)                                                                    \
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16 | G16X_NT)                                                          \
             PP_EPI(NPL_, F16_, G16X_OUT16 | G16X_QKV | G16X_NT)                                                           \
+            PP_EPI(NPL_, F16_, G16X_OUTF32 | G16X_OUT16 | G16X_GELU16)         /* training forward fc1 */                 \
+            PP_EPI(NPL_, F16_, G16X_OUTF32 | G16X_OUT16 | G16X_GELU16 | G16X_NT)                                          \
             default: break;                                                                                               \
         }
         bool done = false;

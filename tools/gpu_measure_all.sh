@@ -7,9 +7,10 @@ python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_tests.txt 2>&1; tail
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 bash tools/gpu_profile_bench.sh ${TAG}_f16x3 > gpurun_out/${TAG}_profile.log 2>&1
 bash tools/gpu_profile_bench.sh ${TAG}_bf16 --precision bf16 > gpurun_out/${TAG}_profile_bf16.log 2>&1
+bash tools/gpu_profile_bench.sh ${TAG}_exact --precision exact --batch 64 > gpurun_out/${TAG}_profile_exact.log 2>&1
 bash tools/gpu_pmc_bench.sh ${TAG} f16x3 128 > gpurun_out/${TAG}_pmc.log 2>&1
 bash tools/gpu_pmc_bench.sh ${TAG} bf16 128 > gpurun_out/${TAG}_pmc_bf16.log 2>&1
-python tools/bench_generate.py --batches 1 16 --steps 2 8 > gpurun_out/${TAG}_generate.txt 2>&1
+python tools/bench_generate.py --batches 1 8 16 --steps 2 8 > gpurun_out/${TAG}_generate.txt 2>&1
 python tools/bench_forward.py > gpurun_out/${TAG}_forward.txt 2>&1
 python tools/bench_e2e.py > gpurun_out/${TAG}_e2e.json 2> gpurun_out/${TAG}_e2e.err
 tail -c 300 gpurun_out/${TAG}_bench.err
