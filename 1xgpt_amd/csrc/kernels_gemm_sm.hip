@@ -280,6 +280,10 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
     static const int on = study_env("GENIE_GEMM16_SM", 1);
     static const long max_out = study_env("GENIE_GEMM16_SM_MAX", (int)(1L << 20));
     if (!on || (long)M * N * batch > max_out) return GENIE_E_UNSUPPORTED;
+    // long contractions (fc2, K = 2048) above 512 K outputs (2,048 rows x 512): the LDS-tiled 128x128 kernel is ahead -- every
+    // workgroup here streams its operands from L2 itself, and at 32x32 tiles that is the bound (f16x3 63.4 -> 48.4 us, bf16
+    // 25.4 -> 24.1; at 1,024 rows this kernel is 1.5-1.7x ahead, `profiles/r03_sm_threshold.txt`)
+    if (K > 512 && (long)M * N * batch > (1L << 19)) return GENIE_E_UNSUPPORTED;
     if (N % 4 || ldc % 4 || lda % 8 || ldw % 8 || planeA % 8 || planeW % 8) return GENIE_E_UNSUPPORTED;
     if (npl == 2 && (flags & G16X_OUT16) && plane16 == 0) return GENIE_E_UNSUPPORTED;
     // 8 waves = 8 K-splits (every wave gets K/8 >= 64 k; at K = 512 the whole contraction is in flight at once); K = 256
