@@ -40,32 +40,24 @@ def code_objects(lib, tmp):
     return outs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("lib", nargs="?", default=os.path.join(REPO, "1xgpt_amd", "libgenie_hip.so"))
-    ap.add_argument("--kernel", default=None, help="only kernels whose demangled name contains this")
-    ap.add_argument("--dump", default=None, help="print the disassembly of kernels whose name contains this")
-    ap.add_argument("--all", action="store_true", help="also kernels without LDS-DMA")
-    a = ap.parse_args()
+def audit(lib, kernel=None, dump=None, all_kernels=False):
+    """[(demangled kernel name, #LDS-DMA, #vmcnt(0), #vmcnt(n), #barriers, #mfma, scratch bytes, vgprs)] for the library's kernels."""
     with tempfile.TemporaryDirectory() as tmp:
         dis, meta = "", ""
-        for co in code_objects(a.lib, tmp):
+        for co in code_objects(lib, tmp):
             dis += "\n" + subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
             meta += "\n" + subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-    regs = {}
-    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", meta):
-        regs[m.group(1)] = (int(m.group(2)), int(m.group(3)))
-    # llvm-readelf's note layout varies; fall back to a line scan
-    if not regs:
-        cur = {}
-        for line in meta.splitlines():
-            s = line.strip()
-            for key in (".name:", ".private_segment_fixed_size:", ".vgpr_count:", ".agpr_count:", ".group_segment_fixed_size:"):
-                if s.startswith(key) or s.startswith("- " + key):
-                    cur[key] = s.split(":", 1)[1].strip()
-            if ".vgpr_count:" in cur and ".name:" in cur and ".private_segment_fixed_size:" in cur and s.startswith(".wavefront_size"):
-                regs[cur[".name:"]] = (int(cur[".private_segment_fixed_size:"]), int(cur[".vgpr_count:"]))
-                cur = {}
+    regs, cur = {}, {}
+    for line in meta.splitlines():
+        s = line.strip()
+        if s.startswith("- "):
+            s = s[2:]
+        for key in (".name:", ".private_segment_fixed_size:", ".vgpr_count:"):
+            if s.startswith(key):
+                cur[key] = s.split(":", 1)[1].strip()
+        if s.startswith(".wavefront_size") and len(cur) == 3:
+            regs[cur[".name:"]] = (int(cur[".private_segment_fixed_size:"]), int(cur[".vgpr_count:"]))
+            cur = {}
     kernels = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:\n)", dis)
     names = subprocess.run(["c++filt"], input="\n".join(re.findall(r"<([^>]+)>:", dis)), capture_output=True, text=True).stdout.split("\n")
     rows = []
@@ -77,23 +69,33 @@ def main():
         mangled = m.group(1)
         dem = names[i] if i < len(names) else mangled
         i += 1
-        if a.kernel and a.kernel not in dem:
+        if kernel and kernel not in dem:
             continue
-        if a.dump and a.dump in dem:
+        if dump and dump in dem:
             print(f"==== {dem}\n{k}")
         dma = len(re.findall(r"buffer_load_dword\w* .* lds|global_load_lds_\w+", k))
-        if not dma and not a.all:
+        if not dma and not all_kernels:
             continue
         full = len(re.findall(r"s_waitcnt[^\n]*vmcnt\(0\)", k))
         counted = len(re.findall(r"s_waitcnt[^\n]*vmcnt\((?!0\))\d+\)", k))
         bars = len(re.findall(r"s_barrier", k))
         mfma = len(re.findall(r"v_mfma_", k))
         scratch, vg = regs.get(mangled, (-1, -1))
-        short = re.sub(r"\(.*", "", dem)
-        rows.append((short[:86], dma, full, counted, bars, mfma, scratch, vg))
+        rows.append((re.sub(r"\(.*", "", dem), dma, full, counted, bars, mfma, scratch, vg))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("lib", nargs="?", default=os.path.join(REPO, "1xgpt_amd", "libgenie_hip.so"))
+    ap.add_argument("--kernel", default=None, help="only kernels whose demangled name contains this")
+    ap.add_argument("--dump", default=None, help="print the disassembly of kernels whose name contains this")
+    ap.add_argument("--all", action="store_true", help="also kernels without LDS-DMA")
+    a = ap.parse_args()
+    rows = audit(a.lib, a.kernel, a.dump, a.all)
     print(f"# {a.lib}\n# {'kernel':86s} {'DMA':>4s} {'vmcnt(0)':>8s} {'vmcnt(n)':>8s} {'barrier':>7s} {'mfma':>5s} {'scratch':>7s} {'vgpr':>5s}")
     for r in rows:
-        print(f"{r[0]:88s} {r[1]:4d} {r[2]:8d} {r[3]:8d} {r[4]:7d} {r[5]:5d} {r[6]:7d} {r[7]:5d}")
+        print(f"{r[0][:86]:88s} {r[1]:4d} {r[2]:8d} {r[3]:8d} {r[4]:7d} {r[5]:5d} {r[6]:7d} {r[7]:5d}")
 
 
 if __name__ == "__main__":
