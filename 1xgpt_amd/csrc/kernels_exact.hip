@@ -411,8 +411,23 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 4) void gemm_f32_dma_kernel(con
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int n_tiles = (N + 127) / 128;
-    const int m0 = (blockIdx.x / n_tiles) * 128, n0 = (blockIdx.x % n_tiles) * 128;
+    // XCD-aware tile order (workgroups are dealt to the 8 XCDs round-robin): the 8 row tiles of a group go to the 8 XCDs and each
+    // XCD walks its row tile's column tiles one after the other, so an A panel is fetched into ONE L2, not into N / 128 of them
+    const int n_tiles = (N + 127) / 128, m_tiles = (M + 127) / 128;
+    int m_tile, n_tile;
+    {
+        const int bid = blockIdx.x, full = (m_tiles / 8) * 8 * n_tiles;
+        if (bid < full) {
+            const int grp = bid / (8 * n_tiles), rem = bid - grp * 8 * n_tiles;
+            m_tile = grp * 8 + (rem & 7);
+            n_tile = rem >> 3;
+        } else {
+            const int rem = bid - full;
+            m_tile = (m_tiles / 8) * 8 + rem / n_tiles;
+            n_tile = rem % n_tiles;
+        }
+    }
+    const int m0 = m_tile * 128, n0 = n_tile * 128;
     A += (size_t)blockIdx.y * strideA;
     W += (size_t)blockIdx.y * strideW;
     C += (size_t)blockIdx.y * strideC;
@@ -1255,9 +1270,12 @@ __global__ __launch_bounds__(512) void attn_spatial_f32_mfma_kernel(const float*
                     qf[kk].w = (qf[kk].w - mu) * rs * nw[c0 + 3] + nb[c0 + 3];
                 }
             }
+            // q *= scale (attention.py:48), and log2(e) with it: the softmax below is 2^(s - max) on v_exp_f32 (one instruction,
+            // ~1 ulp) instead of the library expf's dozen -- 128 of them per lane sit between the two MFMA sections
+            const float qsc = scale * 1.4426950408889634f;
 #pragma unroll
-            for (int kk = 0; kk < DH / 8; ++kk) {  // q *= scale  (attention.py:48)
-                qf[kk].x *= scale; qf[kk].y *= scale; qf[kk].z *= scale; qf[kk].w *= scale;
+            for (int kk = 0; kk < DH / 8; ++kk) {
+                qf[kk].x *= qsc; qf[kk].y *= qsc; qf[kk].z *= qsc; qf[kk].w *= qsc;
             }
         }
         // ---- S^T tiles
@@ -1286,7 +1304,7 @@ __global__ __launch_bounds__(512) void attn_spatial_f32_mfma_kernel(const float*
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sc[kt][e] = expf(sc[kt][e] - mx); sum += sc[kt][e]; }
+            for (int e = 0; e < 16; ++e) { sc[kt][e] = __builtin_amdgcn_exp2f(sc[kt][e] - mx); sum += sc[kt][e]; }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         // ---- O = P V

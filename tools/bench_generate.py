@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--model", default="c138")
     ap.add_argument("--batches", type=int, nargs="+", default=[1, 16])
     ap.add_argument("--steps", type=int, nargs="+", default=[2, 8])
+    ap.add_argument("--schedules", nargs="+", default=["full_forward", "kv_cache"], choices=["full_forward", "kv_cache"])
     a = ap.parse_args()
     cfgmod = importlib.import_module("1xgpt_amd.config")
     synth = importlib.import_module("1xgpt_amd.synthetic")
@@ -32,7 +33,7 @@ def main():
         for steps in a.steps:
             noise = torch.rand(8, max(steps - 1, 1), B, cfg.S, device="cuda")
             for name, fn in (("full_forward", G.generate_frames), ("kv_cache", G.generate_frames_cached)):
-                if name == "full_forward" and B * steps > 64:
+                if name not in a.schedules or (name == "full_forward" and B * steps > 64):
                     continue
                 fn(m, ex, 8, steps, 0.0, False, noise=noise)
                 torch.cuda.synchronize()
