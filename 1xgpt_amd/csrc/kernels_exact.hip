@@ -1845,6 +1845,49 @@ __global__ __launch_bounds__(256) void attn_temporal_single_kernel(const TI* __r
         const float var = wave_sum(c * c) / DH;
         return c * (1.0f / sqrtf(var + 1e-5f)) * nw[act ? lane : 0] + nb[act ? lane : 0];
     };
+    if constexpr (DH >= 16) {
+        if (t < 16 && !nw) {
+            // The shipped window without qk-norm: lane (j = lane / 4, c = lane % 4) takes frame j's key, features [c CH, (c + 1) CH):
+            // all t + 1 scores come out of ONE pass -- a CH-long dot product per lane and two cross-lane adds -- instead of t + 1
+            // 64-lane reductions one after the other (the kernel was bound by that chain: 58 us at 16 clips for 200 MB of cache);
+            // max / sum over the 16 frame groups are four butterfly steps each.  P.V stays lane = feature with p_j broadcast from
+            // lane 4 j; every key and value load is issued before the first use.
+            constexpr int CH = DH / 4;
+            const int j = lane >> 2, c4 = lane & 3;
+            const TI* hb = cache + ((size_t)(b * T) * S + s) * 3 * d + head * DH;
+            float qv[CH], kv[CH], vj[16];
+            load_vals<CH>(hb + (size_t)t * tok_stride + c4 * CH, qv);
+            load_vals<CH>(hb + (size_t)(j <= t ? j : t) * tok_stride + d + c4 * CH, kv);
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj)   // (frames past t re-read frame t, branch-free: their probability is 0)
+                vj[jj] = load_val(hb + (size_t)(jj <= t ? jj : t) * tok_stride + 2 * d + (act ? lane : 0));
+            // (ties the score arithmetic behind the issue of the value loads: one memory round trip, not two)
+            asm volatile("" : "+v"(qv[0]), "+v"(kv[0]) :: "memory");
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) part = fmaf(qv[e], kv[e], part);
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);
+            const float sc = j <= t ? part * scale : -INFINITY;
+            float mxs = sc;
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) mxs = fmaxf(mxs, __shfl_xor(mxs, o));
+            const float pe = j <= t ? expf(sc - mxs) : 0.f;
+            float sm = pe;
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) sm += __shfl_xor(sm, o);
+            const float pn = pe * (1.0f / sm);
+            float o16 = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) o16 = fmaf(__shfl(pn, 4 * jj), vj[jj], o16);
+            if (!act) return;
+            const size_t oi16 = (size_t)bs * d + head * DH + lane;
+            if (!out16) out[oi16] = o16;
+            else if (plane) { uint16_t hi, lo; split_f16(o16, hi, lo); out16[oi16] = hi; out16[plane + oi16] = lo; }
+            else out16[oi16] = f32_to_bf16(o16);
+            return;
+        }
+    }
     float q = norm(load_val(base + (size_t)t * tok_stride)) * scale;
     if (!act) q = 0.f;
     if (t < 16) {

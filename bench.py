@@ -694,7 +694,7 @@ def main():
                                        "parity mode: f32-class products cost 3 f16 MFMAs each, so roofline.frac <= 1/3 by "
                                        "construction (roofline.design_ceiling); the bf16 leg reported beside it has no such ceiling "
                                        "but fails the CE / bit-exact-ids clause; the clause IS met in precision `exact` (exact_evaluate: "
-                                       "f32 matrix instruction, roofline against its 157.3 TFLOP/s peak) at a third of the frames/s")
+                                       "f32 matrix instruction, roofline against its 157.3 TFLOP/s peak) at about 0.4 of the frames/s")
                    if args.precision == "f16x3" else None},
         "ce": m["loss"], "sampled_token_acc": m["acc"],
         "model_tflops_per_gpu": passes_per_step * F * args.steps / seconds / 1e12,
