@@ -133,11 +133,13 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 // The same LayerNorm for C = 256 / 512 (the shipped widths), tuned for bandwidth: a lane owns VPL = C/64 CONTIGUOUS
 // channels (32-byte loads, one 16-byte store per 16-bit plane), a wave walks 4 consecutive rows with the next row's
 // loads in flight while the current one is reduced, and gamma / beta are read once per wave.
-template <typename OutT, bool SPLIT, int VPL>
+// RPW rows per wave: 4 for the chip-filling launches, 1 when the whole problem is a few thousand rows (one-frame passes: four
+// times the waves, a quarter of the serial reduce chain per wave).
+template <typename OutT, bool SPLIT, int VPL, int RPW = 4>
 __global__ __launch_bounds__(256) void layer_norm_fast_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                               const float* __restrict__ b, OutT* __restrict__ y, long rows,
                                                               float eps, size_t plane) {
-    constexpr int C = 64 * VPL, RPW = 4;
+    constexpr int C = 64 * VPL;
     const int lane = threadIdx.x & 63;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row0 >= rows) return;
@@ -197,14 +199,22 @@ __global__ __launch_bounds__(256) void layer_norm_fast_kernel(const float* __res
             for (int k = 0; k < VPL; k += 4)
                 *reinterpret_cast<float4*>(yr + k) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
         }
+        if (r + 1 < RPW) {
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < VPL; ++k) cur[k] = nxt[k];
+        }
     }
 }
 template <typename OutT, bool SPLIT>
 static bool launch_layer_norm_fast(const float* x, const float* g, const float* b, OutT* y, long rows, int C, float eps,
                                    size_t plane, hipStream_t st) {
     if (C != 512 && C != 256) return false;
+    if (rows <= 16384) {
+        const unsigned blocks1 = (unsigned)((rows + 3) / 4);
+        if (C == 512) layer_norm_fast_kernel<OutT, SPLIT, 8, 1><<<blocks1, 256, 0, st>>>(x, g, b, y, rows, eps, plane);
+        else layer_norm_fast_kernel<OutT, SPLIT, 4, 1><<<blocks1, 256, 0, st>>>(x, g, b, y, rows, eps, plane);
+        return true;
+    }
     const unsigned blocks = (unsigned)((rows + 15) / 16);
     if (C == 512) layer_norm_fast_kernel<OutT, SPLIT, 8><<<blocks, 256, 0, st>>>(x, g, b, y, rows, eps, plane);
     else layer_norm_fast_kernel<OutT, SPLIT, 4><<<blocks, 256, 0, st>>>(x, g, b, y, rows, eps, plane);
