@@ -85,6 +85,22 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
 #pragma unroll
             for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accc[i][j][e] = 0.f; }
 
+    // The epilogue's residual and bias values of this thread (one float4 each when the tile has <= NT float4s: every shipped
+    // shape) are requested NOW: read after the reduce they were one more exposed L2 round trip of a kernel that is one round
+    // trip long.  (The residual may alias the output; this thread is the only one that writes what it reads.)
+    constexpr int C4 = TN / 4;
+    constexpr bool PRE = TM * C4 <= NT;
+    const float* Rsrc0 = Rf ? Rf + (size_t)blockIdx.y * strideC : (Cf ? Cf + (size_t)blockIdx.y * strideC : nullptr);
+    float4 pre_r = make_float4(0.f, 0.f, 0.f, 0.f), pre_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (PRE) {
+        const int rl = tid / C4, c4 = (tid % C4) * 4;
+        const int row = m0 + rl, col = n0 + c4;
+        if (tid < TM * C4 && row < M && col < N) {
+            if (bias) pre_b = *reinterpret_cast<const float4*>(bias + col);
+            if ((flags & G16X_ACCUM) && Rsrc0) pre_r = *reinterpret_cast<const float4*>(Rsrc0 + (size_t)row * ldc + col);
+        }
+    }
+
     // one block = 64 k: per (row tile, plane) a lane holds 32 values = the operands of four MFMA steps.  NB blocks are in
     // flight per wave (a register ring: a block's registers are refilled right after its MFMAs have been issued).
     struct Block {
@@ -227,7 +243,6 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
     const float* Rsrc = Rf ? Rf + (size_t)blockIdx.y * strideC : Cf;
     const bool do_gelu = flags & G16X_GELU, do_acc = flags & G16X_ACCUM;
     const bool out16 = flags & G16X_OUT16, outf = flags & G16X_OUTF32;
-    constexpr int C4 = TN / 4;
 #pragma unroll
     for (int idx4 = tid; idx4 < TM * C4; idx4 += NT) {
         const int rl = idx4 / C4, c4 = (idx4 % C4) * 4;
@@ -239,8 +254,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
         }
         const int row = m0 + rl, col = n0 + c4;
         if (row >= M || col >= N) continue;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+        float4 bv = pre_b;
+        if constexpr (!PRE) { if (bias) bv = *reinterpret_cast<const float4*>(bias + col); }
         v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
         if (do_gelu) {
             const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
@@ -248,7 +263,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
         }
         const size_t idx = (size_t)row * ldc + col;
         if (do_acc) {
-            const float4 o = *reinterpret_cast<const float4*>(Rsrc + idx);
+            float4 o = pre_r;
+            if constexpr (!PRE) o = *reinterpret_cast<const float4*>(Rsrc + idx);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
         if (outf) *reinterpret_cast<float4*>(Cf + idx) = v;
