@@ -347,7 +347,8 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="one extra profiled step: per-kernel-class times")
     ap.add_argument("--no-reuse", action="store_true",
                     help="run the reference's 15 x maskgit_steps FULL forwards per batch instead of teacher-forced "
-                         "prefix reuse (1 clean pass + maskgit_steps masked-frame passes, identical outputs)")
+                         "prefix reuse (1 clean pass + maskgit_steps masked-frame passes; same per-row arithmetic, equal up to f32 "
+                         "accumulation order)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the full-forward-schedule secondary leg (profiling runs: only headline launches in the trace)")
