@@ -146,7 +146,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     // one 8 KB piece (j = 0, 1) of a half-tile: ht 0 A-early, 1 A-late, 2 B-early, 3 B-late; all arguments wave-uniform
     auto piece = [&](int ht, int j, int buf, int kt) {
         if constexpr (ABL & 1) { if (in_loop) return; }
-        const int soff = kt * BK * 2 + (ht == 1 ? lateA : ht == 3 ? lateB : 0);
+        // (ABL & 256, study: every K-tile re-reads K-tile 0's addresses -- the same DMA instructions and LDS writes, all L2 hits)
+        const int soff = ((ABL & 256) ? 0 : kt * BK * 2) + (ht == 1 ? lateA : ht == 3 ? lateB : 0);
         unsigned char* dst = smem + buf * PP_BUF + ht * PP_HT + wid * 2048 + j * 1024;
         // ABL & 64 / & 128 (study): non-temporal policy (aux = 2) on the A / W stream
         constexpr int AUXA = (ABL & 64) ? 2 : 0, AUXW = (ABL & 128) ? 2 : 0;
@@ -833,6 +834,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     else if (abl == 16) PP_LAUNCH_ABL(16);
     else if (abl == 11) PP_LAUNCH_ABL(11);
     else if (abl == 32) PP_LAUNCH_ABL(32);
+    else if (abl == 256) PP_LAUNCH_ABL(256);   // energy study: all operand reads are L2 hits
     else if (abl == 96) PP_LAUNCH_ABL(96);     // stamps + nt on the A stream
     else if (abl == 160) PP_LAUNCH_ABL(160);   // stamps + nt on the W stream
     else if (abl == 224) PP_LAUNCH_ABL(224);   // stamps + nt on both

@@ -5,8 +5,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 _lib = importlib.import_module("1xgpt_amd._lib")
 zero = "--zero" in sys.argv
+shape = [int(a) for a in sys.argv[1:] if a.isdigit()]   # optional: M N K (default 4096 4096 4096)
 lib = _lib.load()
-M = N = K = 4096
+M, N, K = shape if len(shape) == 3 else (4096, 4096, 4096)
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn(M, K, device="cuda", generator=g); W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
 if zero:
@@ -25,4 +26,4 @@ while time.time() - t0 < 12.0:
         call()
     torch.cuda.synchronize(); n += 200
 dt = time.time() - t0
-print(("zero" if zero else "random"), f"operands: {2.0 * M * N * K * n / dt / 1e12:.1f} TFLOP/s algorithmic (x3 MFMA issue) over {dt:.1f} s")
+print(f"M={M} N={N} K={K}", ("zero" if zero else "random"), f"operands: {2.0 * M * N * K * n / dt / 1e12:.1f} TFLOP/s algorithmic (x3 MFMA issue) over {dt:.1f} s")
