@@ -26,6 +26,13 @@ __device__ __forceinline__ void split_h(float a, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((a - hf) * 2048.0f);
 }
 
+#ifdef GENIE_STUDY
+__device__ unsigned long long* g_split_stamps = nullptr;   // GENIE_SPLIT_STAMPS=1: workgroup (0,0,0), wave 0 stamps s_memtime per phase
+#define SPLIT_STAMP(i) do { if (g_split_stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_split_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPLIT_STAMP(i) do { } while (0)
+#endif
+
 template <int DH>
 __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  int d, float scale, const float* __restrict__ nw,
@@ -49,6 +56,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
     const long row0 = (long)blockIdx.x * S;
     const int head = blockIdx.y;
     const float* base = qkv + (size_t)row0 * 3 * d + head * DH;
+    SPLIT_STAMP(0);
 
     // ---- stage K: two adjacent lanes per key row, DH/2 features each (qk-norm statistics span both)
     {
@@ -120,7 +128,9 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
             }
         }
     }
+    SPLIT_STAMP(1);
     __syncthreads();
+    SPLIT_STAMP(2);
     if (qw > 0 && wid >= qw) return;
 
     const int qb = qw > 0 ? blockIdx.z * qw + wid : blockIdx.z;  // 32 queries per wave (qw = 0: per workgroup)
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
                 qh[kk][j] = a; ql[kk][j] = b;
             }
     }
+    SPLIT_STAMP(3);
     if (qw == 0) {
         // ---- KEY-SPLIT mode (a handful of sequences, e.g. one frame of batch-1 generate): the workgroup owns 32 queries and
         // its 8 waves take one 32-key tile each -- 24 MFMAs and 16 exponentials per wave instead of 192 and 128 in one wave --
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(p[e] - mw); lw += p[e]; }
         lw += __shfl_xor(lw, 32);
+        SPLIT_STAMP(4);
         float* stat = reinterpret_cast<float*>(smem + 2 * K_PLANE + 2 * VT_PLANE);  // [8 waves][32 queries][2]
         if (h == 0) { stat[(wid * 32 + r) * 2] = mw; stat[(wid * 32 + r) * 2 + 1] = lw; }
         f32x16 oa[DH / 32], oc[DH / 32];
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
                 oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[dt], 0, 0, 0);
             }
         }
+        SPLIT_STAMP(5);
         __syncthreads();  // every wave has read its K tile: the K planes become the partial-output scratch [wave][32 q][DH]
         float* op = reinterpret_cast<float*>(smem) + (size_t)wid * 32 * DH;
 #pragma unroll
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
             for (int e = 0; e < 16; ++e)
                 op[((e & 3) + 8 * (e >> 2) + 4 * h) * DH + dt * 32 + r] = oa[dt][e] + oc[dt][e] * (1.0f / 2048.0f);
         __syncthreads();
+        SPLIT_STAMP(6);
         // merge: thread -> (query, 4 features); waves in order
         constexpr int F4 = DH / 4;
         for (int idx = tid; idx < 32 * F4; idx += 512) {
@@ -262,6 +276,7 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
                                                                    (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16));
             }
         }
+        SPLIT_STAMP(7);
         return;
     }
     // ---- S^T tiles: sc[kt][e] = score(key kt*32 + (e&3) + 8(e>>2) + 4h, query r)
@@ -347,6 +362,153 @@ __global__ __launch_bounds__(512) void attn_spatial_split_kernel(const float* __
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The key-split form for a handful of (sequence, head) pairs (one frame of batch-1..4 generate) WITHOUT the LDS staging:
+// workgroup = (sequence, head, block of 32 queries), wave w = key tile w.  Every wave reads exactly the fragments its 24 matrix
+// instructions need straight from the f32 qkv rows (L2-resident: the qkv GEMM has just written them) in ONE round of loads --
+//   K tile   lane (r, h): key 32 w + r, features 16 kk + 8 h .. + 7      (A operand of S^T = K Q^T)
+//   Q block  lane (r, h): query 32 qb + r, the same features              (B operand)
+//   V tile   lane (r, h): feature 32 dt + r of keys 32 w + 4 h + 16 m + {0..3, 8..11}   (B operand of O = P V, already "transposed")
+// -- splits them in registers and merges the eight partial (max, sum, O) triples through LDS in wave order.  The staged kernel
+// above spent half of its 31 k cycles converting and transposing ALL 256 keys in every one of the eight query-block workgroups of a
+// head and then waited for its Q rows behind the staging barrier (per-phase stamps, GENIE_SPLIT_STAMPS).  No qk-norm here.
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(512) void attn_spatial_keysplit_kernel(const float* __restrict__ qkv, float* __restrict__ out, int d,
+                                                                    float scale, uint16_t* __restrict__ out16, size_t plane) {
+    constexpr int S = 256, KK = DH / 16, DT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* part = reinterpret_cast<float*>(smem);                          // [8 waves][32 queries][DH]
+    float* stat = reinterpret_cast<float*>(smem + 8 * 32 * DH * 4);         // [8 waves][32 queries][2]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long row0 = (long)blockIdx.x * S;
+    const int head = blockIdx.y, qb = blockIdx.z, kt = wid;
+    const size_t ld = (size_t)3 * d;
+    const float* base = qkv + (size_t)row0 * ld + head * DH;
+    typedef float kf4 __attribute__((ext_vector_type(4)));
+
+    // ---- one round of loads: K tile rows, Q block rows (8 floats per 16-feature step), the V values of both P V steps
+    kf4 kf[KK][2], qf[KK][2];
+    float vf[2][DT][8];
+    {
+        const float* kp = base + (size_t)(kt * 32 + r) * ld + d + 8 * h;
+        const float* qp = base + (size_t)(qb * 32 + r) * ld + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            kf[kk][0] = *reinterpret_cast<const kf4*>(kp + 16 * kk);
+            kf[kk][1] = *reinterpret_cast<const kf4*>(kp + 16 * kk + 4);
+            qf[kk][0] = *reinterpret_cast<const kf4*>(qp + 16 * kk);
+            qf[kk][1] = *reinterpret_cast<const kf4*>(qp + 16 * kk + 4);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const int key = kt * 32 + 4 * h + 16 * m + (s8 & 3) + 8 * (s8 >> 2);
+                    vf[m][dt][s8] = base[(size_t)key * ld + 2 * d + dt * 32 + r];
+                }
+    }
+    // ---- S^T tile = K Q^T on split operands (scores carried as s * log2 e: the scale goes into Q before the split)
+    const float scale_l2 = scale * 1.4426950408889634f;
+    f32x16 a0, c0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { a0[e] = 0.f; c0[e] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        f16x8 kh, kl, qh, ql;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 a, b;
+            split_h(kf[kk][j >> 2][j & 3], a, b);
+            kh[j] = a; kl[j] = b;
+            split_h(qf[kk][j >> 2][j & 3] * scale_l2, a, b);
+            qh[j] = a; ql[j] = b;
+        }
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, a0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, c0, 0, 0, 0);
+    }
+    float p[16];
+    float mw = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { p[e] = a0[e] + c0[e] * (1.0f / 2048.0f); mw = fmaxf(mw, p[e]); }
+    mw = fmaxf(mw, __shfl_xor(mw, 32));
+    float lw = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(p[e] - mw); lw += p[e]; }
+    lw += __shfl_xor(lw, 32);
+    if (h == 0) { stat[(wid * 32 + r) * 2] = mw; stat[(wid * 32 + r) * 2 + 1] = lw; }
+    // ---- partial O = P V: register e = 8 m + s8 of the score tile is slot s8 of step m (key 32 w + 4 h + 16 m + (s8&3) + 8 (s8>>2))
+    f32x16 oa[DT], oc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oa[dt][e] = 0.f; oc[dt][e] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f16x8 ph, pl;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            _Float16 a, b;
+            split_h(p[8 * m + s8], a, b);
+            ph[s8] = a; pl[s8] = b;
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f16x8 vh, vl;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                _Float16 a, b;
+                split_h(vf[m][dt][s8], a, b);
+                vh[s8] = a; vl[s8] = b;
+            }
+            oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, oa[dt], 0, 0, 0);
+            oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[dt], 0, 0, 0);
+            oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[dt], 0, 0, 0);
+        }
+    }
+    float* op = part + (size_t)wid * 32 * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            op[((e & 3) + 8 * (e >> 2) + 4 * h) * DH + dt * 32 + r] = oa[dt][e] + oc[dt][e] * (1.0f / 2048.0f);
+    __syncthreads();
+    // ---- merge like an online softmax, waves in order: thread -> (query, 4 features)
+    constexpr int F4 = DH / 4;
+    for (int idx = tid; idx < 32 * F4; idx += 512) {
+        const int q = idx / F4, f4 = (idx % F4) * 4;
+        float mg = -INFINITY;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) mg = fmaxf(mg, stat[(w8 * 32 + q) * 2]);
+        float l = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) {
+            const float sc8 = __builtin_amdgcn_exp2f(stat[(w8 * 32 + q) * 2] - mg);
+            l += stat[(w8 * 32 + q) * 2 + 1] * sc8;
+            const kf4 t = *reinterpret_cast<const kf4*>(part + ((size_t)w8 * 32 + q) * DH + f4);
+            o.x += t.x * sc8; o.y += t.y * sc8; o.z += t.z * sc8; o.w += t.w * sc8;
+        }
+        const float invl = 1.0f / l;
+        o.x *= invl; o.y *= invl; o.z *= invl; o.w *= invl;
+        const size_t oi = (size_t)(row0 + qb * 32 + q) * d + head * DH + f4;
+        if (!out16) *reinterpret_cast<float4*>(out + oi) = o;
+        else if (plane) {
+            uint32_t h01, h23, l01, l23;
+            split_f16_x4(o.x, o.y, o.z, o.w, h01, h23, l01, l23);
+            *reinterpret_cast<uint2*>(out16 + oi) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(out16 + plane + oi) = make_uint2(l01, l23);
+        } else {
+            *reinterpret_cast<uint2*>(out16 + oi) = make_uint2((uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16),
+                                                               (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16));
+        }
+    }
+}
+
 // Same contract as launch_attn_spatial_f32_mfma (f32 qkv in; f32 / split-f16 / bf16 out); S = 256 only.
 int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, int d, int H, int Dh, float scale,
                               const float* nw, const float* nb, hipStream_t st, uint16_t* out16, size_t plane) {
@@ -358,10 +520,43 @@ int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, i
     const int qw = n_seq * H <= 32 ? (ksplit ? 0 : 1) : (n_seq * H <= 64 ? 2 : (n_seq * H <= 128 ? 4 : 8));
     dim3 grid((unsigned)n_seq, H, qw ? 8 / qw : 8);
     ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * Dh * H * (double)n_seq, (double)n_seq * S * H * Dh * 16.0, st);
+    static const int direct = study_env("GENIE_ATTN_KEYSPLIT_DIRECT", 1);
+    if (qw == 0 && !nw && direct) {   // a handful of pairs, no qk-norm: fragments straight from the qkv rows, no LDS staging
+        const size_t lds2 = (size_t)8 * 32 * Dh * 4 + 2048;
+        if (Dh == 64) {
+            (void)hipFuncSetAttribute((const void*)attn_spatial_keysplit_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attn_spatial_keysplit_kernel<64><<<grid, 512, lds2, st>>>(qkv, out, d, scale, out16, plane);
+        } else {
+            (void)hipFuncSetAttribute((const void*)attn_spatial_keysplit_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attn_spatial_keysplit_kernel<32><<<grid, 512, lds2, st>>>(qkv, out, d, scale, out16, plane);
+        }
+        GENIE_LAUNCH_CHECK("attn_spatial_keysplit");
+        return GENIE_OK;
+    }
+#ifdef GENIE_STUDY   // per-phase s_memtime stamps of workgroup 0 (synchronises inside the launch: study builds only)
+    static const int stamps = study_env("GENIE_SPLIT_STAMPS", 0);
+    static unsigned long long* dstamps = nullptr;
+    if (stamps && !dstamps) {
+        (void)hipMalloc(&dstamps, 8 * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_stamps), &dstamps, sizeof(dstamps));
+    }
+#endif
     if (Dh == 64) {
         (void)hipFuncSetAttribute((const void*)attn_spatial_split_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attn_spatial_split_kernel<64><<<grid, 512, lds, st>>>(qkv, out, d, scale, nw, nb, out16, plane, qw);
+#ifdef GENIE_STUDY
+        if (stamps && qw == 0) {
+            static int shown = 0;
+            if (shown++ % 512 == 100) {
+                unsigned long long hb[8];
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(hb, dstamps, sizeof(hb), hipMemcpyDeviceToHost);
+                fprintf(stderr, "split_stamps (ticks since start): staged %llu barrier %llu qsplit %llu qk+softmax %llu pv %llu partials %llu merge-start %llu end %llu\n",
+                        hb[1] - hb[0], hb[2] - hb[0], hb[3] - hb[0], hb[4] - hb[0], hb[5] - hb[0], hb[6] - hb[0], hb[6] - hb[0], hb[7] - hb[0]);
+            }
+        }
+#endif
     } else {
         (void)hipFuncSetAttribute((const void*)attn_spatial_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
