@@ -520,7 +520,8 @@ int launch_attn_spatial_split(const float* qkv, float* out, int S, long n_seq, i
     // key split up to 256 pairs (32 clips of a one-frame pass): with the direct kernel it is ahead of the staged query-split
     // modes everywhere below the fused chip-filling path (+4 % generate at 6-8 clips, +0.5-1 % at 16-32: profiles/r03_keysplit_pairs.txt)
     static const int ks_pairs = study_env("GENIE_ATTN_KEYSPLIT_MAX_PAIRS", 256);
-    const int qw = n_seq * H <= ks_pairs ? (ksplit ? 0 : 1) : (n_seq * H <= 64 ? 2 : (n_seq * H <= 128 ? 4 : 8));
+    // (qk-norm models keep the staged kernel, whose key split pays up to 32 pairs only)
+    const int qw = n_seq * H <= (nw ? 32 : ks_pairs) ? (ksplit ? 0 : 1) : (n_seq * H <= 64 ? 2 : (n_seq * H <= 128 ? 4 : 8));
     dim3 grid((unsigned)n_seq, H, qw ? 8 / qw : 8);
     ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * Dh * H * (double)n_seq, (double)n_seq * S * H * Dh * 16.0, st);
     static const int direct = study_env("GENIE_ATTN_KEYSPLIT_DIRECT", 1);
