@@ -8,5 +8,6 @@ cd $GRAFT_REPO_ROOT
 db=$(find gpurun_out/${TAG}_trace -name "*.db" | head -1)
 echo "# cd /tmp && rocprofv3 --kernel-trace -- python3 tools/bench_generate.py $@" > gpurun_out/${TAG}_kernel_stats.txt
 python tools/rocprof_summary.py "$db" gpurun_out/${TAG}_kernel_stats.txt | head -40
+python tools/rocprof_gaps.py "$db" gpurun_out/${TAG}_kernel_stats.txt
 rm -rf gpurun_out/${TAG}_trace
 cat gpurun_out/${TAG}_generate.txt | head -5
