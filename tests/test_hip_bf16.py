@@ -34,7 +34,8 @@ def models(golden):
 
 @pytest.mark.parametrize("prec", ["bf16", "f16x3"])
 @pytest.mark.parametrize("M,N,K", [(128, 192, 64), (100, 70, 64), (513, 1024, 256), (4096, 1536, 512), (37, 64, 2048),
-                                   (256, 1536, 512), (256, 512, 512), (256, 2048, 512), (256, 512, 2048), (250, 1024, 512)])
+                                   (256, 1536, 512), (256, 512, 512), (256, 2048, 512), (256, 512, 2048), (250, 1024, 512),
+                                   (2048, 512, 2048), (4096, 512, 512), (1000, 512, 512)])
 def test_linear_lowp(prec, M, N, K):
     """genie_linear_lowp on pre-packed operands vs float64 on the SAME rounded operands (asymmetric, ragged M/N).  The
     256-row shapes are one frame of the batch-1 generate path: the split-K small-problem kernel (kernels_gemm_sm.hip)."""
@@ -65,6 +66,10 @@ def test_linear_lowp(prec, M, N, K):
     yd = dev(y0.copy())
     lib_mod.check(L.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), 0, yd.data_ptr(), M, N, K, 1, 1, st), "lowp")
     assert np.abs(yd.cpu().numpy() - (y0 + O.gelu_erf(ref - b))).max() < 2 * tol
+    # residual accumulate WITH the bias (proj / fc2 of the model: the epilogue reads both ahead of its stores)
+    yd = dev(y0.copy())
+    lib_mod.check(L.genie_linear_lowp(code, x16.data_ptr(), W16.data_ptr(), bd.data_ptr(), yd.data_ptr(), M, N, K, 0, 1, st), "lowp")
+    assert np.abs(yd.cpu().numpy() - (y0 + ref)).max() < 2 * tol
 
 
 @pytest.mark.parametrize("name", ["tiny_ln", "tiny_qknorm", "tiny_mup", "tiny_qknorm_mup"])

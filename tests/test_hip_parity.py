@@ -57,6 +57,9 @@ def test_linear(M, N, K):
     out = dev(y0.copy())
     att.hip_linear(dev(x), dev(W), None, out=out, accumulate=True)
     assert np.abs(out.cpu().numpy() - (y0 + ref - b)).max() < 3e-5 * max(1.0, np.abs(ref).max())
+    out = dev(y0.copy())   # accumulate with the bias (proj / fc2): residual and bias both read ahead of the tile's stores
+    att.hip_linear(dev(x), dev(W), dev(b), out=out, accumulate=True)
+    assert np.abs(out.cpu().numpy() - (y0 + ref)).max() < 3e-5 * max(1.0, np.abs(ref).max())
 
 
 def test_layer_norm():
