@@ -771,6 +771,43 @@ int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const ui
                             strideA, strideC, Rf, strideW, /*weights_on_w=*/false);
 }
 
+// ---- fc2 of the one-frame passes at 2,048-4,096 rows (generate at 8-16 clips): N = d = 512 gives 64-128 tiles of 128x128 for a
+// K = 2,048 contraction -- half of the CUs idle and a 64-step K chain.  Split K in two over the GEMM's batch index (256 workgroups,
+// 32 steps each) into two f32 slabs in the (idle) logits scratch, then x += bias + slab0 + slab1 in that fixed order
+// (profiles/r03_fc2_splitk_ab.txt).  Only when the 16-bit shadow of x is not wanted (every layer but the last of a LayerNorm model).
+__global__ __launch_bounds__(256) void splitk2_residual_kernel(float* __restrict__ x, const float* __restrict__ s0,
+                                                               const float* __restrict__ s1, const float* __restrict__ bias,
+                                                               size_t n4, int N) {
+    typedef float sk4 __attribute__((ext_vector_type(4)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    sk4 v = reinterpret_cast<const sk4*>(x)[i];
+    const sk4 a = reinterpret_cast<const sk4*>(s0)[i], b = reinterpret_cast<const sk4*>(s1)[i];
+    sk4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const sk4*>(bias + (i * 4) % (size_t)N);
+    v = v + ((a + bv) + b);
+    reinterpret_cast<sk4*>(x)[i] = v;
+}
+// returns GENIE_E_UNSUPPORTED when the shape is not in that range (the caller then runs the fused-epilogue GEMM)
+template <int NPL>
+static int fc2_splitk2(const genie_cfg& c, const uint16_t* h16, long plane_h, const uint16_t* w16, long plane_w, const float* bias,
+                       float* x, Workspace& w, int M, hipStream_t st) {
+    static const int on = study_env("GENIE_FC2_SPLITK", 1);
+    const int d = c.d_model, K = c.hidden;
+    const long tiles = (long)((M + 127) / 128) * ((d + 127) / 128);
+    const size_t V = (size_t)c.factored_vocab * c.num_factored;
+    if (!on || !w.skip_shadow_mlp || !w.logits || K < 2048 || K % 256 || d % 4 || tiles > 128 || (long)M * d <= (1L << 19) ||
+        V < 2 * (size_t)d || weight_is_wide(w16))
+        return GENIE_E_UNSUPPORTED;
+    float* slabs = w.logits;
+    GENIE_TRY(launch_gemm16<NPL>(h16, K, plane_h, w16, K, plane_w, nullptr, slabs, nullptr, 0, d, M, d, K / 2, G16_OUTF32, 1.0f, st,
+                                 2, (long)(K / 2), (long)M * d, nullptr, (long)(K / 2), true, false));
+    const size_t n4 = (size_t)M * d / 4;
+    splitk2_residual_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(x, slabs, slabs + (size_t)M * d, bias, n4, d);
+    GENIE_LAUNCH_CHECK("splitk2_residual");
+    return GENIE_OK;
+}
+
 // ---- elementwise helpers -----------------------------------------------------------------------
 __global__ void cast16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -920,6 +957,10 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.fc1_w16, d, 0, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, big16, 0, c.hidden,
                                M, c.hidden, d, G16_GELU | G16_OUT16, 1.0f, st));
     }
+    {
+        const int rs = fc2_splitk2<1>(c, big16, 0, lw.fc2_w16, 0, c.mlp_bias ? lw.fc2_b : nullptr, x, w, M, st);
+        if (rs != GENIE_E_UNSUPPORTED) return rs;
+    }
     GENIE_TRY(launch_gemm16<1>(big16, c.hidden, 0, lw.fc2_w16, c.hidden, 0, c.mlp_bias ? lw.fc2_b : nullptr, x, x16, 0,
                                d, M, d, c.hidden, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
     return GENIE_OK;
@@ -1068,6 +1109,10 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
                                hid, d, G16_GELU | G16_OUT16, 1.0f, st));
     }
     GENIE_STUDY_CLASS(5);
+    {
+        const int rs = fc2_splitk2<2>(c, hs, (long)ph, lw.fc2_w16, (long)pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, w, M, st);
+        if (rs != GENIE_E_UNSUPPORTED) return rs;
+    }
     GENIE_TRY(launch_gemm16<2>(hs, hid, ph, lw.fc2_w16, hid, pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, xs, pd, d, M, d,
                                hid, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
     return GENIE_OK;
