@@ -29,23 +29,29 @@ class GenieCfg(C.Structure):
 
 
 class AttnWeights(C.Structure):
-    _fields_ = [(n, c_ptr) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "norm_w", "norm_b", "qkv_w16", "proj_w16")]
+    _fields_ = [(n, c_ptr) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "norm_w", "norm_b", "qkv_w16", "proj_w16",
+                                     "fused_w16")] + [("w16_wide", C.c_int32)]
 
 
 class LayerWeights(C.Structure):
     _fields_ = [("norm1_w", c_ptr), ("norm1_b", c_ptr), ("spatial", AttnWeights), ("temporal", AttnWeights),
                 ("norm2_w", c_ptr), ("norm2_b", c_ptr), ("fc1_w", c_ptr), ("fc1_b", c_ptr), ("fc2_w", c_ptr),
-                ("fc2_b", c_ptr), ("fc1_w16", c_ptr), ("fc2_w16", c_ptr)]
+                ("fc2_b", c_ptr), ("fc1_w16", c_ptr), ("fc2_w16", c_ptr), ("mlp_fused_w16", c_ptr), ("w16_wide", C.c_int32)]
 
 
 class Weights(C.Structure):
     _fields_ = [("pos_embed", c_ptr), ("mask_embed", c_ptr), ("embed", c_ptr * 4), ("out_w", c_ptr),
-                ("out_b", c_ptr), ("out_w16", c_ptr), ("layers_host", C.POINTER(LayerWeights))]
+                ("out_b", c_ptr), ("out_w16", c_ptr), ("layers_host", C.POINTER(LayerWeights)), ("out_w16_wide", C.c_int32)]
+
+WIDE_QKV, WIDE_PROJ, WIDE_FC1, WIDE_FC2 = 1, 2, 1, 2          # bits of the w16_wide fields (genie_hip.h)
+TEMPORAL_FUSED_ELEMS, MLP_FUSED_ELEMS = 262144, 524288        # bf16 values of the fused kernels' weight streams
+ABI_VERSION = 2
 
 
 # name -> (restype, argtypes); must list every symbol include/genie_hip.h declares
 SIGNATURES = {
     "genie_version": (C.c_int, []),
+    "genie_abi_layout": (C.c_int, [C.POINTER(C.c_size_t), C.c_int]),
     "genie_last_error": (C.c_char_p, []),
     "genie_check_config": (C.c_int, [C.POINTER(GenieCfg)]),
     "genie_workspace_bytes": (C.c_size_t, [C.POINTER(GenieCfg), C.c_int]),
@@ -108,7 +114,8 @@ SIGNATURES = {
     "genie_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "genie_profile_kernels": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "genie_study_build": (C.c_int, []),
-    "genie_weight_range_hint": (C.c_int, [c_ptr, C.c_int]),
+    "genie_pack_temporal_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
+    "genie_pack_mlp_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_bits_from_tokens": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_rescale_u8_bf16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_rescale_u8_f32": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
@@ -156,8 +163,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.genie_version() != 1:
-            raise RuntimeError(f"libgenie_hip ABI version {lib.genie_version()} != 1")
+        if lib.genie_version() != ABI_VERSION:
+            raise RuntimeError(f"libgenie_hip ABI version {lib.genie_version()} != {ABI_VERSION}")
         if os.environ.get("GENIE_HIP_LIBRARY") or lib.genie_study_build():
             import sys
             print(f"1xgpt_amd: using {LIB_PATH} (study build: {bool(lib.genie_study_build())}) -- not the shipping library",

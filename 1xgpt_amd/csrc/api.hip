@@ -3,6 +3,7 @@
 // stream; nothing here allocates, synchronises or touches the host-side of any tensor.
 #include <math.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -246,6 +247,14 @@ using namespace genie;
 extern "C" {
 
 int genie_version(void) { return GENIE_ABI_VERSION; }
+int genie_abi_layout(size_t* out_host, int n) {
+    const size_t v[9] = {sizeof(genie_cfg), sizeof(genie_attn_weights), offsetof(genie_attn_weights, fused_w16),
+                         offsetof(genie_attn_weights, w16_wide), sizeof(genie_layer_weights),
+                         offsetof(genie_layer_weights, mlp_fused_w16), offsetof(genie_layer_weights, w16_wide),
+                         sizeof(genie_weights), offsetof(genie_weights, out_w16_wide)};
+    for (int i = 0; i < n && i < 9 && out_host; ++i) out_host[i] = v[i];
+    return 9;
+}
 const char* genie_last_error(void) { return g_err; }
 int genie_check_config(const genie_cfg* cfg) { return check_cfg(cfg); }
 
@@ -668,9 +677,13 @@ int genie_profile_kernels(int kernel_class, char* buf, size_t buf_bytes) {
     return GENIE_OK;
 }
 
-int genie_weight_range_hint(const void* w16, int wide) {
-    GENIE_CHECK_ARG(w16 != nullptr, "weight_range_hint: NULL weight");
-    return set_weight_wide(w16, wide);
+int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream) {
+    GENIE_CHECK_ARG(qkv_w && proj_w && dst, "pack_temporal_fused: NULL pointer");
+    return launch_pack_temporal_fused(qkv_w, proj_w, dst, as_stream(stream));
+}
+int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream) {
+    GENIE_CHECK_ARG(fc1_w && fc2_w && dst, "pack_mlp_fused: NULL pointer");
+    return launch_pack_mlp_fused(fc1_w, fc2_w, dst, as_stream(stream));
 }
 
 int genie_study_build(void) { return kStudyBuild ? 1 : 0; }

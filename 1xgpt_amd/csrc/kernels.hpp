@@ -47,9 +47,11 @@ inline bool temporal_qkv16(const genie_cfg& c, int model_T) {
     return c.precision == GENIE_PREC_BF16 && (model_T > 0 ? model_T : c.T) <= 16 && (c.head_dim == 32 || c.head_dim == 64);
 }
 
-// f16x3 weight tensors with |w| >= 32 (kernels_bf16.hip): kept off the 2^11-scaling single-accumulator GEMM
-bool weight_is_wide(const void* W16);
-int set_weight_wide(const void* W16, int wide);
+// kernels_fused.hip: fused sub-blocks of the shipped geometry (GENIE_PREC_BF16, d 256); GENIE_E_UNSUPPORTED otherwise
+int launch_pack_temporal_fused(const float* qkv_w, const float* proj_w, uint16_t* out, hipStream_t st);
+int launch_pack_mlp_fused(const float* fc1_w, const float* fc2_w, uint16_t* out, hipStream_t st);
+int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
+                               hipStream_t st);
 
 // Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
 // tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.

@@ -25,7 +25,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum { G16_GELU = 1, G16_ACCUM = 2, G16_OUT16 = 4, G16_OUTF32 = 8,
        G16_GELU16 = 16, /* erf-GELU on the 16-bit output only: Cf keeps the pre-activation (training forward) */
-       G16_NT = 32      /* non-temporal output stores: the output is larger than the on-die caches (launcher) */ };
+       G16_NT = 32,     /* non-temporal output stores: the output is larger than the on-die caches (launcher) */
+       G16_WIDEW = 1024 /* launcher only (never reaches a kernel): the f16x3 weight's hi plane reaches |w| >= 32 -> not the
+                           2^11-scaling single-accumulator kernel (the `w16_wide` flags of genie_hip.h) */ };
 
 constexpr float SPLIT_INV = 1.0f / 2048.0f;
 
@@ -610,28 +612,10 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     }
 }
 
-// Weight tensors whose packed hi plane reaches |w| >= 32 (genie_weight_range_hint): the single-accumulator split GEMM
-// (gemm16_pp) multiplies the hi plane by 2^11 in f16, exact below 32 only, so these run on the two-accumulator kernels
-// (gemm16_v2 / gemm16_nt / gemm16_sm: hi.hi and the cross terms in separate accumulators, no operand scaling; limit = the f16 range).
-static std::vector<const void*> g_wide_weights;
-static std::mutex g_wide_mutex;
-bool weight_is_wide(const void* W) {
-    if (g_wide_weights.empty()) return false;
-    std::lock_guard<std::mutex> lk(g_wide_mutex);
-    for (const void* p : g_wide_weights)
-        if (p == W) return true;
-    return false;
-}
-int set_weight_wide(const void* W, int wide) {
-    std::lock_guard<std::mutex> lk(g_wide_mutex);
-    for (size_t i = 0; i < g_wide_weights.size(); ++i)
-        if (g_wide_weights[i] == W) {
-            if (!wide) g_wide_weights.erase(g_wide_weights.begin() + (long)i);
-            return GENIE_OK;
-        }
-    if (wide) g_wide_weights.push_back(W);
-    return GENIE_OK;
-}
+// Weight tensors whose packed hi plane reaches |w| >= 32 (the `w16_wide` flags of the weight structs, genie_hip.h): the
+// single-accumulator split GEMM (gemm16_pp) multiplies the hi plane by 2^11 in f16, exact below 32 only, so the layer drivers pass
+// weights_on_w = false for these and they run on the two-accumulator kernels (gemm16_v2 / gemm16_nt / gemm16_sm: hi.hi and the
+// cross terms in separate accumulators, no operand scaling; limit = the f16 range).
 
 #ifdef GENIE_STUDY
 int g_study_gemm_class = 0, g_study_layer = 0;
@@ -656,6 +640,7 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
     GENIE_CHECK_SHAPE(K % BK == 0 && K > 0, "gemm16: K=%d must be a positive multiple of %d", K, BK);
     GENIE_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "gemm16: leading dims must be multiples of 8 elements");
     if (M <= 0 || N <= 0) return GENIE_OK;
+    if (flags & G16_WIDEW) { weights_on_w = false; flags &= ~G16_WIDEW; }
     const double mn = (double)M * N * batch;
     {   // outputs that cannot stay in the 256 MB Infinity Cache anyway are stored non-temporally: +10..18 % on the
         // K = 512 GEMMs at >= 8 clips (they no longer evict the A panel / weights they share the L2 with)
@@ -672,7 +657,7 @@ static int launch_gemm16(const uint16_t* A, long lda, long planeA, const uint16_
 #else
         constexpr int terms = 3;
 #endif
-        if (pp && (NPL == 1 || (weights_on_w && !weight_is_wide(W)))) {
+        if (pp && (NPL == 1 || weights_on_w)) {
             const int npl = (NPL == 2 && terms == 1) ? 1 : NPL;
             const int rc = launch_gemm16_pp(npl, terms, NPL == 2, A, lda, planeA, W, ldw, planeW, bias, Rf, Cf, C16, plane16,
                                             ldc, M, N, K, flags, alpha, st, batch, strideA, strideW, strideC);
@@ -774,7 +759,8 @@ int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const ui
 // ---- fc2 of the one-frame passes at 2,048-4,096 rows (generate at 8-16 clips): N = d = 512 gives 64-128 tiles of 128x128 for a
 // K = 2,048 contraction -- half of the CUs idle and a 64-step K chain.  Split K in two over the GEMM's batch index (256 workgroups,
 // 32 steps each) into two f32 slabs in the (idle) logits scratch, then x += bias + slab0 + slab1 in that fixed order
-// (profiles/r03_fc2_splitk_ab.txt).  Only when the 16-bit shadow of x is not wanted (every layer but the last of a LayerNorm model).
+// (profiles/r03_fc2_splitk_ab.txt).  Only in the one-frame passes of generate (w.frame_t >= 0) and only when the 16-bit shadow of x is
+// not wanted (every layer but the last of a LayerNorm model): full forwards keep the single fused K chain at every batch size.
 __global__ __launch_bounds__(256) void splitk2_residual_kernel(float* __restrict__ x, const float* __restrict__ s0,
                                                                const float* __restrict__ s1, const float* __restrict__ bias,
                                                                size_t n4, int N) {
@@ -791,13 +777,14 @@ __global__ __launch_bounds__(256) void splitk2_residual_kernel(float* __restrict
 // returns GENIE_E_UNSUPPORTED when the shape is not in that range (the caller then runs the fused-epilogue GEMM)
 template <int NPL>
 static int fc2_splitk2(const genie_cfg& c, const uint16_t* h16, long plane_h, const uint16_t* w16, long plane_w, const float* bias,
-                       float* x, Workspace& w, int M, hipStream_t st) {
+                       float* x, Workspace& w, int M, hipStream_t st, bool wide = false) {
     static const int on = study_env("GENIE_FC2_SPLITK", 1);
     const int d = c.d_model, K = c.hidden;
     const long tiles = (long)((M + 127) / 128) * ((d + 127) / 128);
     const size_t V = (size_t)c.factored_vocab * c.num_factored;
-    if (!on || !w.skip_shadow_mlp || !w.logits || K < 2048 || K % 256 || d % 4 || tiles > 128 || (long)M * d <= (1L << 19) ||
-        V < 2 * (size_t)d || weight_is_wide(w16))
+    if (!on || w.frame_t < 0 /* one-frame passes only: a clip's fc2 sum order must not depend on the batch size of a full forward */ ||
+        !w.skip_shadow_mlp || !w.logits || K < 2048 || K % 256 || d % 4 || tiles > 128 || (long)M * d <= (1L << 19) ||
+        V < 2 * (size_t)d || wide)
         return GENIE_E_UNSUPPORTED;
     float* slabs = w.logits;
     GENIE_TRY(launch_gemm16<NPL>(h16, K, plane_h, w16, K, plane_w, nullptr, slabs, nullptr, 0, d, M, d, K / 2, G16_OUTF32, 1.0f, st,
@@ -827,7 +814,7 @@ static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_laye
 #ifdef GENIE_STUDY
     if (npl == 2 && study_terms() != 3) return GENIE_E_UNSUPPORTED;
 #endif
-    if (npl == 2 && weight_is_wide(lw.spatial.qkv_w16)) return GENIE_E_UNSUPPORTED;  // |w| >= 32: two-accumulator GEMM + f32-qkv attention
+    if (npl == 2 && (lw.spatial.w16_wide & GENIE_WIDE_QKV)) return GENIE_E_UNSUPPORTED;  // |w| >= 32: two-accumulator GEMM + f32-qkv attention
     if (!on || c.S != 256 || c.qk_norm || (c.head_dim != 64 && c.head_dim != 32) || d % 256 || d != c.num_heads * c.head_dim)
         return GENIE_E_UNSUPPORTED;
     const long n_seq = (long)B * c.T;
@@ -898,6 +885,15 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     const int oflag = t16 ? G16_OUT16 : G16_OUTF32;
     float* tq = w.tqkv ? w.tqkv : qkv;
     uint16_t* tq16 = reinterpret_cast<uint16_t*>(tq);
+    bool temporal_done = false;
+    if (w.frame_t < 0 && !w.tqkv && !w.tcache && !w.stop_after_tqkv && t16) {
+        // plain full-clip forward of the shipped geometry: qkv + attention + proj + residual in ONE kernel, the qkv never
+        // leaves the registers (kernels_fused.hip); same rounding points as the launches below
+        rc = launch_temporal_fused_bf16(c, lw.temporal, x16, x, B, st);
+        if (rc == GENIE_OK) temporal_done = true;
+        else if (rc != GENIE_E_UNSUPPORTED) return rc;
+    }
+    if (!temporal_done) {
     if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
         float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
         uint16_t* slot16 = reinterpret_cast<uint16_t*>(w.fcache) + (size_t)w.frame_t * c.S * 3 * d;
@@ -940,6 +936,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     // block's spatial qkv only in the qk-norm variant, the readout after the last block
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.temporal.proj_w16, d, 0, c.proj_bias ? lw.temporal.proj_b : nullptr, x,
                                x16, 0, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
+    }
     // MLP
     u = x16;
     bool fc1_done = false;
@@ -1006,6 +1003,10 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
                         lw.fc1_w16 && lw.fc2_w16,
                     "f16x3 precision needs split-f16 weights (genie_pack_split_f16)");
     const size_t pw_qkv = (size_t)3 * d * d, pw_proj = (size_t)d * d, pw_fc = (size_t)hid * d;
+    // |w| >= 32 range flags of the packed tensors (genie_hip.h): those Linears stay off the 2^11-scaling kernel
+    const int wsq = (lw.spatial.w16_wide & GENIE_WIDE_QKV) ? G16_WIDEW : 0, wsp = (lw.spatial.w16_wide & GENIE_WIDE_PROJ) ? G16_WIDEW : 0;
+    const int wtq = (lw.temporal.w16_wide & GENIE_WIDE_QKV) ? G16_WIDEW : 0, wtp = (lw.temporal.w16_wide & GENIE_WIDE_PROJ) ? G16_WIDEW : 0;
+    const int wf1 = (lw.w16_wide & GENIE_WIDE_FC1) ? G16_WIDEW : 0, wf2 = (lw.w16_wide & GENIE_WIDE_FC2) ? G16_WIDEW : 0;
     const float* nws = c.qk_norm ? lw.spatial.norm_w : nullptr;
     const float* nbs = c.qk_norm ? lw.spatial.norm_b : nullptr;
     const float* nwt = c.qk_norm ? lw.temporal.norm_w : nullptr;
@@ -1032,7 +1033,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     if (rc == GENIE_E_UNSUPPORTED) {
     if (!qkv_done)
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.spatial.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv,
-                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32 | wsq, 1.0f, st));
     rc = launch_attn_spatial_split(qkv, nullptr, c.S, (long)B * c.T, d, c.num_heads, c.head_dim, c.attn_scale, nws,
                                    nbs, st, as, pd);
     if (rc == GENIE_E_UNSUPPORTED) {  // generic kernel writes f32 into x-sized scratch (logits region), then split
@@ -1045,14 +1046,14 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     GENIE_TRY(rc);
     GENIE_STUDY_CLASS(2);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.spatial.proj_w16, d, pw_proj, c.proj_bias ? lw.spatial.proj_b : nullptr, x,
-                               xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
+                               xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16 | wsp, 1.0f, st));
     // ---- temporal
     GENIE_STUDY_CLASS(1);
     float* tq = w.tqkv ? w.tqkv : qkv;
     if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
         float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
         GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr,
-                                   slot, nullptr, 0, 3 * d, c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.S * d,
+                                   slot, nullptr, 0, 3 * d, c.S, 3 * d, d, G16_OUTF32 | wtq, 1.0f, st, B, (long)c.S * d,
                                    (long)w.frame_T * c.S * 3 * d));
         rc = launch_attn_temporal_single(w.fcache, nullptr, B, w.frame_T, c.S, w.frame_t, d, c.num_heads, c.head_dim,
                                          c.attn_scale, nwt, nbt, st, as, pd);
@@ -1060,11 +1061,11 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     const int Tq = (w.tqkv && w.tq_frames > c.T) ? w.tq_frames : c.T;  // frames per clip in tq's layout
     if (Tq != c.T && B > 1)  // a short clean pass into a longer cache: one GEMM batch entry per clip
         GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
-                                   nullptr, 0, 3 * d, c.T * c.S, 3 * d, d, G16_OUTF32, 1.0f, st, B, (long)c.T * c.S * d,
+                                   nullptr, 0, 3 * d, c.T * c.S, 3 * d, d, G16_OUTF32 | wtq, 1.0f, st, B, (long)c.T * c.S * d,
                                    (long)Tq * c.S * 3 * d));
     else
     GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr, tq,
-                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32, 1.0f, st));
+                               nullptr, 0, 3 * d, M, 3 * d, d, G16_OUTF32 | wtq, 1.0f, st));
     if (w.stop_after_tqkv) return GENIE_OK;
     if (w.tcache) {
         rc = launch_attn_temporal_prefix(tq, w.tcache, nullptr, B, c.T, c.S, d, c.num_heads, c.head_dim, c.attn_scale,
@@ -1089,7 +1090,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     GENIE_TRY(rc);
     GENIE_STUDY_CLASS(3);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.temporal.proj_w16, d, pw_proj, c.proj_bias ? lw.temporal.proj_b : nullptr,
-                               x, xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
+                               x, xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0) | wtp, 1.0f, st));
     // ---- MLP
     GENIE_STUDY_CLASS(4);
     u = xs;
@@ -1106,15 +1107,15 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
         u = as;
     }
     GENIE_TRY(launch_gemm16<2>(u, d, pd, lw.fc1_w16, d, pw_fc, c.mlp_bias ? lw.fc1_b : nullptr, nullptr, hs, ph, hid, M,
-                               hid, d, G16_GELU | G16_OUT16, 1.0f, st));
+                               hid, d, G16_GELU | G16_OUT16 | wf1, 1.0f, st));
     }
     GENIE_STUDY_CLASS(5);
     {
-        const int rs = fc2_splitk2<2>(c, hs, (long)ph, lw.fc2_w16, (long)pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, w, M, st);
+        const int rs = fc2_splitk2<2>(c, hs, (long)ph, lw.fc2_w16, (long)pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, w, M, st, wf2 != 0);
         if (rs != GENIE_E_UNSUPPORTED) return rs;
     }
     GENIE_TRY(launch_gemm16<2>(hs, hid, ph, lw.fc2_w16, hid, pw_fc, c.mlp_bias ? lw.fc2_b : nullptr, x, xs, pd, d, M, d,
-                               hid, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16), 1.0f, st));
+                               hid, G16_ACCUM | G16_OUTF32 | (w.skip_shadow_mlp ? 0 : G16_OUT16) | wf2, 1.0f, st));
     return GENIE_OK;
 }
 
@@ -1134,7 +1135,7 @@ int readout_f16x3(const genie_cfg& c, const genie_weights& wt, const float* x, W
     float* dst = (layout == GENIE_LAYOUT_TOKEN_MAJOR) ? logits : w.logits;
     GENIE_STUDY_CLASS(6);
     GENIE_TRY(launch_gemm16<2>(xs + (size_t)t0 * c.S * d, d, pd, wt.out_w16, d, (size_t)V * d, wt.out_b, dst, nullptr, 0,
-                               V, (int)rows, V, d, G16_OUTF32, c.readout_mult, st, B, (long)c.T * c.S * d, rows * V));
+                               V, (int)rows, V, d, G16_OUTF32 | (wt.out_w16_wide ? G16_WIDEW : 0), c.readout_mult, st, B, (long)c.T * c.S * d, rows * V));
     if (layout != GENIE_LAYOUT_TOKEN_MAJOR) GENIE_TRY(launch_transpose(w.logits, logits, B, (int)rows, V, st));
     return GENIE_OK;
 }

@@ -1,0 +1,323 @@
+// Fused sub-blocks of the STBlock for the shipped geometry (magvit_n32_h8_d256: d = 256, 8 heads of 32, T = 16,
+// hidden = 1024) in GENIE_PREC_BF16.  At d = 256 every Linear of the block is HBM-bound when run as its own launch
+// (43 FLOP per byte for the out-projection), so these kernels keep a token's activations in REGISTERS from the
+// first Linear of a sub-block to its residual update and stream only the weights:
+//
+//   temporal_fused_bf16_kernel   x += proj_t( causal-attention_T( qkv_t( bf16(x) ) ) )   (st_transformer.py:77-78,
+//                                attention.py:36-61): replaces qkv GEMM + temporal attention + proj GEMM
+//                                (403 + 403 MB of qkv written and re-read, 134 + 134 MB of attention output per layer at 64 clips).
+//
+// Common structure ("lane = token"):
+//   * every matrix instruction is v_mfma_f32_16x16x32_bf16 (16x16x16 for the 16-key P.V product).  A 16-token group is one
+//     spatial position's 16 frames; a wave owns G = 2 groups.  A group's operand fragment (lane: token l & 15, k-group l >> 4,
+//     8 consecutive k) is loaded ONCE from the bf16 shadow of x and serves as the B operand of the "swapped" products
+//     D[feature][token] = W . X^T (q, k, out-projection) and as the A operand of the plain one D[token][feature] (v).
+//   * results chain without leaving registers because the 16x16 accumulator layout (lane: column l & 15, rows 4 (l >> 4) + r)
+//     of one product IS an operand layout of the next, up to a fixed permutation of the contraction index that the weight
+//     packing absorbs:   K', Q' (lane = frame, 8 features) -> S^T = K' Q'^T (one MFMA per head) -> softmax over a lane's 4 keys
+//     and the 4 lane groups -> P (lane = query, 4 keys) is the B operand and V (lane = feature, 4 frames) the A operand of
+//     O^T = V^T P -> O^T (lane = frame, 8 features of the head) is the B operand of the out-projection's K-step for that head.
+//   * the weights arrive as a STREAM of 1 KB fragments in consumption order (genie_pack_temporal_fused_bf16), 16 per 16 KB
+//     stage, through a 4-slot LDS ring filled by buffer_load ... lds three stages ahead; a fragment read is one lane-linear
+//     ds_read_b128, one workgroup barrier per stage, and each fragment feeds G matrix instructions.
+//   * 4 waves per workgroup (128 tokens per block), 2 workgroups per CU (<= 256 registers per lane): one workgroup's
+//     HBM phases (operand load, residual read-modify-write) run under the other's matrix work.
+// Numerics = the bf16 contract of kernels_bf16.hip / oracle BF16_MFMA: Linear operands bf16 (q, k, v rounded to bf16 as the
+// stored temporal qkv is), f32 accumulation, f32 softmax; P is split into two bf16 terms (hi + lo, 16 mantissa bits) so the
+// P.V product is f32-class as in the unfused f32 attention kernel.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int FS_STAGE = 16384;  // bytes of one stage = 16 fragments of 1 KB
+constexpr int FS_NS = 4;         // ring slots
+constexpr int FS_RING = FS_NS * FS_STAGE;
+
+__device__ __forceinline__ void fs_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void fs_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ f32x4 mma32(const s16x8& a, const s16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16k(const s16x4& a, const s16x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+// two accumulator tiles (features 0-15 | 16-31 of a head, lane = token) -> one 8-value bf16 operand fragment
+__device__ __forceinline__ s16x8 pack8(const f32x4& lo, const f32x4& hi) {
+    u32x4 p;
+    p.x = f32x2_to_bf16x2(lo.x, lo.y);
+    p.y = f32x2_to_bf16x2(lo.z, lo.w);
+    p.z = f32x2_to_bf16x2(hi.x, hi.y);
+    p.w = f32x2_to_bf16x2(hi.z, hi.w);
+    return __builtin_bit_cast(s16x8, p);
+}
+__device__ __forceinline__ s16x4 pack4(const f32x4& v) {
+    u32x2 p;
+    p.x = f32x2_to_bf16x2(v.x, v.y);
+    p.y = f32x2_to_bf16x2(v.z, v.w);
+    return __builtin_bit_cast(s16x4, p);
+}
+
+}  // namespace
+
+// Weight stream of one layer (bf16, 32 stages x 16 fragments x 64 lanes x 8 values = 256 K values = 512 KB):
+//   stage n < 24: head h = n / 3, part = n % 3 (q, k, v); fragment f = 2 ks + ft (ks = 32-wide K-step, ft = 16-feature tile):
+//       [lane l][e] = Wqkv[part * 256 + h * 32 + ft * 16 + (l & 15)][32 ks + 8 (l >> 4) + e]
+//   stage 24 + h: out-projection K-step of head h; fragment f = 16-column tile ct:
+//       [lane l][e] = Wproj[ct * 16 + (l & 15)][32 h + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)],  g = l >> 4
+//   (the feature order of the second form is the order in which a lane holds its head's 8 attention outputs).
+__global__ void pack_temporal_fused_kernel(const float* __restrict__ qkv_w, const float* __restrict__ proj_w,
+                                           uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per output value
+    if (i >= 32 * 16 * 64 * 8) return;
+    const int e = i & 7, l = (i >> 3) & 63, f = (i >> 9) & 15, n = i >> 13;
+    const int g = l >> 4;
+    float v;
+    if (n < 24) {
+        const int h = n / 3, part = n % 3, ks = f >> 1, ft = f & 1;
+        v = qkv_w[(size_t)(part * 256 + h * 32 + ft * 16 + (l & 15)) * 256 + 32 * ks + 8 * g + e];
+    } else {
+        const int h = n - 24;
+        const int feat = 32 * h + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+        v = proj_w[(size_t)(f * 16 + (l & 15)) * 256 + feat];
+    }
+    out[i] = f32_to_bf16(v);
+}
+
+// x16: (B, 16, S, 256) bf16 shadow of x (read);  x: (B, 16, S, 256) f32, updated in place.
+// A block = 8 consecutive spatial positions of one clip x 16 frames; wave w owns positions 2 w, 2 w + 1.
+template <bool QKV_BIAS>
+__global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint16_t* __restrict__ x16, float* __restrict__ x,
+                                                                     const uint16_t* __restrict__ wstream,
+                                                                     const float* __restrict__ qkv_b,
+                                                                     const float* __restrict__ proj_b, int n_blocks, int S,
+                                                                     float scale_log2e) {
+    constexpr int D = 256, T = 16, NH = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+
+    // biases live in LDS behind the ring (proj 256 floats, then qkv 768): plain global loads next to LDS-DMA in flight make
+    // the compiler drain the whole ring at their first use, ds_reads do not
+    float* sbias = reinterpret_cast<float*>(smem + FS_RING);
+    for (int i = tid; i < 256 + (QKV_BIAS ? 768 : 0); i += 256) sbias[i] = i < 256 ? (proj_b ? proj_b[i] : 0.f) : qkv_b[i - 256];
+    __syncthreads();
+
+    auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, 32 * FS_STAGE, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16;
+    int n_issue = 0;  // stages issued so far (monotonic; stream position = n & 31, slot = n & 3)
+    auto issue_stage = [&]() {
+        const int soff = (n_issue & 31) * FS_STAGE + wid * 4096;
+        unsigned char* dst = smem + (n_issue & (FS_NS - 1)) * FS_STAGE + wid * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voff,
+                                                     soff + j * 1024, 0, 0);
+        ++n_issue;
+    };
+    int n_use = 0;  // stages consumed so far
+    // stage n_use has landed for every wave, and the slot of stage n_use - 1 is free: refill it three stages ahead
+    auto acquire = [&]() -> const unsigned char* {
+        fs_wait_vm<8>();
+        fs_barrier();
+        issue_stage();
+        const unsigned char* p = smem + (n_use & (FS_NS - 1)) * FS_STAGE + lane * 16;
+        ++n_use;
+        return p;
+    };
+    auto frag = [&](const unsigned char* stage, int f) { return *reinterpret_cast<const s16x8*>(stage + f * 1024); };
+
+    issue_stage();
+    issue_stage();
+    issue_stage();
+
+    const int bps = S / 8;  // blocks per clip
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int b = blk / bps, s0 = (blk - b * bps) * 8 + 2 * wid;
+        // this lane's token of group grp: frame r, position s0 + grp
+        const size_t row0 = ((size_t)b * T + r) * S + s0;
+        s16x8 xf[2][8];
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                xf[grp][ks] = *reinterpret_cast<const s16x8*>(x16 + (row0 + grp) * D + 32 * ks + 8 * g);
+        fs_wait_vm<0>();
+
+        s16x8 oall[2][NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            s16x8 qb[2], kb[2];
+            s16x4 vb[2][2];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const unsigned char* stg = acquire();
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (QKV_BIAS) {
+                        const float* bp = sbias + 256 + part * D + h * 32 + ft * 16;
+                        if (part < 2) b0 = *reinterpret_cast<const f32x4*>(bp + 4 * g);  // lane holds features 4 g .. 4 g + 3 of the tile
+                        else b0 = f32x4{bp[r], bp[r], bp[r], bp[r]};                     // lane holds feature r
+                    }
+                    acc[0][ft] = b0;
+                    acc[1][ft] = b0;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) {
+                        const s16x8 wf = frag(stg, 2 * ks + ft);
+#pragma unroll
+                        for (int grp = 0; grp < 2; ++grp)
+                            acc[grp][ft] = part < 2 ? mma32(wf, xf[grp][ks], acc[grp][ft]) : mma32(xf[grp][ks], wf, acc[grp][ft]);
+                    }
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) {
+                    if (part == 0) qb[grp] = pack8(acc[grp][0], acc[grp][1]);
+                    else if (part == 1) kb[grp] = pack8(acc[grp][0], acc[grp][1]);
+                    else { vb[grp][0] = pack4(acc[grp][0]); vb[grp][1] = pack4(acc[grp][1]); }
+                }
+            }
+            // causal attention over the 16 frames of each group (attention.py:48-58): lane = query frame r, keys 4 g + e
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                f32x4 st = mma32(kb[grp], qb[grp], f32x4{0.f, 0.f, 0.f, 0.f});
+                float mx = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * g + e > r) st[e] = -INFINITY;
+                    mx = fmaxf(mx, st[e]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mxs = mx * scale_log2e;
+                float sum = 0.f;
+                f32x4 p, plo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, -mxs));
+                    sum += p[e];
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                const s16x4 phi = pack4(p);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) plo[e] = p[e] - bf16_to_f32((uint16_t)phi[e]);
+                const s16x4 plo16 = pack4(plo);
+                f32x4 o[2];
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    o[ft] = mma16k(vb[grp][ft], phi, f32x4{0.f, 0.f, 0.f, 0.f});
+                    o[ft] = mma16k(vb[grp][ft], plo16, o[ft]);
+                    o[ft] *= inv;
+                }
+                oall[grp][h] = pack8(o[0], o[1]);
+            }
+        }
+
+        // out-projection, swapped: D[out column][token]; lane = frame r holds columns 16 ct + 4 g .. + 3
+        f32x4 out[2][16];
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) {
+            out[0][ct] = *reinterpret_cast<const f32x4*>(sbias + ct * 16 + 4 * g);
+            out[1][ct] = out[0][ct];
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const unsigned char* stg = acquire();
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) {
+                const s16x8 wf = frag(stg, ct);
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) out[grp][ct] = mma32(wf, oall[grp][h], out[grp][ct]);
+            }
+        }
+        // residual update in place: x[token][16 ct + 4 g ..] += out (bias is already in the accumulators).  Four rounds of 8
+        // 16-byte pieces; round k + 1's reads are requested before round k's stores (vmcnt retires in order: a wait for reads
+        // issued behind a store would also wait for the store).
+        float* xr0 = x + row0 * D + 4 * g;
+        f32x4 res[2][8];
+        auto load_round = [&](int k, f32x4* dst) {
+            float* xr = xr0 + (k >> 1) * D + (k & 1) * 128;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dst[c] = *reinterpret_cast<const f32x4*>(xr + c * 16);
+        };
+        load_round(0, res[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k + 1 < 4) load_round(k + 1, res[(k + 1) & 1]);
+            float* xr = xr0 + (k >> 1) * D + (k & 1) * 128;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) res[k & 1][c] += out[k >> 1][(k & 1) * 8 + c];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(xr + c * 16) = res[k & 1][c];
+        }
+    }
+    fs_wait_vm<0>();  // the ring's run-ahead stages must not outlive the workgroup's LDS allocation
+}
+
+int launch_pack_temporal_fused(const float* qkv_w, const float* proj_w, uint16_t* out, hipStream_t st) {
+    pack_temporal_fused_kernel<<<(32 * 16 * 64 * 8) / 256, 256, 0, st>>>(qkv_w, proj_w, out);
+    GENIE_LAUNCH_CHECK("pack_temporal_fused");
+    return GENIE_OK;
+}
+
+int launch_pack_mlp_fused(const float* fc1_w, const float* fc2_w, uint16_t* out, hipStream_t st) {
+    set_error("pack_mlp_fused: not built yet");
+    return GENIE_E_UNSUPPORTED;
+}
+
+// x += proj_t(attention_T(qkv_t(x16))) on dense (B, 16, S, 256) buffers; GENIE_E_UNSUPPORTED for any other geometry
+int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
+                               hipStream_t st) {
+    if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.T != 16 || c.S % 8 || c.qk_norm ||
+        (long)B * c.S < 8 * 256)
+        return GENIE_E_UNSUPPORTED;
+    const int n_blocks = B * c.S / 8;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = n_blocks < 2 * cus ? n_blocks : 2 * cus;
+    const double M = (double)B * c.T * c.S;
+    ProfScope prof(GENIE_KC_FUSED, M * (2.0 * 256 * 1024 + 4.0 * 16 * 256), M * (512.0 + 2048.0), st,
+                   "temporal_fused_bf16_kernel (qkv + causal attention over T + proj + residual)");
+    const size_t lds = FS_RING + 4096;
+    const float sl2e = c.attn_scale * 1.4426950408889634f;
+    if (c.qkv_bias && aw.qkv_b) {
+        (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        temporal_fused_bf16_kernel<true><<<grid, 256, lds, st>>>(x16, x, aw.fused_w16, aw.qkv_b, c.proj_bias ? aw.proj_b : nullptr,
+                                                                 n_blocks, c.S, sl2e);
+    } else {
+        (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        temporal_fused_bf16_kernel<false><<<grid, 256, lds, st>>>(x16, x, aw.fused_w16, nullptr, c.proj_bias ? aw.proj_b : nullptr,
+                                                                  n_blocks, c.S, sl2e);
+    }
+    GENIE_LAUNCH_CHECK("temporal_fused_bf16");
+    return GENIE_OK;
+}
+
+}  // namespace genie

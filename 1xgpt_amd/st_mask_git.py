@@ -30,14 +30,79 @@ _PRECISIONS = {"exact": _lib.PREC_EXACT, "f32": _lib.PREC_EXACT, "bf16": _lib.PR
 
 
 def cosine_schedule(u):
-    """u in [0, 1]  (reference :17-26)."""
+    """Fraction of tokens still masked after a share ``u`` of the MaskGIT steps: cos(pi u / 2), for a Python float
+    (the decoder's own use) or a tensor; anything else is refused like the reference does (st_mask_git.py:17-26)."""
+    if isinstance(u, float):
+        return math.cos(0.5 * math.pi * u)
     if isinstance(u, torch.Tensor):
-        cls = torch
-    elif isinstance(u, float):
-        cls = math
-    else:
-        raise NotImplementedError(f"Unexpected {type(u)=} {u=}")
-    return cls.cos(u * cls.pi / 2)
+        return torch.cos(u * (0.5 * torch.pi))
+    raise NotImplementedError(f"Unexpected {type(u)=} {u=}")
+
+
+class _Packer:
+    """16-bit copies of the Linear weights in the layout the kernels of one precision read, made once per weight table.
+
+    ``packer(weight)`` returns the device pointer of the packed copy (bf16, or the [hi | lo] f16 planes of f16x3);
+    ``is_wide(ptr)`` tells whether that f16x3 tensor breaks the |w| < 32 range contract of the fast split GEMM (the caller
+    writes the answer into the ``w16_wide`` field next to the pointer: the flag travels with the table, the library keeps no
+    registry); ``temporal_fused`` / ``mlp_fused`` build the fragment streams of the fused sub-block kernels
+    (csrc/kernels_fused.hip) for the geometry they cover and return 0 otherwise."""
+
+    def __init__(self, lib, prec, dev, config):
+        self.lib, self.prec, self.dev, self.config = lib, prec, dev, config
+        self.keep, self.wide = [], set()
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def __call__(self, wt):
+        if self.prec == _lib.PREC_BF16:
+            t = torch.empty(wt.shape, dtype=torch.bfloat16, device=self.dev)
+            _lib.check(self.lib.genie_pack_bf16(wt.data_ptr(), t.data_ptr(), wt.numel(), self._stream()), "genie_pack_bf16")
+        else:  # f16x3: [hi plane | lo plane], wt ~ hi + lo / 2048
+            t = torch.empty((2,) + tuple(wt.shape), dtype=torch.float16, device=self.dev)
+            _lib.check(self.lib.genie_pack_split_f16(wt.data_ptr(), t.data_ptr(), wt.numel(), self._stream()),
+                       "genie_pack_split_f16")
+            # Range contract, checked on the packed hi plane at load time.  Beyond the f16 range the precision cannot represent
+            # the tensor at all; from 32 up the 256x256 GEMM's 2^11 scaling of the hi plane would overflow, so the tensor is
+            # flagged and its Linear runs on the two-accumulator kernels (same f32-class result, slower for that tensor only).
+            if not bool(torch.isfinite(t[0]).all()):
+                raise ValueError("f16x3 precision needs finite |weight| < 65504 (the f16 range of the split's hi plane); this "
+                                 "checkpoint has a larger or non-finite weight -- use precision='exact' or 'bf16'")
+            if float(t[0].abs().max()) >= 31.98:
+                import warnings
+                self.wide.add(t.data_ptr())
+                warnings.warn(f"f16x3: a weight tensor of shape {tuple(wt.shape)} has |w| >= 32 (max {float(wt.abs().max()):.3g}): "
+                              "its Linear runs on the two-accumulator split GEMM instead of the 256x256 kernel (same results, "
+                              "lower throughput for that layer)")
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def is_wide(self, ptr):
+        return ptr in self.wide
+
+    def _fused_geometry(self):
+        c = self.config
+        return (self.prec == _lib.PREC_BF16 and c.d_model == 256 and c.num_heads == 8 and not c.qk_norm
+                and os.environ.get("GENIE_NO_FUSED", "0") != "1")
+
+    def temporal_fused(self, attn):
+        if not (self._fused_geometry() and self.config.T == 16):
+            return 0
+        t = torch.empty(_lib.TEMPORAL_FUSED_ELEMS, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_pack_temporal_fused_bf16(attn.qkv.weight.data_ptr(), attn.proj.weight.data_ptr(), t.data_ptr(),
+                                                           self._stream()), "genie_pack_temporal_fused_bf16")
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def mlp_fused(self, mlp):
+        if not (self._fused_geometry() and mlp.fc1.weight.shape[0] == 1024) or True:  # (kernel not built yet)
+            return 0
+        t = torch.empty(_lib.MLP_FUSED_ELEMS, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_pack_mlp_fused_bf16(mlp.fc1.weight.data_ptr(), mlp.fc2.weight.data_ptr(), t.data_ptr(),
+                                                      self._stream()), "genie_pack_mlp_fused_bf16")
+        self.keep.append(t)
+        return t.data_ptr()
 
 
 class GenieOutput(dict):
@@ -104,20 +169,8 @@ class STMaskGIT(nn.Module):
         self._invalidate()
 
     def _invalidate(self):
-        """Forget the cached pointer table (and the library's range hints for its packed tensors)."""
-        self._drop_wide_hints()
+        """Forget the cached pointer table (packed copies and fused streams go with it)."""
         self._table = None
-
-    def _drop_wide_hints(self):
-        for ptr in getattr(self, "_wide", None) or []:
-            try:
-                _lib.load().genie_weight_range_hint(ptr, 0)
-            except Exception:
-                pass
-        self._wide = []
-
-    def __del__(self):
-        self._drop_wide_hints()
 
     def _weights(self):
         if self._table is not None:
@@ -129,40 +182,7 @@ class STMaskGIT(nn.Module):
                 raise RuntimeError(f"parameter {n} must be contiguous float32 (got {p.dtype})")
         cfg = _lib.make_cfg(self.config, self._prec)
         _lib.check(lib.genie_check_config(cfg), "genie_check_config")
-        keep = []
-        wide = []   # packed pointers registered with genie_weight_range_hint (unregistered when the table is rebuilt / dropped)
-        packed = None
-        st = torch.cuda.current_stream().cuda_stream
-        if self._prec == _lib.PREC_BF16:
-
-            def packed(wt):
-                t = torch.empty(wt.shape, dtype=torch.bfloat16, device=dev)
-                _lib.check(lib.genie_pack_bf16(wt.data_ptr(), t.data_ptr(), wt.numel(), st), "genie_pack_bf16")
-                keep.append(t)
-                return t.data_ptr()
-        elif self._prec == _lib.PREC_F16X3:
-
-            def packed(wt):  # [hi plane | lo plane], wt ~ hi + lo/2048
-                t = torch.empty((2,) + tuple(wt.shape), dtype=torch.float16, device=dev)
-                _lib.check(lib.genie_pack_split_f16(wt.data_ptr(), t.data_ptr(), wt.numel(), st),
-                           "genie_pack_split_f16")
-                # the 256x256 GEMM multiplies the weight's hi plane by 2^11 in registers (gemm16_pp): exact below 32 only.
-                # Checked on the packed plane at load time.  A tensor that reaches 32 (but is finite in f16) is registered with the
-                # library, which then runs every Linear reading it on the two-accumulator kernels (no operand scaling; same
-                # f32-class result, slower for that tensor only).  Beyond the f16 range the precision cannot represent it.
-                if not bool(torch.isfinite(t[0]).all()):
-                    raise ValueError("f16x3 precision needs finite |weight| < 65504 (the f16 range of the split's hi plane); this "
-                                     "checkpoint has a larger or non-finite weight -- use precision='exact' or 'bf16'")
-                if float(t[0].abs().max()) >= 31.98:
-                    import warnings
-                    _lib.check(lib.genie_weight_range_hint(t.data_ptr(), 1), "genie_weight_range_hint")
-                    wide.append(t.data_ptr())
-                    warnings.warn(f"f16x3: a weight tensor of shape {tuple(wt.shape)} has |w| >= 32 (max {float(wt.abs().max()):.3g}): "
-                                  "its Linear runs on the two-accumulator split GEMM instead of the 256x256 kernel (same results, "
-                                  "lower throughput for that layer)")
-                keep.append(t)
-                return t.data_ptr()
-
+        packed = _Packer(lib, self._prec, dev, self.config) if self._prec != _lib.PREC_EXACT else None
         L = self.config.num_layers
         layers = (_lib.LayerWeights * L)(*[blk.layer_struct(packed) for blk in self.decoder.layers])
         w = _lib.Weights()
@@ -173,9 +193,10 @@ class STMaskGIT(nn.Module):
         w.out_w, w.out_b = self.out_x_proj.weight.data_ptr(), self.out_x_proj.bias.data_ptr()
         if packed is not None:
             w.out_w16 = packed(self.out_x_proj.weight)
+            w.out_w16_wide = int(packed.is_wide(w.out_w16))
         w.layers_host = layers
-        self._table = (cfg, w, layers, keep)
-        self._wide = wide
+        self._table = (cfg, w, layers, packed)
+        self._wide = sorted(packed.wide) if packed is not None else []
         return self._table
 
     def _workspace(self, B):

@@ -28,7 +28,7 @@ class Mlp(nn.Module):
         return hip_linear(h, self.fc2.weight, self.fc2.bias).view(shp)
 
 
-def _attn_struct(a: SelfAttention, packed=None) -> _lib.AttnWeights:
+def _attn_struct(a: SelfAttention, packed=None, temporal=False) -> _lib.AttnWeights:
     s = _lib.AttnWeights()
     s.qkv_w, s.qkv_b = a.qkv.weight.data_ptr(), _ptr(a.qkv.bias)
     s.proj_w, s.proj_b = a.proj.weight.data_ptr(), _ptr(a.proj.bias)
@@ -36,6 +36,9 @@ def _attn_struct(a: SelfAttention, packed=None) -> _lib.AttnWeights:
         s.norm_w, s.norm_b = a.norm.weight.data_ptr(), a.norm.bias.data_ptr()
     if packed is not None:
         s.qkv_w16, s.proj_w16 = packed(a.qkv.weight), packed(a.proj.weight)
+        s.w16_wide = (_lib.WIDE_QKV if packed.is_wide(s.qkv_w16) else 0) | (_lib.WIDE_PROJ if packed.is_wide(s.proj_w16) else 0)
+        if temporal:
+            s.fused_w16 = packed.temporal_fused(a)
     return s
 
 
@@ -60,11 +63,13 @@ class STBlock(nn.Module):
             lw.norm1_w, lw.norm1_b = self.norm1.weight.data_ptr(), self.norm1.bias.data_ptr()
             lw.norm2_w, lw.norm2_b = self.norm2.weight.data_ptr(), self.norm2.bias.data_ptr()
         lw.spatial = _attn_struct(self.spatial_attn, packed)
-        lw.temporal = _attn_struct(self.temporal_attn, packed)
+        lw.temporal = _attn_struct(self.temporal_attn, packed, temporal=True)
         lw.fc1_w, lw.fc1_b = self.mlp.fc1.weight.data_ptr(), _ptr(self.mlp.fc1.bias)
         lw.fc2_w, lw.fc2_b = self.mlp.fc2.weight.data_ptr(), _ptr(self.mlp.fc2.bias)
         if packed is not None:
             lw.fc1_w16, lw.fc2_w16 = packed(self.mlp.fc1.weight), packed(self.mlp.fc2.weight)
+            lw.w16_wide = (_lib.WIDE_FC1 if packed.is_wide(lw.fc1_w16) else 0) | (_lib.WIDE_FC2 if packed.is_wide(lw.fc2_w16) else 0)
+            lw.mlp_fused_w16 = packed.mlp_fused(self.mlp)
         return lw
 
     def _cfg(self, T, S, precision=_lib.PREC_EXACT) -> _lib.GenieCfg:

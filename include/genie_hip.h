@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 1
+#define GENIE_ABI_VERSION 2
 
 enum {
     GENIE_OK = 0,
@@ -72,6 +72,12 @@ typedef struct genie_attn_weights {
     const float* norm_b;
     const uint16_t* qkv_w16;
     const uint16_t* proj_w16;
+    /* GENIE_PREC_BF16, temporal attention of the shipped geometry (d 256, 8 heads of 32, T 16): the qkv and proj weights as the
+     * fragment stream of the fused qkv + attention + proj kernel (genie_pack_temporal_fused_bf16), or NULL (unfused launches). */
+    const uint16_t* fused_w16;
+    /* GENIE_PREC_F16X3 range flags of the packed tensors (bit 0: qkv_w16, bit 1: proj_w16): set when the tensor's hi plane
+     * reaches |w| >= 32, see "range contract" below.  0 in the other precisions. */
+    int32_t w16_wide;
 } genie_attn_weights;
 
 /* STBlock parameters (genie/st_transformer.py:28-68). */
@@ -88,6 +94,10 @@ typedef struct genie_layer_weights {
     const float* fc2_b;
     const uint16_t* fc1_w16;
     const uint16_t* fc2_w16;
+    /* GENIE_PREC_BF16, d 256 / hidden 1024: fc1 and fc2 as the fragment stream of the fused LayerNorm + MLP kernel
+     * (genie_pack_mlp_fused_bf16), or NULL (unfused launches). */
+    const uint16_t* mlp_fused_w16;
+    int32_t w16_wide; /* f16x3 range flags: bit 0 fc1_w16, bit 1 fc2_w16 */
 } genie_layer_weights;
 
 /* STMaskGIT parameters (genie/st_mask_git.py:36-61); `layers` is a HOST array of num_layers entries. */
@@ -99,9 +109,15 @@ typedef struct genie_weights {
     const float* out_b;
     const uint16_t* out_w16;
     const genie_layer_weights* layers_host;
+    int32_t out_w16_wide; /* f16x3 range flag of out_w16 */
 } genie_weights;
 
 int genie_version(void);
+/* The compiler's view of the POD structs above, for bindings to check their own declarations against (tests/test_abi_and_host.py):
+ * out[0..8) = sizeof(genie_cfg), sizeof(genie_attn_weights), offsetof(.., fused_w16), offsetof(.., w16_wide),
+ * sizeof(genie_layer_weights), offsetof(.., mlp_fused_w16), offsetof(.., w16_wide), sizeof(genie_weights),
+ * offsetof(.., out_w16_wide).  Writes min(n, 9) entries, returns 9. */
+int genie_abi_layout(size_t* out_host, int n);
 const char* genie_last_error(void);
 /* 0 if the kernels support this configuration, GENIE_E_SHAPE otherwise (message in genie_last_error). */
 int genie_check_config(const genie_cfg* cfg);
@@ -115,11 +131,19 @@ int genie_pack_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 int genie_pack_split_f16(const float* src, uint16_t* dst, size_t n, void* stream);
 /* GENIE_PREC_F16X3 range contract per weight tensor.  The chip-filling split GEMM scales the weight's hi plane by 2^11 in f16
  * registers, which is exact for |w| < 32 only.  A caller that packs a tensor whose hi plane reaches 32 (finite in f16, i.e.
- * |w| < 65504) registers its packed pointer here (wide = 1) BEFORE the first forward; every Linear reading that pointer then
- * runs on the two-accumulator kernels, which scale nothing (same f32-class result, lower rate for that tensor only).
- * wide = 0 removes the entry (call it before freeing or re-packing the buffer).  Process-global, thread-safe.
+ * |w| < 65504) sets the tensor's bit in the `w16_wide` field of the struct that carries its pointer; every Linear reading that
+ * tensor then runs on the two-accumulator kernels, which scale nothing (same f32-class result, lower rate for that tensor
+ * only).  The flag travels with the weight table: there is no process-global state.
  * Reference counterpart: none (the reference's Linear layers are f32: st_transformer.py:16-25, attention.py:27-29). */
-int genie_weight_range_hint(const void* w16, int wide);
+enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_FC2 = 2 };
+
+/* Fragment streams of the fused sub-block kernels (GENIE_PREC_BF16, magvit_n32_h8_d256 geometry; csrc/kernels_fused.hip).
+ * temporal: qkv_w (768, 256) and proj_w (256, 256) f32 -> 262,144 bf16 values;  mlp: fc1_w (1024, 256) and fc2_w (256, 1024)
+ * f32 -> 524,288 bf16 values.  Reference counterpart: the nn.Linear weights of attention.py:27-29 / st_transformer.py:16-25. */
+#define GENIE_TEMPORAL_FUSED_ELEMS 262144
+#define GENIE_MLP_FUSED_ELEMS 524288
+int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream);
+int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream);
 
 /* ---- unit entry points (one reference op each; used by the parity tests) -------------------------- */
 
@@ -267,7 +291,7 @@ int genie_maskgit_generate(const genie_cfg* cfg, const genie_weights* w, int64_t
  * Process-global, not thread-safe; at most GENIE_PROFILE_MAX_LAUNCHES launches are timed between resets
  * (later ones run untimed and are not counted). */
 enum { GENIE_KC_GEMM = 0, GENIE_KC_ATTN_SPATIAL = 1, GENIE_KC_ATTN_TEMPORAL = 2, GENIE_KC_LAYERNORM = 3,
-       GENIE_KC_OTHER = 4, GENIE_KC_COUNT = 5 };
+       GENIE_KC_OTHER = 4, GENIE_KC_FUSED = 5 /* fused sub-block kernels (kernels_fused.hip) */, GENIE_KC_COUNT = 6 };
 #define GENIE_PROFILE_MAX_LAUNCHES 32768
 int genie_profile_enable(int class_mask); /* 0 disables */
 int genie_profile_reset(void);
