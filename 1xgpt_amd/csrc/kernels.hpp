@@ -52,6 +52,7 @@ int launch_pack_temporal_fused(const float* qkv_w, const float* proj_w, uint16_t
 int launch_pack_mlp_fused(const float* fc1_w, const float* fc2_w, uint16_t* out, hipStream_t st);
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
                                hipStream_t st);
+int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st);
 
 // Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
 // tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.

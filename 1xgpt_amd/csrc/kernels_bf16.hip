@@ -938,6 +938,10 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
                                x16, 0, d, M, d, d, G16_ACCUM | G16_OUTF32 | (c.qk_norm ? G16_OUT16 : 0), 1.0f, st));
     }
     // MLP
+    if (w.frame_t < 0) {   // LayerNorm + fc1 + GELU + fc2 + residual in one kernel for the shipped geometry (kernels_fused.hip)
+        rc = launch_mlp_fused_bf16(c, lw, x, w.skip_shadow_mlp ? nullptr : x16, (long)M, st);
+        if (rc != GENIE_E_UNSUPPORTED) return rc;
+    }
     u = x16;
     bool fc1_done = false;
     if (!c.qk_norm) {

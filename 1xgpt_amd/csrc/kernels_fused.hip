@@ -286,9 +286,232 @@ int launch_pack_temporal_fused(const float* qkv_w, const float* proj_w, uint16_t
     return GENIE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// mlp_fused_bf16_kernel:  x += fc2( gelu( fc1( LayerNorm(x) ) ) )   (st_transformer.py:16-25, 81) for d = 256, hidden = 1024.
+// Replaces LayerNorm + fc1 GEMM + fc2 GEMM: the normalised operand and the 1024-wide hidden never leave the registers
+// (134 MB of LayerNorm output and 2 x 537 MB of hidden per layer at 64 clips).
+//   * v_mfma_f32_32x32x16_bf16, lane = token (l & 31), k-group l >> 5.  A wave owns 32 consecutive rows of x: it reads them as
+//     f32 fragments (8 consecutive channels per K-step), normalises in registers (row statistics = in-lane sums + one
+//     cross-half exchange) and keeps the 16 bf16 K-step fragments for the whole block.
+//   * the hidden is produced in chunks of 32 units by the swapped product  D[unit][token] = W1 . X^T  (bias in the accumulator's
+//     initial value); after GELU the accumulator's registers 0-7 / 8-15 ARE the two K-step fragments (lane = token, 8 units) of
+//     the swapped second product  D[column][token] += W2 . H^T, whose 8 accumulator tiles hold the token's 256 outputs.
+//   * weight stream (genie_pack_mlp_fused_bf16): 64 stages of 16 fragments, [A_0 | B_0 | A_1 | B_1 | ...] (A_c = fc1 rows of
+//     chunk c over the 16 K-steps, B_c = fc2 columns over chunk c's two K-steps).  The main loop runs in 33 REGIONS: region j
+//     holds the first product of chunk j next to the second product of chunk j - 1 -- independent matrix work to interleave
+//     (the fc1 chain runs on ONE accumulator) and to cover the GELU of the chunk before.  The ring is two 32 KB region slots
+//     [A half | B half]: region j + 1 is requested right after region j's barrier (the slot of region j - 1 is free then) and
+//     waited for with vmcnt(0) one region later -- one barrier and one uniform protocol step per region.
+//   * 4 waves / 128 rows per block, 2 workgroups per CU.
+// Numerics = the bf16 contract (oracle BF16_MFMA): LayerNorm f32 -> bf16 operand, f32 accumulate + bias, erf-GELU in f32
+// (gelu_erf_fast, |error| 1.5e-7) -> bf16 operand, f32 accumulate + bias + f32 residual.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void pack_mlp_fused_kernel(const float* __restrict__ fc1_w, const float* __restrict__ fc2_w, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per output value
+    if (i >= 64 * 16 * 64 * 8) return;
+    const int e = i & 7, l = (i >> 3) & 63, f = (i >> 9) & 15, n = i >> 13;
+    const int h = l >> 5, rr = l & 31;
+    const int c = n >> 1;   // stage 2c = A_c, stage 2c + 1 = B_c
+    float v;
+    if (!(n & 1)) {
+        v = fc1_w[(size_t)(32 * c + rr) * 256 + 16 * f + 8 * h + e];                      // fragment f = K-step
+    } else {
+        const int kk = f >> 3, ct = f & 7;                                                 // fragment f = 8 kk + ct
+        v = fc2_w[(size_t)(32 * ct + rr) * 1024 + 32 * c + 16 * kk + (e & 3) + 8 * (e >> 2) + 4 * h];
+    }
+    out[i] = f32_to_bf16(v);
+}
+
 int launch_pack_mlp_fused(const float* fc1_w, const float* fc2_w, uint16_t* out, hipStream_t st) {
-    set_error("pack_mlp_fused: not built yet");
-    return GENIE_E_UNSUPPORTED;
+    pack_mlp_fused_kernel<<<(64 * 16 * 64 * 8) / 256, 256, 0, st>>>(fc1_w, fc2_w, out);
+    GENIE_LAUNCH_CHECK("pack_mlp_fused");
+    return GENIE_OK;
+}
+
+namespace {
+__device__ __forceinline__ f32x16 mma32x32(const s16x8& a, const s16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+constexpr int ML_OFF_LNG = FS_RING, ML_OFF_LNB = FS_RING + 1024, ML_OFF_B1 = FS_RING + 2048, ML_OFF_B2 = FS_RING + 6144;
+constexpr int ML_LDS = FS_RING + 7168;
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restrict__ x, const uint16_t* __restrict__ wstream,
+                                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                                const float* __restrict__ b1, const float* __restrict__ b2,
+                                                                uint16_t* __restrict__ x16_out, int n_blocks, float eps) {
+    constexpr int D = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    {   // parameter tables in LDS (ds_reads do not disturb the LDS-DMA stream's vmcnt bookkeeping)
+        float* t = reinterpret_cast<float*>(smem + FS_RING);
+        for (int i = tid; i < 1792; i += 256)
+            t[i] = i < 256 ? ln_g[i] : i < 512 ? ln_b[i - 256] : i < 1536 ? (b1 ? b1[i - 512] : 0.f) : (b2 ? b2[i - 1536] : 0.f);
+        __syncthreads();
+    }
+    const float* s_g = reinterpret_cast<const float*>(smem + ML_OFF_LNG);
+    const float* s_b = reinterpret_cast<const float*>(smem + ML_OFF_LNB);
+    const float* s_b1 = reinterpret_cast<const float*>(smem + ML_OFF_B1);
+    const float* s_b2 = reinterpret_cast<const float*>(smem + ML_OFF_B2);
+
+    auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, 64 * FS_STAGE, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16;
+    // request the halves of region j (A_j if j < 32, B_{j-1} if j >= 1) into region slot j & 1; wave w moves pieces 4w .. 4w + 3
+    auto issue_region = [&](int j) {
+        unsigned char* dst = smem + (j & 1) * 2 * FS_STAGE + wid * 4096;
+        if (j < 32) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, voff,
+                                                         (2 * j) * FS_STAGE + wid * 4096 + q * 1024, 0, 0);
+        }
+        if (j >= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + FS_STAGE + q * 1024), 16,
+                                                         voff, (2 * j - 1) * FS_STAGE + wid * 4096 + q * 1024, 0, 0);
+        }
+    };
+    auto frag = [&](const unsigned char* stage, int f) { return *reinterpret_cast<const s16x8*>(stage + f * 1024); };
+    const unsigned char* lbase = smem + lane * 16;
+
+    issue_region(0);
+
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        float* xrow = x + ((size_t)blk * 128 + wid * 32 + r) * D;   // this lane's token
+        // ---- LayerNorm of the wave's 32 rows, straight into the K-step fragments
+        s16x8 xf[16];
+        {
+            f32x4 v[32];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                v[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 8 * h);
+                v[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 8 * h + 4);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / D);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                v[i] -= mean;
+                sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(s_g + 16 * ks + 8 * h), g1 = *reinterpret_cast<const f32x4*>(s_g + 16 * ks + 8 * h + 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(s_b + 16 * ks + 8 * h), c1 = *reinterpret_cast<const f32x4*>(s_b + 16 * ks + 8 * h + 4);
+                xf[ks] = pack8(v[2 * ks] * rstd * g0 + c0, v[2 * ks + 1] * rstd * g1 + c1);
+            }
+        }
+        fs_wait_vm<0>();
+
+        f32x16 out[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(s_b2 + 32 * ct + 8 * j + 4 * h);
+                out[ct][4 * j] = bv.x; out[ct][4 * j + 1] = bv.y; out[ct][4 * j + 2] = bv.z; out[ct][4 * j + 3] = bv.w;
+            }
+        auto bias1 = [&](int c) {
+            f32x16 a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(s_b1 + 32 * c + 8 * j + 4 * h);
+                a[4 * j] = bv.x; a[4 * j + 1] = bv.y; a[4 * j + 2] = bv.z; a[4 * j + 3] = bv.w;
+            }
+            return a;
+        };
+        auto gelu_pack = [&](const f32x16& a, s16x8& h0, s16x8& h1) {
+            float gz[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gz[i] = gelu_erf_fast(a[i]);
+            h0 = pack8(f32x4{gz[0], gz[1], gz[2], gz[3]}, f32x4{gz[4], gz[5], gz[6], gz[7]});
+            h1 = pack8(f32x4{gz[8], gz[9], gz[10], gz[11]}, f32x4{gz[12], gz[13], gz[14], gz[15]});
+        };
+
+        // region 0: fc1 of chunk 0
+        fs_barrier();
+        issue_region(1);
+        f32x16 acc1 = bias1(0);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc1 = mma32x32(frag(lbase, ks), xf[ks], acc1);
+        s16x8 hk0, hk1;
+        gelu_pack(acc1, hk0, hk1);
+        // regions 1..31: fc1 of chunk j next to fc2 of chunk j - 1
+        for (int j = 1; j < 32; ++j) {
+            fs_wait_vm<0>();
+            fs_barrier();
+            issue_region(j + 1);
+            const unsigned char* sa = lbase + (j & 1) * 2 * FS_STAGE;
+            acc1 = bias1(j);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc1 = mma32x32(frag(sa, i), xf[i], acc1);
+                out[i & 7] = mma32x32(frag(sa + FS_STAGE, i), (i >> 3) ? hk1 : hk0, out[i & 7]);
+            }
+            gelu_pack(acc1, hk0, hk1);
+        }
+        // region 32: fc2 of chunk 31; the next block's region 0 is requested here (this block's slot 1 is free after the barrier)
+        fs_wait_vm<0>();
+        fs_barrier();
+        issue_region(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i & 7] = mma32x32(frag(lbase + FS_STAGE, i), (i >> 3) ? hk1 : hk0, out[i & 7]);
+        // ---- residual update in place: lane = token, columns 32 ct + 8 j + 4 h .. + 3; rounds of 8 pieces, next round's reads first
+        f32x4 res[2][8];
+        auto load_round = [&](int k, f32x4* dst) {   // round k = column tiles 2k, 2k + 1
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3) + 4 * h);
+        };
+        load_round(0, res[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k + 1 < 4) load_round(k + 1, res[(k + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x16& o = out[2 * k + (q >> 2)];
+                const int j = q & 3;
+                res[k & 1][q] += f32x4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                *reinterpret_cast<f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3) + 4 * h) = res[k & 1][q];
+                if (x16_out)
+                    *reinterpret_cast<s16x4*>(x16_out + ((size_t)blk * 128 + wid * 32 + r) * D + 32 * (2 * k + (q >> 2)) + 8 * (q & 3) + 4 * h) =
+                        pack4(res[k & 1][q]);
+            }
+        }
+    }
+    fs_wait_vm<0>();
+}
+
+// x += Mlp(LayerNorm(x)) on (rows, 256); x16_out (optional): bf16 shadow of the result.  GENIE_E_UNSUPPORTED outside the geometry.
+int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st) {
+    if (!lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < 128 * 256 || !lw.norm2_w ||
+        !lw.norm2_b)
+        return GENIE_E_UNSUPPORTED;
+    const int n_blocks = (int)(rows / 128);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = n_blocks < 2 * cus ? n_blocks : 2 * cus;
+    ProfScope prof(GENIE_KC_FUSED, (double)rows * 4.0 * 256 * 1024, (double)rows * (2048.0 + (x16_out ? 512.0 : 0.0)), st,
+                   "mlp_fused_bf16_kernel (LayerNorm + fc1 + GELU + fc2 + residual)");
+    (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+    mlp_fused_bf16_kernel<<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, c.mlp_bias ? lw.fc1_b : nullptr,
+                                                     c.mlp_bias ? lw.fc2_b : nullptr, x16_out, n_blocks, 1e-5f);
+    GENIE_LAUNCH_CHECK("mlp_fused_bf16");
+    return GENIE_OK;
 }
 
 // x += proj_t(attention_T(qkv_t(x16))) on dense (B, 16, S, 256) buffers; GENIE_E_UNSUPPORTED for any other geometry

@@ -96,7 +96,7 @@ class _Packer:
         return t.data_ptr()
 
     def mlp_fused(self, mlp):
-        if not (self._fused_geometry() and mlp.fc1.weight.shape[0] == 1024) or True:  # (kernel not built yet)
+        if not (self._fused_geometry() and mlp.fc1.weight.shape[0] == 1024):
             return 0
         t = torch.empty(_lib.MLP_FUSED_ELEMS, dtype=torch.bfloat16, device=self.dev)
         _lib.check(self.lib.genie_pack_mlp_fused_bf16(mlp.fc1.weight.data_ptr(), mlp.fc2.weight.data_ptr(), t.data_ptr(),

@@ -39,7 +39,8 @@ def test_fused_blocks_match_unfused_and_oracle(monkeypatch, qkv_bias):
         for k in sd:
             if k.endswith("qkv.bias"):
                 sd[k] = (0.05 * g.standard_normal(sd[k].shape)).astype(np.float32)
-    B = 9   # 9 x 256 positions = 288 blocks of 8: more blocks than one round of workgroups, ragged last round
+    B = 19  # 19 clips = 608 temporal blocks / 608 MLP blocks for 512 persistent workgroups: every ring carries over from one
+            # block to the next, and the last round is ragged
     ids = synth.make_clips(B, cfg, seed=78)
     x = ids.reshape(B, 16, 16, 16).copy()
     x[:, 8:] = cfg.image_vocab_size
@@ -64,3 +65,9 @@ def test_fused_blocks_match_unfused_and_oracle(monkeypatch, qkv_bias):
     # batch independence: a clip alone takes the unfused launches (too few blocks), in a batch the fused kernel
     h1 = mf.hidden_states(dev(x[4:5])).cpu().numpy()
     assert np.abs(h1[0] - hf[4]).max() < 5e-2 * scale
+    # the readout takes the bf16 shadow of x that the last layer's fused MLP writes: logits of the last frames, fused vs unfused
+    lf = mf.compute_logits_frames(dev(x), 14, 16, "token").cpu().numpy()
+    lu = mu.compute_logits_frames(dev(x), 14, 16, "token").cpu().numpy()
+    dl = np.abs(lf - lu)
+    print("fused vs unfused logits: max", dl.max(), "median", np.median(dl))
+    assert np.median(dl) < 4e-3 and dl.max() < 8e-2
