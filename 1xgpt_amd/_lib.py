@@ -116,6 +116,8 @@ SIGNATURES = {
     "genie_study_build": (C.c_int, []),
     "genie_pack_temporal_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_pack_mlp_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
+    "genie_temporal_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, c_ptr]),
+    "genie_mlp_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(LayerWeights), c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),
     "genie_bits_from_tokens": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_rescale_u8_bf16": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_rescale_u8_f32": (C.c_int, [c_ptr, c_ptr, C.c_size_t, c_ptr]),

@@ -209,9 +209,11 @@ static int decoder(const genie_cfg& c, const genie_weights& wt, float* x, Worksp
     if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, x, w, B, st));
     for (int i = 0; i < c.num_layers; ++i) {
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
+        w.next_layer = i + 1 < c.num_layers ? &wt.layers_host[i + 1] : nullptr;
         GENIE_STUDY_LAYER(i);
         const int rc = st_block(c, wt.layers_host[i], x, w, B, st);
         w.skip_shadow_mlp = false;
+        w.next_layer = nullptr;
         GENIE_TRY(rc);
     }
     return GENIE_OK;
@@ -404,10 +406,12 @@ static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int
         if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; w.tq_frames = cache_frames; }
         else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; w.tshift = tshift; }
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
+        w.next_layer = i + 1 < c.num_layers ? &wt.layers_host[i + 1] : nullptr;
         w.stop_after_tqkv = clean && i + 1 == c.num_layers;  // nothing reads the clean pass's final hidden state
         GENIE_STUDY_LAYER(i);
         int rc = st_block(c, wt.layers_host[i], w.x, w, B, st);
         w.skip_shadow_mlp = false;
+        w.next_layer = nullptr;
         w.stop_after_tqkv = false;
         w.tqkv = nullptr;
         w.tq_frames = 0;
@@ -680,6 +684,17 @@ int genie_profile_kernels(int kernel_class, char* buf, size_t buf_bytes) {
 int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream) {
     GENIE_CHECK_ARG(qkv_w && proj_w && dst, "pack_temporal_fused: NULL pointer");
     return launch_pack_temporal_fused(qkv_w, proj_w, dst, as_stream(stream));
+}
+int genie_temporal_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* x16, float* x, int B, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(aw && x16 && x && B >= 1, "temporal_fused: bad argument");
+    return launch_temporal_fused_bf16(*cfg, *aw, x16, x, B, as_stream(stream));
+}
+int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, float* x, uint16_t* x16_out, int64_t rows,
+                         const float* next_norm_w, const float* next_norm_b, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(lw && x && rows >= 0, "mlp_fused: bad argument");
+    return launch_mlp_fused_bf16(*cfg, *lw, x, x16_out, (long)rows, as_stream(stream), next_norm_w, next_norm_b);
 }
 int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream) {
     GENIE_CHECK_ARG(fc1_w && fc2_w && dst, "pack_mlp_fused: NULL pointer");

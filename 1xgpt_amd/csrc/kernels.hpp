@@ -37,6 +37,10 @@ struct Workspace {
     bool skip_shadow_mlp = false;
     // clean pass, last layer: only the temporal qkv (the cache entry) is needed -- the block returns right after that GEMM
     bool stop_after_tqkv = false;
+    // GENIE_PREC_BF16, fused MLP kernel: the block that follows (NULL after the last one).  Its norm1 is applied in this block's
+    // MLP epilogue and `ln1_done` tells that block to skip its own LayerNorm launch.
+    const genie_layer_weights* next_layer = nullptr;
+    bool ln1_done = false;
 };
 
 // GENIE_PREC_BF16: the temporal qkv buffer and the temporal KV cache hold bf16 values (half the bytes of the HBM-bound temporal
@@ -52,7 +56,8 @@ int launch_pack_temporal_fused(const float* qkv_w, const float* proj_w, uint16_t
 int launch_pack_mlp_fused(const float* fc1_w, const float* fc2_w, uint16_t* out, hipStream_t st);
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
                                hipStream_t st);
-int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st);
+int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,
+                          const float* nx_g = nullptr, const float* nx_b = nullptr);
 
 // Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
 // tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.

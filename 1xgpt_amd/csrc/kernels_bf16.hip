@@ -858,11 +858,13 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     }
     if (!qkv_done) {
         if (!c.qk_norm) {
-            GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
+            if (!w.ln1_done)   // (else: the previous block's fused MLP kernel wrote norm1(x) into xn16)
+                GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
             u = xn16;
         }
         rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st);
     }
+    w.ln1_done = false;
     if (rc == GENIE_E_UNSUPPORTED) {
     if (!qkv_done)
     GENIE_TRY(launch_gemm16<1>(u, d, 0, lw.spatial.qkv_w16, d, 0, c.qkv_bias ? lw.spatial.qkv_b : nullptr, qkv, nullptr,
@@ -939,7 +941,18 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     }
     // MLP
     if (w.frame_t < 0) {   // LayerNorm + fc1 + GELU + fc2 + residual in one kernel for the shipped geometry (kernels_fused.hip)
-        rc = launch_mlp_fused_bf16(c, lw, x, w.skip_shadow_mlp ? nullptr : x16, (long)M, st);
+        const genie_layer_weights* nx = w.next_layer;
+#ifdef GENIE_VAR_NO_LNOUT
+        constexpr int lnout = 0;
+#else
+        constexpr int lnout = 1;
+#endif
+        if (lnout && nx && nx->norm1_w && nx->norm1_b && w.skip_shadow_mlp) {
+            rc = launch_mlp_fused_bf16(c, lw, x, xn16, (long)M, st, nx->norm1_w, nx->norm1_b);
+            if (rc == GENIE_OK) w.ln1_done = true;
+        } else {
+            rc = launch_mlp_fused_bf16(c, lw, x, w.skip_shadow_mlp ? nullptr : x16, (long)M, st);
+        }
         if (rc != GENIE_E_UNSUPPORTED) return rc;
     }
     u = x16;

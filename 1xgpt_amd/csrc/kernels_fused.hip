@@ -39,6 +39,15 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// Ablation knobs exist in the -DGENIE_STUDY build only (GENIE_FUSED_ABL; results are wrong when set).  In the shipping build
+// FS_ABL(bit) is a constant false: the kernels sit at the 256-register edge and an extra run-time branch is enough to make the
+// register allocator spill.
+#ifdef GENIE_STUDY
+#define FS_ABL(bit) ((abl & (bit)) != 0)
+#else
+#define FS_ABL(bit) false
+#endif
+
 namespace {
 
 constexpr int FS_STAGE = 16384;  // bytes of one stage = 16 fragments of 1 KB
@@ -111,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
                                                                      const uint16_t* __restrict__ wstream,
                                                                      const float* __restrict__ qkv_b,
                                                                      const float* __restrict__ proj_b, int n_blocks, int S,
-                                                                     float scale_log2e) {
+                                                                     float scale_log2e, int abl) {
+    // abl (study build only, GENIE_FUSED_ABL; results are WRONG when set): 1 no in-loop LDS-DMA, 2 no residual read / store
     constexpr int D = 256, T = 16, NH = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
     auto acquire = [&]() -> const unsigned char* {
         fs_wait_vm<8>();
         fs_barrier();
-        issue_stage();
+        if (!FS_ABL(1)) issue_stage();
         const unsigned char* p = smem + (n_use & (FS_NS - 1)) * FS_STAGE + lane * 16;
         ++n_use;
         return p;
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
         // residual update in place: x[token][16 ct + 4 g ..] += out (bias is already in the accumulators).  Four rounds of 8
         // 16-byte pieces; round k + 1's reads are requested before round k's stores (vmcnt retires in order: a wait for reads
         // issued behind a store would also wait for the store).
+        if (FS_ABL(2)) continue;
         float* xr0 = x + row0 * D + 4 * g;
         f32x4 res[2][8];
         auto load_round = [&](int k, f32x4* dst) {
@@ -334,13 +345,21 @@ __device__ __forceinline__ f32x16 mma32x32(const s16x8& a, const s16x8& b, const
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 constexpr int ML_OFF_LNG = FS_RING, ML_OFF_LNB = FS_RING + 1024, ML_OFF_B1 = FS_RING + 2048, ML_OFF_B2 = FS_RING + 6144;
-constexpr int ML_LDS = FS_RING + 7168;
+constexpr int ML_OFF_NXG = FS_RING + 7168, ML_OFF_NXB = FS_RING + 8192;
+constexpr int ML_LDS = FS_RING + 9216;
 }  // namespace
 
+// x16_out (optional) receives a bf16 copy of the updated rows: the plain shadow of x (LNOUT = false; the readout's operand after
+// the last block), or -- LNOUT = true -- LayerNorm(x; nx_g, nx_b), i.e. the NEXT block's norm1 output, the operand of its
+// spatial qkv Linear (st_transformer.py:73): the row is complete in this lane pair's registers, so that LayerNorm launch goes.
+template <bool LNOUT>
 __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restrict__ x, const uint16_t* __restrict__ wstream,
                                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                                 const float* __restrict__ b1, const float* __restrict__ b2,
-                                                                uint16_t* __restrict__ x16_out, int n_blocks, float eps) {
+                                                                uint16_t* __restrict__ x16_out, const float* __restrict__ nx_g,
+                                                                const float* __restrict__ nx_b, int n_blocks, float eps, int abl) {
+    // abl (study build only, GENIE_FUSED_ABL; results are WRONG when set): 1 no in-loop LDS-DMA, 2 no residual read / store,
+    // 4 no GELU, 8 no LayerNorm prologue loads
     constexpr int D = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -351,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         float* t = reinterpret_cast<float*>(smem + FS_RING);
         for (int i = tid; i < 1792; i += 256)
             t[i] = i < 256 ? ln_g[i] : i < 512 ? ln_b[i - 256] : i < 1536 ? (b1 ? b1[i - 512] : 0.f) : (b2 ? b2[i - 1536] : 0.f);
+        if constexpr (LNOUT) { t[1792 + tid] = nx_g[tid]; t[2048 + tid] = nx_b[tid]; }
         __syncthreads();
     }
     const float* s_g = reinterpret_cast<const float*>(smem + ML_OFF_LNG);
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
     const unsigned voff = (unsigned)lane * 16;
     // request the halves of region j (A_j if j < 32, B_{j-1} if j >= 1) into region slot j & 1; wave w moves pieces 4w .. 4w + 3
     auto issue_region = [&](int j) {
+        if (FS_ABL(1) && j > 1) return;
         unsigned char* dst = smem + (j & 1) * 2 * FS_STAGE + wid * 4096;
         if (j < 32) {
 #pragma unroll
@@ -389,8 +410,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
             f32x4 v[32];
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                v[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 8 * h);
-                v[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 8 * h + 4);
+                const float* src = FS_ABL(8) ? x + (size_t)lane * D : xrow;
+                v[2 * ks] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 8 * h);
+                v[2 * ks + 1] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 8 * h + 4);
             }
             float sum = 0.f;
 #pragma unroll
@@ -434,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         auto gelu_pack = [&](const f32x16& a, s16x8& h0, s16x8& h1) {
             float gz[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) gz[i] = gelu_erf_fast(a[i]);
+            for (int i = 0; i < 16; ++i) gz[i] = FS_ABL(4) ? a[i] : gelu_erf_fast(a[i]);
             h0 = pack8(f32x4{gz[0], gz[1], gz[2], gz[3]}, f32x4{gz[4], gz[5], gz[6], gz[7]});
             h1 = pack8(f32x4{gz[8], gz[9], gz[10], gz[11]}, f32x4{gz[12], gz[13], gz[14], gz[15]});
         };
@@ -468,38 +490,78 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[i & 7] = mma32x32(frag(lbase + FS_STAGE, i), (i >> 3) ? hk1 : hk0, out[i & 7]);
         // ---- residual update in place: lane = token, columns 32 ct + 8 j + 4 h .. + 3; rounds of 8 pieces, next round's reads first
+        if (FS_ABL(2)) { asm volatile("" :: "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7])); continue; }
         f32x4 res[2][8];
+        float* xrowh = xrow + 4 * h;
         auto load_round = [&](int k, f32x4* dst) {   // round k = column tiles 2k, 2k + 1
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3) + 4 * h);
+            for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xrowh + 32 * (2 * k + (q >> 2)) + 8 * (q & 3));
         };
+        uint16_t* x16row = x16_out + ((size_t)blk * 128 + wid * 32 + r) * D;
         load_round(0, res[0]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k + 1 < 4) load_round(k + 1, res[(k + 1) & 1]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const f32x16& o = out[2 * k + (q >> 2)];
+                f32x16& o = out[2 * k + (q >> 2)];
                 const int j = q & 3;
                 res[k & 1][q] += f32x4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+                if constexpr (LNOUT) {   // the accumulators keep the updated row for the statistics below
+                    o[4 * j] = res[k & 1][q].x; o[4 * j + 1] = res[k & 1][q].y; o[4 * j + 2] = res[k & 1][q].z; o[4 * j + 3] = res[k & 1][q].w;
+                }
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                *reinterpret_cast<f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3) + 4 * h) = res[k & 1][q];
-                if (x16_out)
-                    *reinterpret_cast<s16x4*>(x16_out + ((size_t)blk * 128 + wid * 32 + r) * D + 32 * (2 * k + (q >> 2)) + 8 * (q & 3) + 4 * h) =
-                        pack4(res[k & 1][q]);
+                *reinterpret_cast<f32x4*>(xrowh + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = res[k & 1][q];
+                if constexpr (!LNOUT) {
+                    if (x16_out) *reinterpret_cast<s16x4*>(x16row + 4 * h + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = pack4(res[k & 1][q]);
+                }
             }
+        }
+        if constexpr (LNOUT) {   // LayerNorm of the updated row (two-pass, as layer_norm_fast_kernel) -> bf16
+            const float* s_ng4 = reinterpret_cast<const float*>(smem + ML_OFF_NXG) + 4 * h;
+            const float* s_nb4 = reinterpret_cast<const float*>(smem + ML_OFF_NXB) + 4 * h;
+            uint16_t* x16h = x16row + 4 * h;
+            float sum = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) sum += (out[ct][i] + out[ct][i + 1]) + (out[ct][i + 2] + out[ct][i + 3]);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / D);
+            float sq = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    out[ct][i] -= mean; out[ct][i + 1] -= mean; out[ct][i + 2] -= mean; out[ct][i + 3] -= mean;
+                    sq += (out[ct][i] * out[ct][i] + out[ct][i + 1] * out[ct][i + 1]) + (out[ct][i + 2] * out[ct][i + 2] + out[ct][i + 3] * out[ct][i + 3]);
+                }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 32 * ct + 8 * j;   // (+ 4 h: in the lane's base pointers, so every access is base + immediate)
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(s_ng4 + col), bv = *reinterpret_cast<const f32x4*>(s_nb4 + col);
+                    const f32x4 y = f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]} * rstd * gv + bv;
+                    *reinterpret_cast<s16x4*>(x16h + col) = pack4(y);
+                }
         }
     }
     fs_wait_vm<0>();
 }
 
-// x += Mlp(LayerNorm(x)) on (rows, 256); x16_out (optional): bf16 shadow of the result.  GENIE_E_UNSUPPORTED outside the geometry.
-int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st) {
+// x += Mlp(LayerNorm(x)) on (rows, 256); x16_out (optional): bf16 shadow of the result, or -- when nx_g / nx_b are given --
+// LayerNorm(result; nx_g, nx_b) as bf16.  GENIE_E_UNSUPPORTED outside the geometry.
+int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,
+                          const float* nx_g, const float* nx_b) {
     if (!lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < 128 * 256 || !lw.norm2_w ||
         !lw.norm2_b)
         return GENIE_E_UNSUPPORTED;
+    GENIE_CHECK_ARG((nx_g == nullptr) == (nx_b == nullptr) && (!nx_g || x16_out), "mlp_fused: next-norm parameters need both pointers and x16_out");
     const int n_blocks = (int)(rows / 128);
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -507,9 +569,18 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
     const int grid = n_blocks < 2 * cus ? n_blocks : 2 * cus;
     ProfScope prof(GENIE_KC_FUSED, (double)rows * 4.0 * 256 * 1024, (double)rows * (2048.0 + (x16_out ? 512.0 : 0.0)), st,
                    "mlp_fused_bf16_kernel (LayerNorm + fc1 + GELU + fc2 + residual)");
-    (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
-    mlp_fused_bf16_kernel<<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, c.mlp_bias ? lw.fc1_b : nullptr,
-                                                     c.mlp_bias ? lw.fc2_b : nullptr, x16_out, n_blocks, 1e-5f);
+    const float* fb1 = c.mlp_bias ? lw.fc1_b : nullptr;
+    const float* fb2 = c.mlp_bias ? lw.fc2_b : nullptr;
+    const int abl = study_env("GENIE_FUSED_ABL", 0);
+    if (nx_g) {
+        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        mlp_fused_bf16_kernel<true><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nx_g, nx_b,
+                                                               n_blocks, 1e-5f, abl);
+    } else {
+        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        mlp_fused_bf16_kernel<false><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nullptr,
+                                                                nullptr, n_blocks, 1e-5f, abl);
+    }
     GENIE_LAUNCH_CHECK("mlp_fused_bf16");
     return GENIE_OK;
 }
@@ -533,11 +604,11 @@ int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw,
     if (c.qkv_bias && aw.qkv_b) {
         (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         temporal_fused_bf16_kernel<true><<<grid, 256, lds, st>>>(x16, x, aw.fused_w16, aw.qkv_b, c.proj_bias ? aw.proj_b : nullptr,
-                                                                 n_blocks, c.S, sl2e);
+                                                                 n_blocks, c.S, sl2e, study_env("GENIE_FUSED_ABL", 0));
     } else {
         (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         temporal_fused_bf16_kernel<false><<<grid, 256, lds, st>>>(x16, x, aw.fused_w16, nullptr, c.proj_bias ? aw.proj_b : nullptr,
-                                                                  n_blocks, c.S, sl2e);
+                                                                  n_blocks, c.S, sl2e, study_env("GENIE_FUSED_ABL", 0));
     }
     GENIE_LAUNCH_CHECK("temporal_fused_bf16");
     return GENIE_OK;

@@ -169,8 +169,9 @@ class STMaskGIT(nn.Module):
         self._invalidate()
 
     def _invalidate(self):
-        """Forget the cached pointer table (packed copies and fused streams go with it)."""
+        """Forget the cached pointer table (packed copies, fused streams and range flags go with it)."""
         self._table = None
+        self._wide = []
 
     def _weights(self):
         if self._table is not None:

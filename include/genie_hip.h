@@ -143,6 +143,16 @@ enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_F
 #define GENIE_TEMPORAL_FUSED_ELEMS 262144
 #define GENIE_MLP_FUSED_ELEMS 524288
 int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream);
+/* Unit entry points of the fused sub-blocks (parity tests, tuning).  Both update the f32 residual stream x in place and return
+ * GENIE_E_UNSUPPORTED outside the geometry above (the layer drivers then run the unfused launches).
+ *   temporal: x (B,16,S,256) += proj(causal_attention_T(qkv(x16))), x16 = bf16 copy of x (B,16,S,256); needs aw->fused_w16.
+ *             Reference: st_transformer.py:77-78 (the permute to (B S) T C is never materialised), attention.py:36-61.
+ *   mlp:      x (rows,256) += fc2(gelu(fc1(LayerNorm(x; norm2)))), rows % 128 == 0; x16_out (or NULL) receives the bf16 copy
+ *             of the result, or -- when next_norm_w / next_norm_b are given -- LayerNorm(result; next_norm_*) in bf16 (the next
+ *             block's norm1 output, st_transformer.py:73); needs lw->mlp_fused_w16.  Reference: st_transformer.py:81, 16-25. */
+int genie_temporal_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* x16, float* x, int B, void* stream);
+int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, float* x, uint16_t* x16_out, int64_t rows,
+                         const float* next_norm_w, const float* next_norm_b, void* stream);
 int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream);
 
 /* ---- unit entry points (one reference op each; used by the parity tests) -------------------------- */

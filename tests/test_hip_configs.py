@@ -115,7 +115,8 @@ def test_split_gemm_range_edges():
 
 def test_f16x3_weight_beyond_32_falls_back_per_tensor():
     """A checkpoint with |w| >= 32 in some tensor: that tensor's Linear leaves the 2^11-scaling 256x256
-    kernel for the two-accumulator split GEMM (genie_weight_range_hint), everything else stays where it was, and the logits
+    kernel for the two-accumulator split GEMM (the `w16_wide` flag next to its pointer in the weight table, genie_hip.h), everything
+    else stays where it was, and the logits
     remain f32-class against the oracle.  Rows of the readout, of fc1 and of the spatial V projection are scaled up."""
     cfg = pkg("config").GenieConfig(num_layers=2, num_heads=8, d_model=512, T=16, S=256, num_factored_vocabs=2,
                                     qk_norm=False, use_mup=False)
