@@ -48,6 +48,51 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define FS_ABL(bit) false
 #endif
 
+// Study build: GENIE_FUSED_STAMPS=1 makes wave 0 of every workgroup record s_memrealtime (100 MHz) at four points of each of its
+// first 8 blocks (block start, operand rows in registers, main loop done, residual stores issued) plus its hardware id, and
+// accumulate wave 0's main-loop cycles (s_memtime) by category: 0 wait (vmcnt + barrier), 1 LDS-DMA issue, 2 matrix section
+// (fragment reads + MFMAs), 3 VALU section (GELU / softmax + packing).  Read back with genie_study_fused_stamps
+// (tools/fused_timeline.py).  Layout: [512 workgroups][1 + 8 * 4] stamp words, then [512][4] cycle words.
+#ifdef GENIE_STUDY
+__device__ unsigned long long* g_fs_stamps = nullptr;
+#define FS_STAMP(blk_i, k)                                                                                           \
+    do {                                                                                                             \
+        if (g_fs_stamps && threadIdx.x == 0 && (blk_i) < 8)                                                          \
+            g_fs_stamps[(size_t)blockIdx.x * 33 + 1 + (blk_i) * 4 + (k)] = __builtin_amdgcn_s_memrealtime();          \
+    } while (0)
+#define FS_STAMP_ID()                                                                                                \
+    do {                                                                                                             \
+        if (g_fs_stamps && threadIdx.x == 0) {                                                                       \
+            unsigned hw, xcc;                                                                                        \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                        \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                      \
+            g_fs_stamps[(size_t)blockIdx.x * 33] = ((unsigned long long)xcc << 32) | hw;                              \
+        }                                                                                                            \
+    } while (0)
+#define FS_CYC_DECL unsigned long long fs_cyc[4] = {0, 0, 0, 0}, fs_t = __builtin_amdgcn_s_memtime()
+#define FS_CYC(cat)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();                      \
+        fs_cyc[cat] += n_ - fs_t;                                                        \
+        fs_t = n_;                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#define FS_CYC_RESET() (fs_t = __builtin_amdgcn_s_memtime())
+#define FS_CYC_DUMP()                                                                    \
+    do {                                                                                 \
+        if (g_fs_stamps && threadIdx.x == 0)                                             \
+            for (int q_ = 0; q_ < 4; ++q_) g_fs_stamps[33 * 512 + (size_t)blockIdx.x * 4 + q_] = fs_cyc[q_]; \
+    } while (0)
+#else
+#define FS_STAMP(blk_i, k) ((void)0)
+#define FS_STAMP_ID() ((void)0)
+#define FS_CYC_DECL ((void)0)
+#define FS_CYC(cat) ((void)0)
+#define FS_CYC_RESET() ((void)0)
+#define FS_CYC_DUMP() ((void)0)
+#endif
+
 namespace {
 
 constexpr int FS_STAGE = 16384;  // bytes of one stage = 16 fragments of 1 KB
@@ -134,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
     for (int i = tid; i < 256 + (QKV_BIAS ? 768 : 0); i += 256) sbias[i] = i < 256 ? (proj_b ? proj_b[i] : 0.f) : qkv_b[i - 256];
     __syncthreads();
 
+    FS_CYC_DECL;
     auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, 32 * FS_STAGE, 0x00020000);
     const unsigned voff = (unsigned)lane * 16;
     int n_issue = 0;  // stages issued so far (monotonic; stream position = n & 31, slot = n & 3)
@@ -149,9 +195,12 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
     int n_use = 0;  // stages consumed so far
     // stage n_use has landed for every wave, and the slot of stage n_use - 1 is free: refill it three stages ahead
     auto acquire = [&]() -> const unsigned char* {
+        FS_CYC(3);
         fs_wait_vm<8>();
         fs_barrier();
+        FS_CYC(0);
         if (!FS_ABL(1)) issue_stage();
+        FS_CYC(1);
         const unsigned char* p = smem + (n_use & (FS_NS - 1)) * FS_STAGE + lane * 16;
         ++n_use;
         return p;
@@ -163,7 +212,10 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
     issue_stage();
 
     const int bps = S / 8;  // blocks per clip
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    FS_STAMP_ID();
+    [[maybe_unused]] int blk_i = 0;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x, ++blk_i) {
+        FS_STAMP(blk_i, 0);
         const int b = blk / bps, s0 = (blk - b * bps) * 8 + 2 * wid;
         // this lane's token of group grp: frame r, position s0 + grp
         const size_t row0 = ((size_t)b * T + r) * S + s0;
@@ -174,6 +226,8 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
             for (int ks = 0; ks < 8; ++ks)
                 xf[grp][ks] = *reinterpret_cast<const s16x8*>(x16 + (row0 + grp) * D + 32 * ks + 8 * g);
         fs_wait_vm<0>();
+        FS_STAMP(blk_i, 1);
+        FS_CYC_RESET();
 
         s16x8 oall[2][NH];
 #pragma unroll
@@ -204,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
                         for (int grp = 0; grp < 2; ++grp)
                             acc[grp][ft] = part < 2 ? mma32(wf, xf[grp][ks], acc[grp][ft]) : mma32(xf[grp][ks], wf, acc[grp][ft]);
                     }
+                FS_CYC(2);
 #pragma unroll
                 for (int grp = 0; grp < 2; ++grp) {
                     if (part == 0) qb[grp] = pack8(acc[grp][0], acc[grp][1]);
@@ -265,10 +320,12 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
 #pragma unroll
                 for (int grp = 0; grp < 2; ++grp) out[grp][ct] = mma32(wf, oall[grp][h], out[grp][ct]);
             }
+            FS_CYC(2);
         }
         // residual update in place: x[token][16 ct + 4 g ..] += out (bias is already in the accumulators).  Four rounds of 8
         // 16-byte pieces; round k + 1's reads are requested before round k's stores (vmcnt retires in order: a wait for reads
         // issued behind a store would also wait for the store).
+        FS_STAMP(blk_i, 2);
         if (FS_ABL(2)) continue;
         float* xr0 = x + row0 * D + 4 * g;
         f32x4 res[2][8];
@@ -287,9 +344,32 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
 #pragma unroll
             for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(xr + c * 16) = res[k & 1][c];
         }
+        FS_STAMP(blk_i, 3);
     }
+    FS_CYC_DUMP();
     fs_wait_vm<0>();  // the ring's run-ahead stages must not outlive the workgroup's LDS allocation
 }
+
+#ifdef GENIE_STUDY
+static unsigned long long* g_fs_stamps_host_ptr = nullptr;
+static void fs_stamps_prepare() {
+    static const int on = study_env("GENIE_FUSED_STAMPS", 0);
+    if (!on) return;
+    if (!g_fs_stamps_host_ptr) {
+        (void)hipMalloc(&g_fs_stamps_host_ptr, sizeof(unsigned long long) * 37 * 512);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fs_stamps), &g_fs_stamps_host_ptr, sizeof(g_fs_stamps_host_ptr));
+    }
+    (void)hipMemset(g_fs_stamps_host_ptr, 0, sizeof(unsigned long long) * 37 * 512);
+}
+extern "C" int genie_study_fused_stamps(unsigned long long* out_host, int n_words) {   // stamps of the LAST fused launch
+    if (!g_fs_stamps_host_ptr || !out_host) return -1;
+    (void)hipDeviceSynchronize();
+    const int n = n_words < 37 * 512 ? n_words : 37 * 512;
+    return hipMemcpy(out_host, g_fs_stamps_host_ptr, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost) == hipSuccess ? n : -1;
+}
+#else
+static void fs_stamps_prepare() {}
+#endif
 
 int launch_pack_temporal_fused(const float* qkv_w, const float* proj_w, uint16_t* out, hipStream_t st) {
     pack_temporal_fused_kernel<<<(32 * 16 * 64 * 8) / 256, 256, 0, st>>>(qkv_w, proj_w, out);
@@ -402,7 +482,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
 
     issue_region(0);
 
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    FS_STAMP_ID();
+    FS_CYC_DECL;
+    [[maybe_unused]] int blk_i = 0;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x, ++blk_i) {
+        FS_STAMP(blk_i, 0);
         float* xrow = x + ((size_t)blk * 128 + wid * 32 + r) * D;   // this lane's token
         // ---- LayerNorm of the wave's 32 rows, straight into the K-step fragments
         s16x8 xf[16];
@@ -435,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
             }
         }
         fs_wait_vm<0>();
+        FS_STAMP(blk_i, 1);
 
         f32x16 out[8];
 #pragma unroll
@@ -462,18 +547,25 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         };
 
         // region 0: fc1 of chunk 0
+        FS_CYC_RESET();
         fs_barrier();
+        FS_CYC(0);
         issue_region(1);
+        FS_CYC(1);
         f32x16 acc1 = bias1(0);
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) acc1 = mma32x32(frag(lbase, ks), xf[ks], acc1);
+        FS_CYC(2);
         s16x8 hk0, hk1;
         gelu_pack(acc1, hk0, hk1);
+        FS_CYC(3);
         // regions 1..31: fc1 of chunk j next to fc2 of chunk j - 1
         for (int j = 1; j < 32; ++j) {
             fs_wait_vm<0>();
             fs_barrier();
+            FS_CYC(0);
             issue_region(j + 1);
+            FS_CYC(1);
             const unsigned char* sa = lbase + (j & 1) * 2 * FS_STAGE;
             acc1 = bias1(j);
 #pragma unroll
@@ -481,7 +573,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                 acc1 = mma32x32(frag(sa, i), xf[i], acc1);
                 out[i & 7] = mma32x32(frag(sa + FS_STAGE, i), (i >> 3) ? hk1 : hk0, out[i & 7]);
             }
+            FS_CYC(2);
             gelu_pack(acc1, hk0, hk1);
+            FS_CYC(3);
         }
         // region 32: fc2 of chunk 31; the next block's region 0 is requested here (this block's slot 1 is free after the barrier)
         fs_wait_vm<0>();
@@ -490,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[i & 7] = mma32x32(frag(lbase + FS_STAGE, i), (i >> 3) ? hk1 : hk0, out[i & 7]);
         // ---- residual update in place: lane = token, columns 32 ct + 8 j + 4 h .. + 3; rounds of 8 pieces, next round's reads first
+        FS_STAMP(blk_i, 2);
         if (FS_ABL(2)) { asm volatile("" :: "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7])); continue; }
         f32x4 res[2][8];
         float* xrowh = xrow + 4 * h;
@@ -550,7 +645,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                     *reinterpret_cast<s16x4*>(x16h + col) = pack4(y);
                 }
         }
+        FS_STAMP(blk_i, 3);
     }
+    FS_CYC_DUMP();
     fs_wait_vm<0>();
 }
 
@@ -572,6 +669,7 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
     const float* fb1 = c.mlp_bias ? lw.fc1_b : nullptr;
     const float* fb2 = c.mlp_bias ? lw.fc2_b : nullptr;
     const int abl = study_env("GENIE_FUSED_ABL", 0);
+    fs_stamps_prepare();
     if (nx_g) {
         (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
         mlp_fused_bf16_kernel<true><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nx_g, nx_b,
@@ -600,6 +698,7 @@ int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw,
     ProfScope prof(GENIE_KC_FUSED, M * (2.0 * 256 * 1024 + 4.0 * 16 * 256), M * (512.0 + 2048.0), st,
                    "temporal_fused_bf16_kernel (qkv + causal attention over T + proj + residual)");
     const size_t lds = FS_RING + 4096;
+    fs_stamps_prepare();
     const float sl2e = c.attn_scale * 1.4426950408889634f;
     if (c.qkv_bias && aw.qkv_b) {
         (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
