@@ -482,12 +482,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_slab_kernel(const uint16_t* __
                 const int s = 3 * a + d;
                 // outstanding DMAs younger than W(s): W(s+1) and, behind stage d = 0, the next slab (4 chunks, 5 for wave 0);
                 // the first stage of a tile also waits for the previous tile's epilogue stores
-                if (s + 1 >= nk || s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (s == 0) asm volatile("" : "+v"(bq0), "+v"(bq1));   // the bias has landed (see above)
-                else if (d == 1 && more) {
+                if (s + 1 >= nk || s == 0) {            // everything, including the bias at the top of a tile
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (s == 0) asm volatile("" : "+v"(bq0), "+v"(bq1));   // the bias has landed (see above)
+                } else if (d == 1 && more) {
                     if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 5) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH + 4) : "memory");
-                } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH) : "memory");
+                }
                 __builtin_amdgcn_s_barrier();
                 if (!(flags & 512)) {
                     if (d == 0 && more) load_slab(a + 1);

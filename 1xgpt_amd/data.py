@@ -9,7 +9,6 @@ collator of data.py:109-169 (random corruption + MaskGIT masking) on whatever de
 """
 import json
 import math
-import os
 import random
 from pathlib import Path
 
@@ -18,43 +17,45 @@ import torch
 from torch.utils.data import Dataset as TorchDataset
 
 
+def _window_starts(n_frames, span, segment_ids=None):
+    """First-frame indices of all windows that fit (their last frame is `span` frames later); with `segment_ids`, only windows
+    that begin and end in the same recording segment."""
+    starts = np.arange(max(n_frames - span, 0))
+    if segment_ids is not None and len(starts):
+        seg = np.asarray(segment_ids)
+        starts = starts[seg[starts] == seg[starts + span]]
+    return starts.tolist()
+
+
+def _drop_shared_frames(starts, window_size, stride):
+    """Walk the (increasing) window starts and keep one only if it shares no frame with a window kept before: two windows on
+    the same stride grid share a frame exactly when their starts differ by stride, 2 stride, ..., (window_size - 1) stride.
+    (Equivalent to the reference's scan over its most recent kept entries, data.py:72-88: kept starts are distinct integers, so
+    every one close enough to collide is among them.)"""
+    kept, seen = [], set()
+    for s0 in starts:
+        if not any((s0 - i * stride) in seen for i in range(1, window_size)):
+            kept.append(s0)
+            seen.add(s0)
+    return kept
+
+
 class RawTokenDataset(TorchDataset):
     def __init__(self, data_dir, window_size, stride=1, filter_interrupts=True, filter_overlaps=False):
-        data_dir = Path(data_dir)
-        with open(data_dir / "metadata.json") as f:
-            self.metadata = json.load(f)
-        shape = (self.metadata["num_images"], self.metadata["s"], self.metadata["s"])
-        video_tokens_path, segment_ids_path = data_dir / "video.bin", data_dir / "segment_ids.bin"
-        token_dtype = np.dtype(self.metadata.get("token_dtype", "uint32"))
-        self.data = np.memmap(video_tokens_path, dtype=token_dtype, mode="r", shape=shape)
-        if os.path.isfile(segment_ids_path):
-            self.segment_ids = np.memmap(segment_ids_path, dtype=np.int32, mode="r",
-                                         shape=(self.metadata["num_images"],))
-        else:
-            self.segment_ids = None
-            if filter_interrupts:
-                raise NotImplementedError("Cannot filter interrupted sequences without segment ids.")
+        root = Path(data_dir)
+        self.metadata = json.loads((root / "metadata.json").read_text())
+        n, side = self.metadata["num_images"], self.metadata["s"]
+        self.data = np.memmap(root / "video.bin", mode="r", shape=(n, side, side),
+                              dtype=np.dtype(self.metadata.get("token_dtype", "uint32")))
+        seg_file = root / "segment_ids.bin"
+        self.segment_ids = np.memmap(seg_file, dtype=np.int32, mode="r", shape=(n,)) if seg_file.is_file() else None
+        if filter_interrupts and self.segment_ids is None:
+            raise NotImplementedError("Cannot filter interrupted sequences without segment ids.")
         self.window_size, self.stride = window_size, stride
-        # frames between the first and last frame of a window (excluding one endpoint)
-        self.video_len = (self.window_size - 1) * self.stride
-
-        n_starts = max(len(self.data) - self.video_len, 0)
-        starts = np.arange(n_starts)
-        if filter_interrupts and n_starts:
-            seg = np.asarray(self.segment_ids)
-            starts = starts[seg[starts] == seg[starts + self.video_len]]
-        self.valid_start_inds = starts.tolist()
-
+        self.video_len = (window_size - 1) * stride          # distance from a window's first frame to its last
+        self.valid_start_inds = _window_starts(len(self.data), self.video_len, self.segment_ids if filter_interrupts else None)
         if filter_overlaps:
-            # greedy, in order: keep a start unless one of the kept starts of the last window_size*stride
-            # entries lies exactly i*stride before it (i = 1..window_size-1), i.e. shares a frame with it
-            kept = []
-            for start_ind in self.valid_start_inds:
-                overlapping = {start_ind - i * self.stride for i in range(1, self.window_size)}
-                recent = kept[-self.window_size * self.stride:]
-                if not any(k in overlapping for k in recent):
-                    kept.append(start_ind)
-            self.valid_start_inds = kept
+            self.valid_start_inds = _drop_shared_frames(self.valid_start_inds, window_size, stride)
 
     def __len__(self):
         return len(self.valid_start_inds)

@@ -62,24 +62,37 @@ def init_device(local_rank: int, world: int = 1):
         timer.cancel()
 
 
-def init_distributed(backend=None):
+def _is_timeout(e: BaseException) -> bool:
+    """A rendezvous that ran out of time: c10d raises DistStoreError / DistNetworkError / TimeoutError / RuntimeError with
+    'timed out' or 'timeout' somewhere in the text, depending on which layer noticed."""
+    if isinstance(e, TimeoutError):
+        return True
+    text = f"{type(e).__name__} {e}".lower()
+    return "timeout" in text or "timed out" in text
+
+
+def init_distributed(backend=None, force_group=False):
     """Initialise torch.distributed from the torchrun environment; returns (rank, world_size, local_rank).
-    Order: this rank's GPU first (init_device: staggered, watched), then the rendezvous with a bounded timeout
-    (GENIE_RDZV_TIMEOUT seconds, default 600; on expiry the rank exits with RDZV_TIMEOUT_RC rather than waiting for the
-    backend's 30-minute default)."""
+    Order: this rank's GPU first (init_device: staggered, watched), then the rendezvous.  Only the RENDEZVOUS is bounded by
+    GENIE_RDZV_TIMEOUT seconds (default 600; on expiry the rank exits with RDZV_TIMEOUT_RC rather than waiting for the
+    backend's 30-minute default): once the group exists its timeout is set back to GENIE_COLLECTIVE_TIMEOUT seconds (default
+    1800), so ranks may reach a later all-reduce or barrier far apart (uneven evaluation shards, a leg that runs on rank 0 only).
+    force_group (or GENIE_DIST_FORCE_GROUP=1): create the process group even at world size 1 -- a one-GPU box can then push
+    the path's collectives through RCCL itself (tests/test_hip_multirank.py)."""
     import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    force_group = force_group or os.environ.get("GENIE_DIST_FORCE_GROUP", "0") == "1"
     if backend != "gloo" or os.environ.get("GENIE_FORCE_DEVICE") is not None:
         init_device(local_rank, world)   # (a pure-CPU gloo run has nothing to initialise)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("GENIE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         limit = float(os.environ.get("GENIE_RDZV_TIMEOUT", "600"))
-        kwargs = {"timeout": datetime.timedelta(seconds=limit)}
+        kwargs = {}
         if backend == "nccl":
             dev_index = local_device_index(local_rank)
             torch.cuda.set_device(dev_index)
@@ -87,11 +100,20 @@ def init_distributed(backend=None):
 
         def rendezvous():
             try:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=limit), **kwargs)
             except Exception as e:  # store / rendezvous timeout: a peer never arrived
-                if "imeout" in f"{type(e).__name__} {e}":
+                if _is_timeout(e):
                     _stall_exit(f"rendezvous did not complete within {limit:.0f} s ({type(e).__name__}: {e})", RDZV_TIMEOUT_RC)
                 raise
+            # the bound above was for the rendezvous only: give the group back the backend's collective timeout (30 minutes)
+            try:
+                from torch.distributed import distributed_c10d as c10d
+                c10d._set_pg_timeout(datetime.timedelta(seconds=float(os.environ.get("GENIE_COLLECTIVE_TIMEOUT", "1800"))))
+            except Exception as e:   # (private helper: if a torch release drops it the short timeout stays -- say so)
+                import sys
+                print(f"1xgpt_amd.distributed: collectives keep the {limit:.0f} s rendezvous timeout ({type(e).__name__}: {e})",
+                      file=sys.stderr)
 
         if backend == "gloo":
             # gloo announces its connections on STDOUT; callers (bench.py) print exactly one JSON line there
@@ -124,10 +146,10 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def reduce_metric_sums(sums: torch.Tensor, seconds: float = None):
+def reduce_metric_sums(sums: torch.Tensor, seconds: float = None, always: bool = False):
     """all-reduce(SUM) a vector of partial sums in place; optionally all-reduce(MAX) the wall time.
-    No-op for a single process."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    No-op for a single process unless `always` (then a world-size-1 group still runs the collective: the RCCL smoke test)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or always):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         if seconds is not None:
             t = torch.tensor([seconds], dtype=torch.float64, device=sums.device)

@@ -10,19 +10,22 @@ from . import _lib
 
 
 class AvgMetric:
-    """Running batch-size-weighted mean (eval_utils.py:10-25)."""
+    """Weighted running mean with the reference's interface (eval_utils.py:10-25): ``update(val, batch_size)`` adds a batch mean
+    with its weight, ``update_list(values)`` adds per-sample values with weight one each, ``mean()`` is sum / weight.  Kept as
+    (weighted sum, weight) so that partial sums from several ranks can be added before dividing (distributed.means_from_sums)."""
 
     def __init__(self):
-        self.total = 0
-        self.count = 0
+        self.total, self.count = 0, 0
+
+    def _add(self, weighted_sum, weight):
+        self.total, self.count = self.total + weighted_sum, self.count + weight
 
     def update(self, val, batch_size=1):
-        self.total += val * batch_size
-        self.count += batch_size
+        self._add(val * batch_size, batch_size)
 
     def update_list(self, flat_vals):
-        self.total += sum(flat_vals)
-        self.count += len(flat_vals)
+        vals = list(flat_vals)
+        self._add(sum(vals), len(vals))
 
     def mean(self):
         return self.total / self.count
@@ -36,15 +39,15 @@ def _cfg_for_ce(T, S, num_factored_vocabs, factored_vocab_size):
 
 def factored_ce_sums(labels_flat, factored_logits, num_factored_vocabs=2, factored_vocab_size=512):
     """-> (3,) float64 device tensor [sum CE, sum all-factors-correct, n tokens] over frames 1..T-1."""
-    assert factored_logits.dim() == 6 \
-        and factored_logits.size()[:3] == (labels_flat.size(0), factored_vocab_size, num_factored_vocabs), \
-        f"Shape of `logits` should be (B, {factored_vocab_size}, {num_factored_vocabs}, T-1, H, W)"
+    B, n_tok = labels_flat.shape[0], labels_flat.shape[1]
+    want = (B, factored_vocab_size, num_factored_vocabs)
+    if factored_logits.dim() != 6 or tuple(factored_logits.shape[:3]) != want:   # same complaint as eval_utils.py:62-64
+        raise AssertionError(f"Shape of `logits` should be (B, {factored_vocab_size}, {num_factored_vocabs}, T-1, H, W)")
     if not factored_logits.is_cuda:
         raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): logits must be on cuda")
-    B = labels_flat.size(0)
-    t = factored_logits.size(3) + 1
-    h, w = factored_logits.size()[-2:]
-    assert t * h * w == labels_flat.size(1), "Shape of `factored_logits` does not match flattened latent image size."
+    t, (h, w) = factored_logits.shape[3] + 1, factored_logits.shape[-2:]
+    if t * h * w != n_tok:                                                        # eval_utils.py:66-67
+        raise AssertionError("Shape of `factored_logits` does not match flattened latent image size.")
     # (B, Vf, nv, T-1, H, W) -> kernel layout (B, nv*Vf, T-1, S)
     lg = factored_logits.permute(0, 2, 1, 3, 4, 5).contiguous().float()
     labels = labels_flat.to(device=lg.device, dtype=torch.int64).contiguous()

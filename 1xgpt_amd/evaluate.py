@@ -38,21 +38,20 @@ class GenieEvaluator:
 
         Total forward passes = (T-1) * maskgit_steps (evaluate.py:90).
         noise: optional (T-1, maskgit_steps-1, B, S) replay of the "random" unmasking draws."""
-        T = self.model.config.T
-        h, w = self.args.latent_h, self.args.latent_w
-        inputs_THW = input_ids.to(self.device).to(torch.int64).view(-1, T, h, w)
-        all_samples, all_logits = [], []
-        for k, timestep in enumerate(range(1, T)):
-            inputs_masked = inputs_THW.clone()
-            inputs_masked[:, timestep:] = self.model.mask_token_id
-            samples_HW, factored_logits = self.model.maskgit_generate(
-                inputs_masked, out_t=timestep, maskgit_steps=self.args.maskgit_steps,
-                temperature=self.args.temperature, noise=None if noise is None else noise[k],
-                return_logits=return_logits, check=False)
-            all_samples.append(samples_HW)
-            all_logits.append(factored_logits)
-        samples_THW = torch.stack(all_samples, dim=1)
-        return samples_THW, (torch.stack(all_logits, dim=3) if return_logits else None)
+        m, a = self.model, self.args
+        T = m.config.T
+        clips = input_ids.to(self.device).to(torch.int64).view(-1, T, a.latent_h, a.latent_w)
+        frames, logits = [], []
+        for t in range(1, T):
+            # timeline t: frames < t are ground truth, frame t and everything after it all-MASK; decode frame t
+            timeline = clips.clone()
+            timeline[:, t:] = m.mask_token_id
+            frame, lg = m.maskgit_generate(timeline, out_t=t, maskgit_steps=a.maskgit_steps, temperature=a.temperature,
+                                           noise=None if noise is None else noise[t - 1], return_logits=return_logits,
+                                           check=False)
+            frames.append(frame)
+            logits.append(lg)
+        return torch.stack(frames, dim=1), (torch.stack(logits, dim=3) if return_logits else None)
 
     def predict_next_frames(self, samples_THW) -> torch.Tensor:
         """Sampled tokens -> RGB frames (B, T-1, 3, 256, 256) uint8 through the on-device MAGVIT2 decoder."""

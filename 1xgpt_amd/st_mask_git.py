@@ -363,30 +363,32 @@ class STMaskGIT(nn.Module):
 
     def generate(self, input_ids, attention_mask=None, max_new_tokens=None, min_new_tokens=None, return_logits=False,
                  maskgit_steps=1, temperature=0.0, noise=None):
-        """Llama-style wrapper: append all-mask frames and decode them one by one (reference :65-113).
-
-        noise: optional (num_new_frames, maskgit_steps-1, B, S)."""
-        assert min_new_tokens in (None, max_new_tokens), \
-            "Expecting `min_new_tokens`, if specified, to match `max_new_tokens`."
-        assert max_new_tokens % self.config.S == 0, "Expecting `max_new_tokens` to be a multiple of `self.config.S`."
-        num_new_frames = max_new_tokens // self.config.S
+        """Autoregressive frame generation behind the reference's Llama-style signature (st_mask_git.py:65-113):
+        ``input_ids`` (B, n_prompt_frames * S) holds the prompt frames; ``max_new_tokens // S`` further frames are decoded one
+        after the other with ``maskgit_generate``, each seeing every frame before it.  Returns the (B, (n_prompt + n_new) * S)
+        token ids, plus -- with ``return_logits`` -- the step-0 factored logits of the new frames stacked on dim 3.
+        ``attention_mask`` is accepted and ignored, as in the reference.  ``min_new_tokens`` may only repeat ``max_new_tokens``.
+        noise: optional (n_new_frames, maskgit_steps - 1, B, S) unmasking draws to replay (the reference draws them itself)."""
+        S = self.config.S
+        if min_new_tokens is not None and min_new_tokens != max_new_tokens:
+            raise AssertionError("Expecting `min_new_tokens`, if specified, to match `max_new_tokens`.")
+        if max_new_tokens % S:
+            raise AssertionError("Expecting `max_new_tokens` to be a multiple of `self.config.S`.")
         ids = self._ids(input_ids)
-        inputs_THW = ids.view(ids.size(0), -1, self.h, self.w)
-        inputs_masked_THW = torch.cat([
-            inputs_THW,
-            torch.full((ids.size(0), num_new_frames, self.h, self.w), self.mask_token_id, dtype=torch.long,
-                       device=ids.device)], dim=1).contiguous()
-        all_factored_logits = []
-        for k, timestep in enumerate(range(inputs_THW.size(1), inputs_THW.size(1) + num_new_frames)):
-            sample_HW, factored_logits = self.maskgit_generate(
-                inputs_masked_THW, timestep, maskgit_steps=maskgit_steps, temperature=temperature,
-                noise=None if noise is None else noise[k], return_logits=return_logits)
-            inputs_masked_THW[:, timestep] = sample_HW
-            all_factored_logits.append(factored_logits)
-        predicted_tokens = inputs_masked_THW.view(ids.size(0), -1)
-        if return_logits:
-            return predicted_tokens, torch.stack(all_factored_logits, dim=3)
-        return predicted_tokens
+        B, n_new = ids.size(0), max_new_tokens // S
+        n_prompt = ids.numel() // (B * S)
+        # one (B, n_prompt + n_new, H, W) canvas: prompt frames up front, the frames to come all-MASK; maskgit_generate fills
+        # canvas[:, t] in place, which is exactly what the next frame's context must contain
+        canvas = torch.full((B, n_prompt + n_new, self.h, self.w), self.mask_token_id, dtype=torch.long, device=ids.device)
+        canvas[:, :n_prompt] = ids.view(B, n_prompt, self.h, self.w)
+        step0_logits = []
+        for k in range(n_new):
+            frame, logits = self.maskgit_generate(canvas, n_prompt + k, maskgit_steps=maskgit_steps, temperature=temperature,
+                                                  noise=None if noise is None else noise[k], return_logits=return_logits)
+            canvas[:, n_prompt + k] = frame
+            step0_logits.append(logits)
+        tokens = canvas.view(B, -1)
+        return (tokens, torch.stack(step0_logits, dim=3)) if return_logits else tokens
 
     # ------------------------------------------------------------------ weights
     def init_weights(self):

@@ -122,8 +122,9 @@ class BucketReducer:
     the exchange of late layers runs under the backward of early ones.  `finish()` makes the current stream wait for
     all of them.  Works on any backend (gloo in the CPU tests)."""
 
-    def __init__(self, flat, bounds, group=None):
-        self.flat, self.bounds, self.group = flat, list(bounds), group
+    def __init__(self, flat, bounds, group=None, always=False):
+        # always: hand the buckets to the process group even at world size 1 (a one-GPU box exercising RCCL itself)
+        self.flat, self.bounds, self.group, self.always = flat, list(bounds), group, always
         self.reset()
 
     def reset(self):
@@ -134,7 +135,7 @@ class BucketReducer:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def ready(self, hi):
-        if self.world == 1:
+        if self.world == 1 and not (self.always and dist.is_available() and dist.is_initialized()):
             return
         while self.next < len(self.bounds) and self.bounds[self.next][1] <= hi:
             lo, up = self.bounds[self.next]

@@ -121,23 +121,58 @@ def pass_flops(cfg, frames=None):
     return T * S * (L * (32 * d * d + 4 * S * d + 4 * T * d) + 2 * d * V)
 
 
-def cpu_baseline(cfg, sd, clips, maskgit_steps, cands=(16, 32)):
+def host_cpu_info():
+    """CPU model string, physical cores (distinct (socket, core) pairs), logical CPUs and the CPUs this process may run on."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model == "unknown":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    logical = logical or (os.cpu_count() or 1)
+    return {"model": model, "physical_cores": len(cores) or logical, "logical_cpus": logical, "usable_cpus": usable}
+
+
+def cpu_baseline(cfg, sd, clips, maskgit_steps, cands=None):
     """The CPU path beside the GPU number: the torch-CPU restatement of the reference forward (oracle/genie_torch_port.py:
     the ops genie/evaluate.py executes with device="cpu") driving the oracle's MaskGIT loop, on this host's cores.
     Bounded sample of the same workload: ALL 15 timesteps of clip 0 (each = `maskgit_steps` full 16-frame forwards), every
     timestep timed on its own so that the line can carry min / median / mean (a shared host is noisy: the run-to-run spread
-    of a single mean was 1.8x).  The intra-op thread count is fixed first: for each candidate one cold forward, then the
-    minimum of two warm ones; the fastest candidate is used for the whole sample.  `value` = 1 / median seconds per timestep
-    (= frames/s, one frame is sampled per timestep); a full clip costs 15 timesteps."""
+    of a single mean was 1.8x).  The intra-op thread count is fixed first from a probe that goes up to ALL physical cores the
+    process may use (8, 16, 32, 64, ..., physical cores: one cold forward each, then the minimum of two warm ones); the fastest
+    candidate is used for the whole sample.  `value` = 1 / median seconds per timestep (= frames/s, one frame is sampled per
+    timestep); a full clip costs 15 timesteps.  The line names the CPU model, its physical core count and the threads used."""
     O = importlib.import_module("oracle.genie_oracle")
     TP = importlib.import_module("oracle.genie_torch_port")
     synth = importlib.import_module("1xgpt_amd.synthetic")
     H = W = int(round(cfg.S ** 0.5))
     x = clips[:1].reshape(1, cfg.T, H, W)
     sdt = TP.to_torch(sd)
-    ncpu = os.cpu_count() or 1
+    host = host_cpu_info()
+    top = max(1, min(host["physical_cores"], host["usable_cpus"]))
     prev_threads = torch.get_num_threads()
-    cands = sorted({c for c in cands if 1 <= c <= ncpu}) or [ncpu]
+    if cands is None:
+        cands = [c for c in (8, 16, 32, 64, 128) if c < top] + [top]
+    cands = sorted({c for c in cands if 1 <= c <= host["usable_cpus"]}) or [top]
     probe = {}
     for c in cands:
         torch.set_num_threads(c)
@@ -165,13 +200,16 @@ def cpu_baseline(cfg, sd, clips, maskgit_steps, cands=(16, 32)):
     srt = sorted(per_t)
     med = srt[len(srt) // 2]
     return {"value": 1.0 / med, "unit": "frames/s", "cores": int(best), "kind": "port",
+            "cpu_model": host["model"], "physical_cores": host["physical_cores"], "logical_cpus": host["logical_cpus"],
+            "usable_cpus": host["usable_cpus"], "threads_probed_s_per_forward": {str(c): round(v, 3) for c, v in sorted(probe.items())},
             "frames_per_s_min_median_mean": [1.0 / srt[-1], 1.0 / med, len(per_t) / dt],
             "seconds_per_timestep_min_median_max": [srt[0], med, srt[-1]],
             "sample": f"torch-CPU f32 port of the reference forward + oracle MaskGIT loop, clip 0, all {len(per_t)} timesteps x "
                       f"{maskgit_steps} MaskGIT steps = {len(per_t) * maskgit_steps} full 16-frame forwards in {dt:.1f} s "
-                      f"(median {med / maskgit_steps:.2f} s/forward); value = 1 / median seconds per timestep; {ncpu} logical "
-                      f"CPUs, intra-op threads {best} fixed from min-of-2 warm forwards: "
-                      + ", ".join(f"{c}: {v:.2f} s" for c, v in sorted(probe.items())),
+                      f"(median {med / maskgit_steps:.2f} s/forward); value = 1 / median seconds per timestep; host: {host['model']}, "
+                      f"{host['physical_cores']} physical cores / {host['logical_cpus']} logical CPUs ({host['usable_cpus']} usable); "
+                      f"intra-op threads {best} = the fastest of the probe up to all physical cores (min-of-2 warm forwards: "
+                      + ", ".join(f"{c}: {v:.2f} s" for c, v in sorted(probe.items())) + ")",
             "reference_cpu_anchor": "SURVEY.md 8(d): the reference itself (genie/evaluate.py path, torch 2.10 CPU) in the build "
                                     "container, 8 threads of a 2.1 GHz Xeon: 2.81 s per C138-shape forward = 0.19 frames/s"}
 
@@ -313,23 +351,31 @@ def spawn_ranks(n):
     if ndev < n and os.environ.get("GENIE_FORCE_DEVICE") is None:
         sys.exit(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible (set GENIE_FORCE_DEVICE=<i> and "
                  f"GENIE_DIST_BACKEND=gloo to run all ranks on one device as a plumbing check)")
-    os.environ["GENIE_BENCH_STARTED_MARKER"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"genie_bench_started_{os.getpid()}")
+    marker = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"genie_bench_started_{os.getpid()}")
+    os.environ["GENIE_BENCH_STARTED_MARKER"] = marker
+    if os.path.exists(marker):   # a stale file of an earlier process with this pid would suppress the one relaunch below
+        os.remove(marker)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    rc = subprocess.call(cmd, env=env)
-    if rc != 0 and os.environ.get("GENIE_BENCH_RELAUNCH", "1") != "0":
-        # a start-up failure (a rank's GPU initialisation stalled twice, or the rendezvous timed out: the ranks exit with
-        # HIP_INIT_STALL_RC / RDZV_TIMEOUT_RC and torchrun tears the group down) gets ONE fresh launcher -- a new child of this
-        # process, which has not touched the GPU; a failure inside the measurement is not retried
-        marker = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"genie_bench_started_{os.getpid()}")
-        if not os.path.exists(marker):
+    try:
+        rc = subprocess.call(cmd, env=env)
+        # A START-UP failure gets ONE fresh launcher (a new child of this process, which has not touched the GPU): a rank's GPU
+        # initialisation stalled twice or the rendezvous timed out -- the ranks then exit with HIP_INIT_STALL_RC /
+        # RDZV_TIMEOUT_RC and torchrun (which reports 1 whatever its workers returned) tears the group down before any rank
+        # has written the marker.  Deterministic failures that also end before the marker (bad arguments, fewer GPUs than
+        # ranks, out of memory in warm-up) say so on stderr and are not worth a second multi-minute attempt: the relaunch is
+        # skipped when the ranks left their own diagnosis in the marker's sibling file.
+        if rc != 0 and os.environ.get("GENIE_BENCH_RELAUNCH", "1") != "0" and not os.path.exists(marker) \
+                and not os.path.exists(marker + ".fatal"):
             print(f"bench.py: launcher exited with {rc} before the timed region started; starting a fresh launcher (once)",
                   file=sys.stderr, flush=True)
             cmd[cmd.index("--master-port") + 1] = str(_free_port())
             rc = subprocess.call(cmd, env=env)
-        else:
-            os.remove(marker)
+    finally:
+        for f in (marker, marker + ".fatal"):
+            if os.path.exists(f):
+                os.remove(f)
     sys.exit(rc)
 
 
@@ -372,10 +418,23 @@ def main():
     wd = int(os.environ.get("GENIE_BENCH_WATCHDOG", "900"))
     if wd > 0:
         faulthandler.dump_traceback_later(wd, exit=True)
+    marker = os.environ.get("GENIE_BENCH_STARTED_MARKER")
+    if marker:
+        # a rank that dies of a Python error before the timed region (bad arguments, a world-size mismatch, out of memory in the
+        # warm-up) leaves "<marker>.fatal": spawn_ranks then reports the failure instead of running the whole launcher again.
+        # (A stalled GPU initialisation / rendezvous leaves through os._exit in 1xgpt_amd.distributed and is relaunched once.)
+        def _fatal_hook(tp, val, tb, _prev=sys.excepthook):
+            if not os.path.exists(marker):
+                try:
+                    open(marker + ".fatal", "w").close()
+                except OSError:
+                    pass
+            _prev(tp, val, tb)
+        sys.excepthook = _fatal_hook
     dist_mod = importlib.import_module("1xgpt_amd.distributed")
     rank, world, local_rank = dist_mod.init_distributed()
     if world != args.gpus:
-        sys.exit(f"bench.py: launcher started WORLD_SIZE={world} rank(s) but --gpus {args.gpus} was asked for")
+        raise RuntimeError(f"bench.py: launcher started WORLD_SIZE={world} rank(s) but --gpus {args.gpus} was asked for")
     if world > 1:  # what the collective backend itself reports, not the environment
         assert torch.distributed.get_world_size() == args.gpus, (torch.distributed.get_world_size(), args.gpus)
     dev_index = dist_mod.local_device_index(local_rank)

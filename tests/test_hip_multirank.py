@@ -99,3 +99,18 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank():
     assert abs(two["ce"] - one["ce"]) < 1e-5, (two["ce"], one["ce"])
     assert "error" not in two["train_step"] and two["train_step"]["n_gpus"] == 2 and two["train_step"]["value"] > 0
     assert "bucketed" in two["train_step"]["gradient_exchange"]
+
+
+def test_rccl_world1():
+    """RCCL itself on the box's GPU: `backend="nccl"` at world size 1 -- init_distributed's device_id path,
+    the evaluator's six-sum f64 all-reduce and the trainer's BucketReducer on device tensors; librccl must be mapped."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), GENIE_RDZV_TIMEOUT="180")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_rccl_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["backend"] == "nccl" and res["world"] == 1
+    assert res["librccl_mapped"], "the nccl backend ran without librccl in the process?"
+    assert res["sums_equal"] and res["grads_equal"] and res["seconds"] == 1.25
+    assert res["buckets_early"] == 1

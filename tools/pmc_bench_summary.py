@@ -58,7 +58,8 @@ def main():
     if os.path.exists(out):
         with open(out) as f:
             doc = json.load(f)
-    doc["_source"] = note
+    doc.setdefault("_sources", {})[prec] = note   # each precision section is its own set of three --pmc passes
+    doc["_source"] = "per precision section: see _sources"
     doc[prec] = res
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
