@@ -465,8 +465,9 @@ def main():
     # tools/make_goldens.py c138_ev from the reference's evaluate.py on these weights): give it the reference's unmasking draws
     # so that the self-check below can compare ids, not only CE
     golden = None
-    gpath = os.path.join(REPO, "tests", "golden", "ev_c138.npz")
-    if rank == 0 and args.model == "c138" and args.maskgit_steps == 2 and os.path.exists(gpath):
+    gname = f"ev_{args.model}"   # ev_c138 (tools/make_goldens.py c138_ev) / ev_c35 (c35_ev: the shipped config at full depth)
+    gpath = os.path.join(REPO, "tests", "golden", gname + ".npz")
+    if rank == 0 and args.maskgit_steps == 2 and os.path.exists(gpath):
         golden = np.load(gpath)
         if np.array_equal(golden["ids"][0], all_clips[0]):
             noise[:, :, 0] = torch.from_numpy(golden["ev_noise"][:, :, 0]).to(dev)
@@ -573,8 +574,8 @@ def main():
             ce_tol = 1e-4 if args.precision != "bf16" else 5e-2
             ok_ref = abs(ce0 - float(golden["ev_loss"])) <= ce_tol and (args.precision == "bf16" or (exact_on_robust and agree > 0.99))
             selfcheck["clip0_vs_reference"] = {
-                "fixture": "tests/golden/ev_c138.npz (the reference's genie/evaluate.py + eval_utils.compute_loss on these weights "
-                           "and this clip, tools/make_goldens.py c138_ev)",
+                "fixture": f"tests/golden/{gname}.npz (the reference's genie/evaluate.py + eval_utils.compute_loss on these weights "
+                           f"and this clip, tools/make_goldens.py {args.model}_ev)",
                 "ce": ce0, "ce_reference": float(golden["ev_loss"]), "ce_delta": ce0 - float(golden["ev_loss"]),
                 "ce_tolerance": ce_tol, "ids_equal_fraction": agree,
                 "timesteps_with_robust_top2_gap": len(robust), "ids_bit_exact_on_those": bool(exact_on_robust), "ok": bool(ok_ref)}

@@ -585,6 +585,9 @@ def main():
         evaluate_fixture("ev_c138", dict(c138, num_heads=8), 0)
     if "c138_ev_h16" in which:
         evaluate_fixture("ev_c138_h16", dict(c138, num_heads=16), 0)
+    if "c35_ev" in which:       # BASELINE config 1's workload on the SHIPPED config (genie/configs/magvit_n32_h8_d256.json) at full depth
+        evaluate_fixture("ev_c35", dict(num_layers=32, num_heads=8, d_model=256, T=16, S=256, num_factored_vocabs=2, qk_norm=False,
+                                        use_mup=False), 0)
     if "c138_gen" in which:
         generate_fixture("gen_c138", dict(num_layers=32, num_heads=8, d_model=512, T=16, S=256,
                                           num_factored_vocabs=2, qk_norm=False, use_mup=False), 0)
