@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GENIE_HIP_LIBRARY") or os.path.join(HERE, "libgenie_h
 PREC_EXACT, PREC_BF16, PREC_F16X3 = 0, 1, 2
 LAYOUT_TOKEN_MAJOR, LAYOUT_BCTHW = 0, 1
 UNMASK_RANDOM, UNMASK_GREEDY = 0, 1
-KC_GEMM, KC_ATTN_SPATIAL, KC_ATTN_TEMPORAL, KC_LAYERNORM, KC_OTHER = range(5)
+KC_GEMM, KC_ATTN_SPATIAL, KC_ATTN_TEMPORAL, KC_LAYERNORM, KC_OTHER, KC_FUSED = range(6)
 E_ARG, E_SHAPE, E_UNSUPPORTED, E_LAUNCH, E_ASSERT = -1, -2, -3, -4, -5
 
 c_f32p = C.c_void_p  # device pointers travel as plain integers

@@ -486,7 +486,7 @@ def main():
         step()
     # timed region: exactly K steps, GEMM launches bracketed by HIP events on the launch stream
     if not args.no_events:
-        _lib.check(lib.genie_profile_enable((1 << _lib.KC_GEMM) | (1 << _lib.KC_ATTN_SPATIAL) |
+        _lib.check(lib.genie_profile_enable((1 << _lib.KC_GEMM) | (1 << _lib.KC_ATTN_SPATIAL) | (1 << _lib.KC_FUSED) |
                                             (1 << _lib.KC_ATTN_TEMPORAL) | (1 << _lib.KC_LAYERNORM)), "profile_enable")
         lib.genie_profile_reset()
     dist_mod.barrier()
@@ -522,10 +522,22 @@ def main():
     for line in kbuf.value.decode(errors="replace").splitlines():
         name, n, ms, fl = line.split("\t")
         gemm_kernels.append({"kernel": name, "launches": int(float(n)), "ms": float(ms), "tflops": float(fl) / max(float(ms), 1e-9) / 1e9})
+    # the fused sub-block kernels of the d = 256 bf16 path (csrc/kernels_fused.hip) carry Linear layers too: they join the list the
+    # dominant matrix kernel is picked from, and their FLOPs / time join the all-GEMM totals
+    _lib.check(lib.genie_profile_read(_lib.KC_FUSED, prof), "profile_read")
+    fused_launches, fused_ms, fused_flops, fused_bytes = list(prof)
+    if fused_launches:
+        _lib.check(lib.genie_profile_kernels(_lib.KC_FUSED, kbuf, len(kbuf)), "profile_kernels")
+        for line in kbuf.value.decode(errors="replace").splitlines():
+            name, n, ms, fl = line.split("\t")
+            gemm_kernels.append({"kernel": name, "launches": int(float(n)), "ms": float(ms), "tflops": float(fl) / max(float(ms), 1e-9) / 1e9,
+                                 "fused_subblock": True})
+        gemm_launches, gemm_ms, gemm_flops, gemm_bytes = (gemm_launches + fused_launches, gemm_ms + fused_ms, gemm_flops + fused_flops,
+                                                          gemm_bytes + fused_bytes)
     gemm_kernels.sort(key=lambda k: -k["ms"])
     other_classes = {}
     for name, kc in (("attention_spatial", _lib.KC_ATTN_SPATIAL), ("attention_temporal", _lib.KC_ATTN_TEMPORAL),
-                     ("layernorm", _lib.KC_LAYERNORM)):
+                     ("layernorm", _lib.KC_LAYERNORM), ("fused_subblocks", _lib.KC_FUSED)):
         _lib.check(lib.genie_profile_read(kc, prof), "profile_read")
         n, ms, fl, by = list(prof)
         if n:
