@@ -982,6 +982,8 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
 
 // The bf16 shadow of x must exist before the first layer when the block has no pre-norm (qk_norm configs).
 int prepare_bf16(const genie_cfg& c, const float* x, Workspace& w, int B, hipStream_t st) {
+    // LayerNorm blocks read the f32 x (norm1) first and their spatial out-projection writes the shadow before anything reads it
+    if (!c.qk_norm) return GENIE_OK;
     const size_t n = (size_t)B * c.T * c.S * c.d_model;
     cast16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(x, (uint16_t*)w.xn, n);
     GENIE_LAUNCH_CHECK("cast16");
@@ -1137,6 +1139,7 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
 }
 
 int prepare_f16x3(const genie_cfg& c, const float* x, Workspace& w, int B, hipStream_t st) {
+    if (!c.qk_norm) return GENIE_OK;   // (as prepare_bf16: nothing reads the split planes of x before the first out-projection rewrites them)
     const size_t n = (size_t)B * c.T * c.S * c.d_model;
     return launch_split_f16(x, (uint16_t*)w.xn, n, n, st);
 }
