@@ -102,7 +102,10 @@ constexpr int FS_RING = FS_NS * FS_STAGE;
 __device__ __forceinline__ void fs_barrier() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
+#if defined(GENIE_VAR_T_ABL) && (GENIE_VAR_T_ABL & 16)
+#else
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -110,7 +113,15 @@ template <int N>
 __device__ __forceinline__ void fs_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+#ifndef GENIE_VAR_T_ABL
+#define GENIE_VAR_T_ABL 0   // variant builds only (results wrong): 4 no matrix instructions, 8 no fragment reads, 16 no barriers
+#endif
 __device__ __forceinline__ f32x4 mma32(const s16x8& a, const s16x8& b, const f32x4& c) {
+    if constexpr (GENIE_VAR_T_ABL & 4) {
+        f32x4 r = c;
+        asm volatile("" : "+v"(r) : "v"(a), "v"(b));
+        return r;
+    }
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mma16k(const s16x4& a, const s16x4& b, const f32x4& c) {
@@ -205,11 +216,48 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
         ++n_use;
         return p;
     };
-    auto frag = [&](const unsigned char* stage, int f) { return *reinterpret_cast<const s16x8*>(stage + f * 1024); };
+    auto frag = [&](const unsigned char* stage, int f) {
+        if constexpr (GENIE_VAR_T_ABL & 8) {   // (variant: no LDS fragment reads -- a lane-dependent constant instead)
+            const short v = (short)(lane + f);
+            return s16x8{v, v, v, v, v, v, v, v};
+        } else {
+            return *reinterpret_cast<const s16x8*>(stage + f * 1024);
+        }
+    };
+#ifdef GENIE_VAR_T_PAIR
+    // variant: 32 KB stages (two 16-fragment parts per barrier), two slots: half the barriers, prefetch distance one stage
+    int s_issue = 0;   // 32 KB stages requested so far (stream position = s & 15, slot = s & 1)
+    auto issue_pair = [&]() {
+        const int soff = (s_issue & 15) * 2 * FS_STAGE + wid * 8192;
+        unsigned char* dst = smem + (s_issue & 1) * 2 * FS_STAGE + wid * 8192;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voff,
+                                                     soff + j * 1024, 0, 0);
+        ++s_issue;
+    };
+    int s_use = 0;
+    const unsigned char* pair_base = nullptr;
+    // part p of the block (p = 0..31, a compile-time constant at every call site): even parts open a new 32 KB stage
+    auto acquire_part = [&](int p) -> const unsigned char* {
+        if (!(p & 1)) {
+            fs_wait_vm<0>();
+            fs_barrier();
+            if (!FS_ABL(1)) issue_pair();
+            pair_base = smem + (s_use & 1) * 2 * FS_STAGE + lane * 16;
+            ++s_use;
+            return pair_base;
+        }
+        return pair_base + FS_STAGE;
+    };
+    issue_pair();
+#else
+    auto acquire_part = [&](int) -> const unsigned char* { return acquire(); };
 
     issue_stage();
     issue_stage();
     issue_stage();
+#endif
 
     const int bps = S / 8;  // blocks per clip
     FS_STAMP_ID();
@@ -236,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
             s16x4 vb[2][2];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                const unsigned char* stg = acquire();
+                const unsigned char* stg = acquire_part(3 * h + part);
                 f32x4 acc[2][2];
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
@@ -313,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const unsigned char* stg = acquire();
+            const unsigned char* stg = acquire_part(24 + h);
 #pragma unroll
             for (int ct = 0; ct < 16; ++ct) {
                 const s16x8 wf = frag(stg, ct);
