@@ -311,6 +311,44 @@ def test_sample_temperature(golden, models):
     assert agree >= 0.95  # cdf boundaries are f32 on the device, f64 in the oracle
 
 
+def test_sample_temperature_exact_outside_cdf_margins():
+    """temperature > 0, draw by draw: on the SAME logits and uniforms the kernel's inverse-CDF pick must equal the
+    f64 inverse-CDF pick for every draw whose target u * sum lies further than 2e-6 (relative to the sum) from a CDF step -- the f32
+    partial sums of the kernel cannot move a boundary by more than ~1e-7 -- and such ambiguous draws must be rare.  Confidence =
+    product of the picked probabilities."""
+    lib = pkg("_lib")
+    L = lib.load()
+    cfg = pkg("config").GenieConfig(num_layers=1, num_heads=2, d_model=64, T=4, S=256, num_factored_vocabs=2, qk_norm=False, use_mup=False)
+    c = lib.make_cfg(cfg, lib.PREC_EXACT)
+    g = np.random.default_rng(17)
+    R, S, Vf = 24, cfg.S, 512
+    logits = (g.standard_normal((R, S, 2 * Vf)) * 2.5).astype(np.float32)
+    uni = g.random((2, R, S), dtype=np.float32)
+    d_logits, d_uni = dev(logits), dev(uni)
+    samples = torch.empty(R, S, dtype=torch.int64, device="cuda")
+    conf = torch.empty(R, S, dtype=torch.float32, device="cuda")
+    lib.check(L.genie_sample(c, d_logits.data_ptr(), lib.LAYOUT_TOKEN_MAJOR, R, 0.8, d_uni.data_ptr(), samples.data_ptr(),
+                             conf.data_ptr(), torch.cuda.current_stream().cuda_stream), "genie_sample")
+    got = samples.cpu().numpy()
+    picks, ambiguous, want_conf = [], np.zeros((R, S), bool), np.ones((R, S))
+    for k, f in enumerate((1, 0)):                       # the hi vocabulary is drawn first (st_mask_git.py:179)
+        l = logits[:, :, f * Vf:(f + 1) * Vf].astype(np.float64)
+        e = np.exp(l - l.max(-1, keepdims=True))
+        tot = e.sum(-1)
+        cdf = np.cumsum(e, -1)
+        target = uni[k].astype(np.float64) * tot
+        pick = np.minimum((cdf < target[..., None]).sum(-1), Vf - 1)
+        ambiguous |= (np.abs(cdf - target[..., None]).min(-1) / tot) < 2e-6
+        picks.append(pick)
+        want_conf *= np.take_along_axis(e, pick[..., None], -1)[..., 0] / tot
+    want = picks[0] * Vf + picks[1]
+    assert ambiguous.mean() < 0.01, ambiguous.mean()
+    clear = ~ambiguous
+    assert np.array_equal(got[clear], want[clear]), int((got[clear] != want[clear]).sum())
+    assert (got[ambiguous] == want[ambiguous]).mean() > 0.3 if ambiguous.any() else True
+    np.testing.assert_allclose(conf.cpu().numpy()[clear], want_conf[clear], rtol=2e-5)
+
+
 def test_bits_from_tokens():
     lib = pkg("_lib")
     L = lib.load()
