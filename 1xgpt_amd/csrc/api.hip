@@ -696,6 +696,16 @@ int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, fl
     GENIE_CHECK_ARG(lw && x && rows >= 0, "mlp_fused: bad argument");
     return launch_mlp_fused_bf16(*cfg, *lw, x, x16_out, (long)rows, as_stream(stream), next_norm_w, next_norm_b);
 }
+int genie_pack_spatial_proj_fused_bf16(const float* proj_w, uint16_t* dst, void* stream) {
+    GENIE_CHECK_ARG(proj_w && dst, "pack_spatial_proj_fused: NULL pointer");
+    return launch_pack_spatial_proj(proj_w, dst, as_stream(stream));
+}
+int genie_spatial_attn_proj_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* qkv_planes, float* x,
+                                       uint16_t* x16, int64_t n_seq, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(aw && qkv_planes && x && x16 && n_seq >= 1, "spatial_attn_proj_fused: bad argument");
+    return launch_spatial_attn_proj_bf16(*cfg, *aw, qkv_planes, x, x16, (long)n_seq, as_stream(stream));
+}
 int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream) {
     GENIE_CHECK_ARG(fc1_w && fc2_w && dst, "pack_mlp_fused: NULL pointer");
     return launch_pack_mlp_fused(fc1_w, fc2_w, dst, as_stream(stream));

@@ -54,6 +54,9 @@ inline bool temporal_qkv16(const genie_cfg& c, int model_T) {
 // kernels_fused.hip: fused sub-blocks of the shipped geometry (GENIE_PREC_BF16, d 256); GENIE_E_UNSUPPORTED otherwise
 int launch_pack_temporal_fused(const float* qkv_w, const float* proj_w, uint16_t* out, hipStream_t st);
 int launch_pack_mlp_fused(const float* fc1_w, const float* fc2_w, uint16_t* out, hipStream_t st);
+int launch_pack_spatial_proj(const float* proj_w, uint16_t* out, hipStream_t st);
+int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* qkv16, float* x, uint16_t* x16,
+                                  long n_seq, hipStream_t st);
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
                                hipStream_t st);
 int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,

@@ -807,8 +807,11 @@ __global__ void cast16_kernel(const float* __restrict__ src, uint16_t* __restric
 // qkv round trip, no operand split / transpose inside the attention kernel.  Covers the shipped geometry (S = 256, head_dim
 // 32 / 64, d % 256 == 0, LayerNorm blocks, chip-filling batches); anything else returns GENIE_E_UNSUPPORTED and the caller
 // runs the f32-qkv path below.
+// x / x16 / proj_done (bf16 only): when given and the geometry allows, the attention AND the out-projection + residual run as
+// kernels_fused.hip's spatial_attn_proj kernel (x, x16 updated, *proj_done = true: the caller skips its proj GEMM)
 static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_layer_weights& lw, const uint16_t* u, size_t planeA,
-                                   size_t planeW, Workspace& w, int B, uint16_t* out16, size_t out_plane, hipStream_t st) {
+                                   size_t planeW, Workspace& w, int B, uint16_t* out16, size_t out_plane, hipStream_t st,
+                                   float* x = nullptr, uint16_t* x16 = nullptr, bool* proj_done = nullptr) {
     static const int on = study_env("GENIE_ATTN_DMA", 1);
     const int d = c.d_model;
 #ifdef GENIE_STUDY
@@ -824,6 +827,11 @@ static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_laye
                                     c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, nullptr, qkv16, (long)M * d, d, M, 3 * d, d,
                                     G16X_OUT16 | G16X_QKV, 1.0f, st, 1, 0, 0, 0, c.attn_scale * 1.4426950408889634f, c.head_dim);
     if (rc != GENIE_OK) return rc;
+    if (npl == 1 && x && x16 && proj_done) {   // shipped geometry, bf16: attention over all heads + out-projection + residual in one kernel
+        const int rf = launch_spatial_attn_proj_bf16(c, lw.spatial, qkv16, x, x16, n_seq, st);
+        if (rf == GENIE_OK) { *proj_done = true; return GENIE_OK; }
+        if (rf != GENIE_E_UNSUPPORTED) return rf;
+    }
     return launch_attn_spatial_dma(npl, qkv16, n_seq, d, c.num_heads, c.head_dim, out16, out_plane, st);
 }
 
@@ -848,7 +856,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     // spatial
     const uint16_t* u = x16;
     int rc = GENIE_E_UNSUPPORTED;
-    bool qkv_done = false;
+    bool qkv_done = false, proj_done = false;
     if (!c.qk_norm) {  // one-frame passes: LayerNorm inside the small GEMM's fragment path (no LayerNorm launch)
         const int r2 = launch_gemm16_sm_ln(1, x, d, lw.norm1_w, lw.norm1_b, 1e-5f, lw.spatial.qkv_w16, d, 0,
                                            c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, qkv, nullptr, 0, 3 * d, M, 3 * d, d,
@@ -862,7 +870,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
                 GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
             u = xn16;
         }
-        rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st);
+        rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st, x, x16, &proj_done);
     }
     w.ln1_done = false;
     if (rc == GENIE_E_UNSUPPORTED) {
@@ -878,6 +886,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     }
     }
     GENIE_TRY(rc);
+    if (!proj_done)
     GENIE_TRY(launch_gemm16<1>(xn16, d, 0, lw.spatial.proj_w16, d, 0, c.proj_bias ? lw.spatial.proj_b : nullptr, x, x16,
                                0, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16, 1.0f, st));
     // temporal (no pre-norm): operand = bf16 shadow of x.  t16: the temporal qkv (and the KV cache slices) hold bf16 -- the qkv

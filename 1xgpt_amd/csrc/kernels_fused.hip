@@ -731,6 +731,234 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
     return GENIE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// spatial_attn_proj_bf16_kernel:  x += proj_s( softmax(q k^T) v )  over the 256 tokens of a frame, all 8 heads (attention.py:36-61
+// with causal = False, st_transformer.py:73-74), from the operand planes [Q * scale * log2e | K | V^T] the spatial qkv GEMM writes
+// (launch_gemm16_pp with G16X_QKV; layouts in kernels_attn_dma.hip).  Replaces the attention launch + the out-projection GEMM:
+// the attention output (134 MB written + read per layer at 64 clips) never exists and the residual row is updated once.
+//   * one workgroup of 8 waves per (b, t) sequence, persistent over sequences; wave w owns queries 32 w .. 32 w + 31 of EVERY head,
+//     so a token's output row accumulates in its lane pair's registers across the heads (8 tiles of 32 columns, 128 registers).
+//   * per head: K (16 KB), V^T (16 KB) and the out-projection's 16 fragments for that head (16 KB) arrive by LDS-DMA in a
+//     double buffer together with the head's Q rows (16 KB: a wave reads its own 32 rows back as fragments; held in registers one
+//     head ahead they cost 16 registers the kernel does not have); the next head's 64 KB are requested at this head's barrier,
+//     across sequence boundaries.
+//   * with 128 registers taken by the output row there is no room for a query's 256 scores (128 registers per lane), so the
+//     softmax is ONLINE over eight tiles of 32 keys: S^T tile (2 MFMAs, lane = query, 16 scores) -> running max / sum update,
+//     O rescale -> P (bf16) is the B operand and the V^T fragment the A operand of O^T += V^T P^T (2 MFMAs, lane = query, 16
+//     features) -> after the last tile O / sum, rounded to bf16, is the B operand of the head's two out-projection K-steps.
+// Numerics = the bf16 attention contract of attn_spatial_dma_kernel (q, k, v, p, o rounded to bf16, f32 accumulation and softmax);
+// the probabilities are taken against the running maximum instead of the row maximum (same value up to the rounding of p).
+namespace {
+constexpr int SA_BUF = 4 * 16384;                 // K | V^T | Wp fragments | Q of one head
+constexpr int SA_LDS = 2 * SA_BUF + 1024;         // double buffer + out-projection bias
+}  // namespace
+
+// Wp stream of one layer (bf16, 8 heads x 16 fragments x 64 lanes x 8 values = 64 K values = 128 KB): head hd, fragment f = 8 kk + ct:
+//   [lane l][e] = Wproj[32 ct + (l & 31)][32 hd + 16 kk + (e & 3) + 8 (e >> 2) + 4 (l >> 5)]
+__global__ void pack_spatial_proj_kernel(const float* __restrict__ proj_w, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 8 * 16 * 64 * 8) return;
+    const int e = i & 7, l = (i >> 3) & 63, f = (i >> 9) & 15, hd = i >> 13;
+    const int kk = f >> 3, ct = f & 7, h = l >> 5;
+    out[i] = f32_to_bf16(proj_w[(size_t)(32 * ct + (l & 31)) * 256 + 32 * hd + 16 * kk + (e & 3) + 8 * (e >> 2) + 4 * h]);
+}
+
+int launch_pack_spatial_proj(const float* proj_w, uint16_t* out, hipStream_t st) {
+    pack_spatial_proj_kernel<<<(8 * 16 * 64 * 8) / 256, 256, 0, st>>>(proj_w, out);
+    GENIE_LAUNCH_CHECK("pack_spatial_proj");
+    return GENIE_OK;
+}
+
+__global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const uint16_t* __restrict__ qkv16, long P,
+                                                                        const uint16_t* __restrict__ wstream,
+                                                                        const float* __restrict__ proj_b, float* __restrict__ x,
+                                                                        uint16_t* __restrict__ x16, long n_seq) {
+    constexpr int D = 256, NH = 8, DH = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    float* sbias = reinterpret_cast<float*>(smem + 2 * SA_BUF);
+    if (tid < 256) sbias[tid] = proj_b ? proj_b[tid] : 0.f;
+    __syncthreads();
+
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qkv16, 0, -1, 0x00020000);
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv16 + (size_t)P), 0, -1, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv16 + (size_t)2 * P), 0, -1, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, NH * 16384, 0x00020000);
+    // per-lane source offsets of this wave's LDS-DMA pieces (two K, two V^T, two Wp per head), conventions of kernels_attn_dma.hip:
+    //   K chunk (64 keys x 64 bytes): piece = 16 rows, the 16-byte slot of a row XOR (row / 4) % 4
+    //   V^T chunk (32 features x 128 bytes = 64 keys): piece = 8 feature rows, slot XOR (feature / 2) % 8
+    unsigned voK[2], voV[2];
+    int pcK[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pc = 2 * wid + j;                  // piece 0..15 of the head's K (and of its V^T): chunk pc >> 2, part pc & 3
+        pcK[j] = pc;
+        const int pp = pc & 3;
+        {
+            const int row = pp * 16 + (lane >> 2);
+            const int slot = (lane & 3) ^ ((row >> 2) & 3);
+            voK[j] = (unsigned)((row * DH + slot * 8) * 2);
+        }
+        {
+            const int f = pp * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((f >> 1) & 7);
+            voV[j] = (unsigned)((f * 256 + slot * 8) * 2);
+        }
+    }
+    // item = (sequence, head) in the order this workgroup walks them
+    auto issue_item = [&](long seq, int hd, int buf) {
+        unsigned char* base = smem + buf * SA_BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = pcK[j] >> 2, pp = pcK[j] & 3;
+            const int soK = (int)((((seq * NH + hd) * 256 + c * 64) * (long)DH) * 2);
+            const int soV = (int)((((seq * NH + hd) * DH) * 256 + c * 64) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(base + c * 4096 + pp * 1024), 16,
+                                                     voK[j], soK, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(base + 16384 + c * 4096 + pp * 1024),
+                                                     16, voV[j], soV, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + 32768 + pcK[j] * 1024), 16,
+                                                     (unsigned)lane * 16, hd * 16384 + pcK[j] * 1024, 0, 0);
+            // Q rows 16 (2 wid + j) .. + 15 of the head (this wave's own queries), same row image as a K chunk
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(base + 49152 + pcK[j] * 1024), 16,
+                                                     voK[j], soK, 0, 0);
+        }
+    };
+    // fragment read offsets (bytes inside a chunk): K rows, V^T rows
+    unsigned offK[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) offK[kk] = r * 64 + (((2 * kk + h) ^ ((r >> 2) & 3)) << 4);
+    const unsigned offV = r * 128;
+    const int vsw = (r >> 1) & 7;
+
+    const long seq0 = blockIdx.x, step = gridDim.x;
+    if (seq0 >= n_seq) return;
+    issue_item(seq0, 0, 0);
+    int buf = 0;
+    for (long seq = seq0; seq < n_seq; seq += step) {
+        f32x16 out[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + 32 * ct + 8 * j + 4 * h);
+                out[ct][4 * j] = bv.x; out[ct][4 * j + 1] = bv.y; out[ct][4 * j + 2] = bv.z; out[ct][4 * j + 3] = bv.w;
+            }
+#pragma unroll 1
+        for (int hd = 0; hd < NH; ++hd) {
+            // this head's 48 KB have landed for every wave (and its Q fragments for this one); the other buffer is free
+            fs_wait_vm<0>();
+            fs_barrier();
+            {
+                const bool last_h = hd == NH - 1;
+                const long nseq = last_h ? seq + step : seq;
+                const int nhd = last_h ? 0 : hd + 1;
+                if (nseq < n_seq) issue_item(nseq, nhd, buf ^ 1);
+            }
+            const unsigned char* kb = smem + buf * SA_BUF;
+            s16x8 qf[2];   // B operand of S^T = K Q^T: lane = query r, 8 features 16 kk + 8 h ..
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const s16x8*>(kb + 49152 + wid * 2048 + offK[kk]);
+            const unsigned char* vb = kb + 16384;
+            const unsigned char* wb = kb + 32768 + lane * 16;
+            f32x16 o;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = 0.f;
+            float m = -1.0e30f, l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {        // 32 keys per step (chunk c = kt / 2 of the K / V^T images, tile t = kt % 2)
+                const int c = kt >> 1, t = kt & 1;
+                f32x16 sc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sc[e] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    sc = mma32x32(*reinterpret_cast<const s16x8*>(kb + c * 4096 + t * 2048 + offK[kk]), qf[kk], sc);
+                float mc = sc[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mc = fmaxf(mc, sc[e]);
+                mc = fmaxf(mc, __shfl_xor(mc, 32));
+                const float mn = fmaxf(m, mc);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                float ls = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sc[e] = __builtin_amdgcn_exp2f(sc[e] - mn);
+                    ls += sc[e];
+                }
+                l = l * alpha + ls;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] *= alpha;
+                // O^T += V^T P^T: MFMA mm takes the lane's scores 8 mm .. 8 mm + 7 of the tile (keys 16 mm + (s & 3) + 8 (s >> 2) + 4 h:
+                // the order the V^T planes store every 16-key group in)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const s16x8 pa = pack8(f32x4{sc[8 * mm], sc[8 * mm + 1], sc[8 * mm + 2], sc[8 * mm + 3]},
+                                           f32x4{sc[8 * mm + 4], sc[8 * mm + 5], sc[8 * mm + 6], sc[8 * mm + 7]});
+                    const s16x8 vf = *reinterpret_cast<const s16x8*>(vb + c * 4096 + offV + (((t * 4 + 2 * mm + h) ^ vsw) << 4));
+                    o = mma32x32(vf, pa, o);
+                }
+            }
+            l += __shfl_xor(l, 32);
+            const float inv = __builtin_amdgcn_rcpf(l);
+            const s16x8 ob0 = pack8(f32x4{o[0], o[1], o[2], o[3]} * inv, f32x4{o[4], o[5], o[6], o[7]} * inv);
+            const s16x8 ob1 = pack8(f32x4{o[8], o[9], o[10], o[11]} * inv, f32x4{o[12], o[13], o[14], o[15]} * inv);
+#pragma unroll
+            for (int f = 0; f < 16; ++f)
+                out[f & 7] = mma32x32(*reinterpret_cast<const s16x8*>(wb + f * 1024), (f >> 3) ? ob1 : ob0, out[f & 7]);
+            buf ^= 1;
+        }
+        // ---- residual update in place + the bf16 shadow of the updated row (the temporal sub-block's operand)
+        float* xrow = x + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
+        uint16_t* x16row = x16 + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
+        f32x4 res[2][8];
+        auto load_round = [&](int k, f32x4* dst) {   // round k = column tiles 2k, 2k + 1
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3));
+        };
+        load_round(0, res[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k + 1 < 4) load_round(k + 1, res[(k + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x16& oo = out[2 * k + (q >> 2)];
+                const int j = q & 3;
+                res[k & 1][q] += f32x4{oo[4 * j], oo[4 * j + 1], oo[4 * j + 2], oo[4 * j + 3]};
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                *reinterpret_cast<f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = res[k & 1][q];
+                *reinterpret_cast<s16x4*>(x16row + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = pack4(res[k & 1][q]);
+            }
+        }
+    }
+    fs_wait_vm<0>();
+}
+
+// x += proj_s(attention_S(planes)) and x16 = bf16(x) for n_seq sequences of 256 tokens; GENIE_E_UNSUPPORTED outside d 256 / 8 x 32
+int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* qkv16, float* x, uint16_t* x16,
+                                  long n_seq, hipStream_t st) {
+    if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.S != 256 || c.qk_norm || n_seq < 256)
+        return GENIE_E_UNSUPPORTED;
+    const long P = n_seq * 256 * 256;
+    if ((double)P * 2 + 4096.0 * 256 >= 2.0e9) return GENIE_E_UNSUPPORTED;   // 32-bit scalar offsets inside the plane descriptors
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)(n_seq < cus ? n_seq : cus);
+    const double M = (double)n_seq * 256;
+    ProfScope prof(GENIE_KC_FUSED, M * (4.0 * 256 * 256 + 2.0 * 256 * 256), M * (3 * 512.0 + 2048.0 + 512.0), st,
+                   "spatial_attn_proj_bf16_kernel (attention over S, all heads + proj + residual)");
+    (void)hipFuncSetAttribute((const void*)spatial_attn_proj_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS);
+    spatial_attn_proj_bf16_kernel<<<grid, 512, SA_LDS, st>>>(qkv16, P, aw.fused_w16, c.proj_bias ? aw.proj_b : nullptr, x, x16, n_seq);
+    GENIE_LAUNCH_CHECK("spatial_attn_proj_bf16");
+    return GENIE_OK;
+}
+
 // x += proj_t(attention_T(qkv_t(x16))) on dense (B, 16, S, 256) buffers; GENIE_E_UNSUPPORTED for any other geometry
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
                                hipStream_t st) {

@@ -95,6 +95,15 @@ class _Packer:
         self.keep.append(t)
         return t.data_ptr()
 
+    def spatial_fused(self, attn):
+        if not (self._fused_geometry() and self.config.S == 256):
+            return 0
+        t = torch.empty(_lib.SPATIAL_PROJ_FUSED_ELEMS, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.genie_pack_spatial_proj_fused_bf16(attn.proj.weight.data_ptr(), t.data_ptr(), self._stream()),
+                   "genie_pack_spatial_proj_fused_bf16")
+        self.keep.append(t)
+        return t.data_ptr()
+
     def mlp_fused(self, mlp):
         if not (self._fused_geometry() and mlp.fc1.weight.shape[0] == 1024):
             return 0

@@ -37,8 +37,7 @@ def _attn_struct(a: SelfAttention, packed=None, temporal=False) -> _lib.AttnWeig
     if packed is not None:
         s.qkv_w16, s.proj_w16 = packed(a.qkv.weight), packed(a.proj.weight)
         s.w16_wide = (_lib.WIDE_QKV if packed.is_wide(s.qkv_w16) else 0) | (_lib.WIDE_PROJ if packed.is_wide(s.proj_w16) else 0)
-        if temporal:
-            s.fused_w16 = packed.temporal_fused(a)
+        s.fused_w16 = packed.temporal_fused(a) if temporal else packed.spatial_fused(a)
     return s
 
 

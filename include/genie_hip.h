@@ -72,8 +72,10 @@ typedef struct genie_attn_weights {
     const float* norm_b;
     const uint16_t* qkv_w16;
     const uint16_t* proj_w16;
-    /* GENIE_PREC_BF16, temporal attention of the shipped geometry (d 256, 8 heads of 32, T 16): the qkv and proj weights as the
-     * fragment stream of the fused qkv + attention + proj kernel (genie_pack_temporal_fused_bf16), or NULL (unfused launches). */
+    /* GENIE_PREC_BF16, shipped geometry (d 256, 8 heads of 32), or NULL (unfused launches): in the TEMPORAL attention's struct
+     * (T 16) the qkv and proj weights as the fragment stream of the fused qkv + attention + proj kernel
+     * (genie_pack_temporal_fused_bf16); in the SPATIAL attention's struct (S 256) the proj weights as the fragment stream of
+     * the fused attention + proj kernel (genie_pack_spatial_proj_fused_bf16). */
     const uint16_t* fused_w16;
     /* GENIE_PREC_F16X3 range flags of the packed tensors (bit 0: qkv_w16, bit 1: proj_w16): set when the tensor's hi plane
      * reaches |w| >= 32, see "range contract" below.  0 in the other precisions. */
@@ -142,18 +144,26 @@ enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_F
  * f32 -> 524,288 bf16 values.  Reference counterpart: the nn.Linear weights of attention.py:27-29 / st_transformer.py:16-25. */
 #define GENIE_TEMPORAL_FUSED_ELEMS 262144
 #define GENIE_MLP_FUSED_ELEMS 524288
+#define GENIE_SPATIAL_PROJ_FUSED_ELEMS 65536 /* spatial: proj_w (256, 256) f32 -> the out-projection's fragments per head */
 int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream);
 /* Unit entry points of the fused sub-blocks (parity tests, tuning).  Both update the f32 residual stream x in place and return
  * GENIE_E_UNSUPPORTED outside the geometry above (the layer drivers then run the unfused launches).
  *   temporal: x (B,16,S,256) += proj(causal_attention_T(qkv(x16))), x16 = bf16 copy of x (B,16,S,256); needs aw->fused_w16.
  *             Reference: st_transformer.py:77-78 (the permute to (B S) T C is never materialised), attention.py:36-61.
+ *   spatial:  x (n_seq*256, 256) += proj(softmax(q k^T) v) from the operand planes [Q scale log2e | K | V^T] of the spatial qkv GEMM
+ *             (n_seq sequences of 256 tokens, 8 heads of 32), x16 = bf16 copy of the result; needs aw->fused_w16.
+ *             Reference: st_transformer.py:73-74, attention.py:48-60.  (The planes are an internal format of the block driver:
+ *             this entry exists for tuning -- tools/bench_fused.py -- the parity tests go through the block.)
  *   mlp:      x (rows,256) += fc2(gelu(fc1(LayerNorm(x; norm2)))), rows % 128 == 0; x16_out (or NULL) receives the bf16 copy
  *             of the result, or -- when next_norm_w / next_norm_b are given -- LayerNorm(result; next_norm_*) in bf16 (the next
  *             block's norm1 output, st_transformer.py:73); needs lw->mlp_fused_w16.  Reference: st_transformer.py:81, 16-25. */
 int genie_temporal_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* x16, float* x, int B, void* stream);
+int genie_spatial_attn_proj_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* qkv_planes, float* x,
+                                       uint16_t* x16, int64_t n_seq, void* stream);
 int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, float* x, uint16_t* x16_out, int64_t rows,
                          const float* next_norm_w, const float* next_norm_b, void* stream);
 int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream);
+int genie_pack_spatial_proj_fused_bf16(const float* proj_w, uint16_t* dst, void* stream);
 
 /* ---- unit entry points (one reference op each; used by the parity tests) -------------------------- */
 
