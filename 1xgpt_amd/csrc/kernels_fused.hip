@@ -748,7 +748,26 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
 //     features) -> after the last tile O / sum, rounded to bf16, is the B operand of the head's two out-projection K-steps.
 // Numerics = the bf16 attention contract of attn_spatial_dma_kernel (q, k, v, p, o rounded to bf16, f32 accumulation and softmax);
 // the probabilities are taken against the running maximum instead of the row maximum (same value up to the rounding of p).
+#ifndef GENIE_VAR_S_ABL
+#define GENIE_VAR_S_ABL 0   // variant builds only (results wrong): 1 no LDS-DMA after the first item, 2 no residual epilogue,
+#endif                      // 4 no matrix instructions, 8 no exponentials, 16 no LDS fragment reads
 namespace {
+__device__ __forceinline__ f32x16 sa_mma(const s16x8& a, const s16x8& b, const f32x16& c) {
+    if constexpr (GENIE_VAR_S_ABL & 4) {
+        f32x16 r_ = c;
+        asm volatile("" : "+v"(r_) : "v"(a), "v"(b));
+        return r_;
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float sa_exp2(float v) {
+    if constexpr (GENIE_VAR_S_ABL & 8) return v * 0.001f;
+    return __builtin_amdgcn_exp2f(v);
+}
+__device__ __forceinline__ s16x8 sa_frag(const unsigned char* p, int lane) {
+    if constexpr (GENIE_VAR_S_ABL & 16) { const short v = (short)lane; return s16x8{v, v, v, v, v, v, v, v}; }
+    return *reinterpret_cast<const s16x8*>(p);
+}
 constexpr int SA_BUF = 4 * 16384;                 // K | V^T | Wp fragments | Q of one head
 constexpr int SA_LDS = 2 * SA_BUF + 1024;         // double buffer + out-projection bias
 }  // namespace
@@ -772,7 +791,7 @@ int launch_pack_spatial_proj(const float* proj_w, uint16_t* out, hipStream_t st)
 __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const uint16_t* __restrict__ qkv16, long P,
                                                                         const uint16_t* __restrict__ wstream,
                                                                         const float* __restrict__ proj_b, float* __restrict__ x,
-                                                                        uint16_t* __restrict__ x16, long n_seq) {
+                                                                        uint16_t* __restrict__ x16, long n_seq, int stagger) {
     constexpr int D = 256, NH = 8, DH = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -835,27 +854,44 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
 
     const long seq0 = blockIdx.x, step = gridDim.x;
     if (seq0 >= n_seq) return;
+    // Staggered start: every workgroup does identical work, so the chip would run in lockstep -- all CUs in their attention phases
+    // with HBM idle, then all 256 bursts of 640 KB (residual rows in, updated rows and their shadow out) at once, which must drain
+    // before anyone passes the next head's wait (measured: the kernel's time was compute + bytes / HBM bandwidth).  Workgroup b
+    // waits (b mod 8) x stagger ticks of 10 ns before its first sequence, which spreads the bursts over the sequence period for good.
+    if (stagger > 0) {
+        const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * (unsigned long long)stagger;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     issue_item(seq0, 0, 0);
     int buf = 0;
     for (long seq = seq0; seq < n_seq; seq += step) {
+        // The output row STARTS as the residual row: out = x (+ bias), the heads' projections accumulate on top, and the epilogue only
+        // stores.  The 32 row pieces are requested here -- right behind the previous sequence's stores -- and are first needed by
+        // the out-projection at the END of head 0, a whole attention later: the residual read (268 MB per layer at 64 clips) costs
+        // no time of its own, where an epilogue that reads, adds and stores cost 140 us of 344 (every workgroup of the chip in its
+        // epilogue at once, HBM-bound, all matrix pipes idle).
+        float* xrow = x + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
         f32x16 out[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + 32 * ct + 8 * j + 4 * h);
-                out[ct][4 * j] = bv.x; out[ct][4 * j + 1] = bv.y; out[ct][4 * j + 2] = bv.z; out[ct][4 * j + 3] = bv.w;
+                const f32x4 xv = (GENIE_VAR_S_ABL & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(xrow + 32 * ct + 8 * j);
+                out[ct][4 * j] = xv.x; out[ct][4 * j + 1] = xv.y; out[ct][4 * j + 2] = xv.z; out[ct][4 * j + 3] = xv.w;
             }
 #pragma unroll 1
         for (int hd = 0; hd < NH; ++hd) {
-            // this head's 48 KB have landed for every wave (and its Q fragments for this one); the other buffer is free
-            fs_wait_vm<0>();
+            // this head's 64 KB have landed for every wave; the other buffer is free.  Head 0 of every sequence but the first: the
+            // 64 stores of the previous sequence's epilogue are YOUNGER than this head's 8 LDS-DMA pieces (requested at that
+            // sequence's last barrier) and may stay in flight -- vmcnt retires in order, so 63 outstanding means the pieces are in.
+            if (hd == 0 && seq != seq0) fs_wait_vm<63>(); else fs_wait_vm<0>();
             fs_barrier();
             {
                 const bool last_h = hd == NH - 1;
                 const long nseq = last_h ? seq + step : seq;
                 const int nhd = last_h ? 0 : hd + 1;
-                if (nseq < n_seq) issue_item(nseq, nhd, buf ^ 1);
+                if (nseq < n_seq && !(GENIE_VAR_S_ABL & 1)) issue_item(nseq, nhd, buf ^ 1);
             }
             const unsigned char* kb = smem + buf * SA_BUF;
             s16x8 qf[2];   // B operand of S^T = K Q^T: lane = query r, 8 features 16 kk + 8 h ..
@@ -875,18 +911,18 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
                 for (int e = 0; e < 16; ++e) sc[e] = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    sc = mma32x32(*reinterpret_cast<const s16x8*>(kb + c * 4096 + t * 2048 + offK[kk]), qf[kk], sc);
+                    sc = sa_mma(sa_frag(kb + c * 4096 + t * 2048 + offK[kk], lane), qf[kk], sc);
                 float mc = sc[0];
 #pragma unroll
                 for (int e = 1; e < 16; ++e) mc = fmaxf(mc, sc[e]);
                 mc = fmaxf(mc, __shfl_xor(mc, 32));
                 const float mn = fmaxf(m, mc);
-                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                const float alpha = sa_exp2(m - mn);
                 m = mn;
                 float ls = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    sc[e] = __builtin_amdgcn_exp2f(sc[e] - mn);
+                    sc[e] = sa_exp2(sc[e] - mn);
                     ls += sc[e];
                 }
                 l = l * alpha + ls;
@@ -898,8 +934,8 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
                 for (int mm = 0; mm < 2; ++mm) {
                     const s16x8 pa = pack8(f32x4{sc[8 * mm], sc[8 * mm + 1], sc[8 * mm + 2], sc[8 * mm + 3]},
                                            f32x4{sc[8 * mm + 4], sc[8 * mm + 5], sc[8 * mm + 6], sc[8 * mm + 7]});
-                    const s16x8 vf = *reinterpret_cast<const s16x8*>(vb + c * 4096 + offV + (((t * 4 + 2 * mm + h) ^ vsw) << 4));
-                    o = mma32x32(vf, pa, o);
+                    const s16x8 vf = sa_frag(vb + c * 4096 + offV + (((t * 4 + 2 * mm + h) ^ vsw) << 4), lane);
+                    o = sa_mma(vf, pa, o);
                 }
             }
             l += __shfl_xor(l, 32);
@@ -908,31 +944,41 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
             const s16x8 ob1 = pack8(f32x4{o[8], o[9], o[10], o[11]} * inv, f32x4{o[12], o[13], o[14], o[15]} * inv);
 #pragma unroll
             for (int f = 0; f < 16; ++f)
-                out[f & 7] = mma32x32(*reinterpret_cast<const s16x8*>(wb + f * 1024), (f >> 3) ? ob1 : ob0, out[f & 7]);
+                out[f & 7] = sa_mma(sa_frag(wb + f * 1024, lane), (f >> 3) ? ob1 : ob0, out[f & 7]);
             buf ^= 1;
         }
-        // ---- residual update in place + the bf16 shadow of the updated row (the temporal sub-block's operand)
-        float* xrow = x + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
-        uint16_t* x16row = x16 + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
-        f32x4 res[2][8];
-        auto load_round = [&](int k, f32x4* dst) {   // round k = column tiles 2k, 2k + 1
+        // ---- epilogue: x = out + bias (the row already holds x + all heads' projections) and its bf16 shadow (the temporal
+        // sub-block's operand).  A lane owns a TOKEN, so a store straight from the accumulators writes 32-byte pieces of 32 different
+        // rows -- measured: those requests, not their bytes, were most of the epilogue's cost (the same bytes as lane-linear stores:
+        // -40 us of 350).  So each 32-column tile goes through a wave-private 4.5 KB LDS tile (rows padded to 144 bytes) and leaves as
+        // whole 128-byte lines: 8 rows per store instruction.  The tile lives in the buffer of the head just finished (one extra
+        // barrier per sequence makes sure every wave is done reading it).
+        if constexpr (GENIE_VAR_S_ABL & 2) { asm volatile("" :: "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7])); continue; }
+        fs_barrier();
+        {
+            float* tile = reinterpret_cast<float*>(smem + (buf ^ 1) * SA_BUF + wid * 8192);   // (buf was toggled after the last head)
+            float* xw = x + ((size_t)seq * 256 + wid * 32) * D;
+            uint16_t* xw16 = x16 + ((size_t)seq * 256 + wid * 32) * D;
+            const int rr = lane >> 3, cc = (lane & 7) * 4;        // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3));
-        };
-        load_round(0, res[0]);
+            for (int ct = 0; ct < 8; ++ct) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k + 1 < 4) load_round(k + 1, res[(k + 1) & 1]);
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(tile + r * 36 + 8 * j + 4 * h) =
+                        f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]} +
+                        *reinterpret_cast<const f32x4*>(sbias + 32 * ct + 8 * j + 4 * h);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x16& oo = out[2 * k + (q >> 2)];
-                const int j = q & 3;
-                res[k & 1][q] += f32x4{oo[4 * j], oo[4 * j + 1], oo[4 * j + 2], oo[4 * j + 3]};
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                *reinterpret_cast<f32x4*>(xrow + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = res[k & 1][q];
-                *reinterpret_cast<s16x4*>(x16row + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = pack4(res[k & 1][q]);
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc);
+                    *reinterpret_cast<f32x4*>(xw + (size_t)(rr + 8 * i2) * D + 32 * ct + cc) = v;
+                    *reinterpret_cast<s16x4*>(xw16 + (size_t)(rr + 8 * i2) * D + 32 * ct + cc) = pack4(v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
     }
@@ -954,7 +1000,12 @@ int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& 
     ProfScope prof(GENIE_KC_FUSED, M * (4.0 * 256 * 256 + 2.0 * 256 * 256), M * (3 * 512.0 + 2048.0 + 512.0), st,
                    "spatial_attn_proj_bf16_kernel (attention over S, all heads + proj + residual)");
     (void)hipFuncSetAttribute((const void*)spatial_attn_proj_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS);
-    spatial_attn_proj_bf16_kernel<<<grid, 512, SA_LDS, st>>>(qkv16, P, aw.fused_w16, c.proj_bias ? aw.proj_b : nullptr, x, x16, n_seq);
+#ifndef GENIE_VAR_S_STAGGER
+#define GENIE_VAR_S_STAGGER 0     // (measured: 3-15 us per class only adds the delay -- profiles/r04_fused_experiments.txt)
+#endif
+    const int stagger = n_seq >= 2 * (long)grid ? study_env("GENIE_FUSED_STAGGER_S", GENIE_VAR_S_STAGGER) : 0;
+    spatial_attn_proj_bf16_kernel<<<grid, 512, SA_LDS, st>>>(qkv16, P, aw.fused_w16, c.proj_bias ? aw.proj_b : nullptr, x, x16, n_seq,
+                                                             stagger);
     GENIE_LAUNCH_CHECK("spatial_attn_proj_bf16");
     return GENIE_OK;
 }
