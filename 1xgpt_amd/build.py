@@ -67,6 +67,6 @@ def build_variant(name, defines, verbose=False):
 if __name__ == "__main__":
     if "--variant" in sys.argv:   # python 1xgpt_amd/build.py --variant <name> [-DX ...]
         i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")], verbose=True))
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith(("-D", "-f", "-m"))], verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

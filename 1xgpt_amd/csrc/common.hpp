@@ -101,6 +101,29 @@ __device__ __forceinline__ genie_f2 gelu_erf_fast2(genie_f2 z) {
     return zp - w;
 }
 
+// Two GELUs for a consumer that rounds them to bf16 at once (the fused MLP kernel's hidden): no transcendental, packed f32.
+//   gelu(z) = z * Phi(z),  Phi(z) - 1/2 = zc * P(zc^2),  zc = clamp(z, -4.25, 4.25),  P of degree 8 (weighted minimax fit of
+//   (Phi(z) - 1/2) / z on [0, 4.25], tools/fit_gelu_poly.py, tests/test_gelu_poly.py):  |Phi error| <= 1.3e-5 for every z (0 < Phi < 1
+//   also beyond the clamp), |gelu error| <= 5.3e-5 absolute; relative 1.4e-5 for z > 0.25 -- 0.7 % of a bf16 half-ulp, fewer than 1
+//   value in 100 rounds to the neighbouring bf16; on the negative side (|gelu| <= 0.17) the absolute bound holds but the relative
+//   one does not (Phi itself is small there): ~7 % of those values land on a neighbouring bf16, 1-2 ulp at z < -3.
+//   13 instructions per PAIR (2 v_med3, v_pk_mul, 9 v_pk_fma, v_pk_mul) against 2 x 15 with two quarter-rate ones for
+//   gelu_erf_fast.  NOT for the parity-grade modes (their GELU stays at 1.5e-7).
+__device__ __forceinline__ genie_f2 gelu_erf_poly2(genie_f2 z) {
+    auto splat = [](float c) { return genie_f2{c, c}; };
+    const genie_f2 zc = {__builtin_amdgcn_fmed3f(z[0], -4.25f, 4.25f), __builtin_amdgcn_fmed3f(z[1], -4.25f, 4.25f)};
+    const genie_f2 s = zc * zc;
+    genie_f2 p = __builtin_elementwise_fma(s, splat(5.564818051e-11f), splat(-5.327728037e-09f));
+    p = __builtin_elementwise_fma(p, s, splat(2.255418963e-07f));
+    p = __builtin_elementwise_fma(p, s, splat(-5.626413895e-06f));
+    p = __builtin_elementwise_fma(p, s, splat(9.341857367e-05f));
+    p = __builtin_elementwise_fma(p, s, splat(-1.108560245e-03f));
+    p = __builtin_elementwise_fma(p, s, splat(9.815969504e-03f));
+    p = __builtin_elementwise_fma(p, s, splat(-6.634449214e-02f));
+    p = __builtin_elementwise_fma(p, s, splat(3.989023268e-01f));
+    return z * __builtin_elementwise_fma(zc, p, splat(0.5f));
+}
+
 // round-to-nearest-even f32 -> bf16 bits: v_cvt_pk_bf16_f32 (gfx950), one instruction instead of the five of the integer
 // emulation  u += 0x7FFF + ((u >> 16) & 1); u >>= 16  -- the same rounding for every finite value
 typedef __bf16 genie_bf2 __attribute__((ext_vector_type(2)));

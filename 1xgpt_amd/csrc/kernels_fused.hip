@@ -109,9 +109,28 @@ __device__ __forceinline__ void fs_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+#ifndef GENIE_VAR_M_PF
+#define GENIE_VAR_M_PF 2   // fragment prefetch depth of the mlp kernel's region loop (0: compiler-scheduled reads; 3 = 256 registers)
+#endif
 template <int N>
 __device__ __forceinline__ void fs_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// Fragment reads the compiler does not get to schedule: at ~250 registers it keeps ONE fragment buffer per loop and emits
+// ds_read -> s_waitcnt lgkmcnt(0) -> MFMA, so every matrix instruction waits out a full LDS round trip.  fs_lds_rd issues a read
+// the compiler knows nothing about, fs_lds_wait<N> is "all but my N youngest LDS reads have landed" tied to the fragment it guards
+// (the "+v" makes the MFMA that consumes the fragment depend on the wait).  LDS reads return in order and the compiler's own waits
+// can only over-wait; no scalar memory loads may be outstanding in such a section (they share lgkmcnt and return out of order).
+template <int OFF>
+__device__ __forceinline__ void fs_lds_rd(s16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void fs_lds_wait(s16x8& frag) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+}
+__device__ __forceinline__ unsigned fs_lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 #ifndef GENIE_VAR_T_ABL
 #define GENIE_VAR_T_ABL 0   // variant builds only (results wrong): 4 no matrix instructions, 8 no fragment reads, 16 no barriers
@@ -589,7 +608,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         auto gelu_pack = [&](const f32x16& a, s16x8& h0, s16x8& h1) {
             float gz[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) gz[i] = FS_ABL(4) ? a[i] : gelu_erf_fast(a[i]);
+            for (int i = 0; i < 16; i += 2) {
+#ifdef GENIE_VAR_M_GELU_AS   // (variant: the 1.5e-7 GELU of the GEMM epilogues)
+                gz[i] = FS_ABL(4) ? a[i] : gelu_erf_fast(a[i]); gz[i + 1] = FS_ABL(4) ? a[i + 1] : gelu_erf_fast(a[i + 1]);
+#else
+                const genie_f2 g2 = FS_ABL(4) ? genie_f2{a[i], a[i + 1]} : gelu_erf_poly2(genie_f2{a[i], a[i + 1]});
+                gz[i] = g2[0]; gz[i + 1] = g2[1];
+#endif
+            }
             h0 = pack8(f32x4{gz[0], gz[1], gz[2], gz[3]}, f32x4{gz[4], gz[5], gz[6], gz[7]});
             h1 = pack8(f32x4{gz[8], gz[9], gz[10], gz[11]}, f32x4{gz[12], gz[13], gz[14], gz[15]});
         };
@@ -616,11 +642,37 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
             FS_CYC(1);
             const unsigned char* sa = lbase + (j & 1) * 2 * FS_STAGE;
             acc1 = bias1(j);
+#if GENIE_VAR_M_PF > 0
+            {   // the region's 32 fragments [A_0 B_0 A_1 B_1 ...] through GENIE_VAR_M_PF rotating buffers
+                constexpr int PF = GENIE_VAR_M_PF;
+                const unsigned la = fs_lds_addr(sa);
+                s16x8 fb[PF];
+#define ML_OFF(n) ((((n) & 1) ? FS_STAGE : 0) + ((n) >> 1) * 1024)
+#define ML_STEP(n)                                                                                                       \
+    {                                                                                                                    \
+        fs_lds_wait<((31 - (n)) < (PF - 1) ? (31 - (n)) : (PF - 1))>(fb[(n) % PF]);                                       \
+        if constexpr (((n) & 1) != 0) out[((n) >> 1) & 7] = mma32x32(fb[(n) % PF], ((n) >> 4) ? hk1 : hk0, out[((n) >> 1) & 7]); \
+        else acc1 = mma32x32(fb[(n) % PF], xf[(n) >> 1], acc1);                                                         \
+        if constexpr ((n) + PF < 32) fs_lds_rd<ML_OFF(((n) + PF) & 31)>(fb[(n) % PF], la);                              \
+    }
+                fs_lds_rd<ML_OFF(0)>(fb[0], la);
+                if constexpr (PF > 1) fs_lds_rd<ML_OFF(1)>(fb[1 % PF], la);
+                if constexpr (PF > 2) fs_lds_rd<ML_OFF(2)>(fb[2 % PF], la);
+                if constexpr (PF > 3) fs_lds_rd<ML_OFF(3)>(fb[3 % PF], la);
+                ML_STEP(0) ML_STEP(1) ML_STEP(2) ML_STEP(3) ML_STEP(4) ML_STEP(5) ML_STEP(6) ML_STEP(7)
+                ML_STEP(8) ML_STEP(9) ML_STEP(10) ML_STEP(11) ML_STEP(12) ML_STEP(13) ML_STEP(14) ML_STEP(15)
+                ML_STEP(16) ML_STEP(17) ML_STEP(18) ML_STEP(19) ML_STEP(20) ML_STEP(21) ML_STEP(22) ML_STEP(23)
+                ML_STEP(24) ML_STEP(25) ML_STEP(26) ML_STEP(27) ML_STEP(28) ML_STEP(29) ML_STEP(30) ML_STEP(31)
+#undef ML_STEP
+#undef ML_OFF
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 acc1 = mma32x32(frag(sa, i), xf[i], acc1);
                 out[i & 7] = mma32x32(frag(sa + FS_STAGE, i), (i >> 3) ? hk1 : hk0, out[i & 7]);
             }
+#endif
             FS_CYC(2);
             gelu_pack(acc1, hk0, hk1);
             FS_CYC(3);
