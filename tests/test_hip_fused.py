@@ -71,3 +71,85 @@ def test_fused_blocks_match_unfused_and_oracle(monkeypatch, qkv_bias):
     dl = np.abs(lf - lu)
     print("fused vs unfused logits: max", dl.max(), "median", np.median(dl))
     assert np.median(dl) < 4e-3 and dl.max() < 8e-2
+
+
+# ---- the unit entry points of the C ABI (include/genie_hip.h: genie_temporal_fused_bf16, genie_mlp_fused_bf16) against the oracle's
+# sub-block functions on the same random operands
+def _bf16_bits_to_f32(t):
+    return (t.view(torch.int16).cpu().numpy().astype(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def _unit_setup():
+    _lib = pkg("_lib")
+    cfgmod = pkg("config")
+    c = cfgmod.c35()
+    return _lib, _lib.load(), c, _lib.make_cfg(c, _lib.PREC_BF16), torch.cuda.current_stream().cuda_stream
+
+
+def test_temporal_fused_entry_point_vs_oracle():
+    """x += proj(causal_attention_T(qkv(x)))  (st_transformer.py:77-78, attention.py:36-61), 8 clips = the kernel's minimum."""
+    _lib, lib, c, cfg, st = _unit_setup()
+    g = np.random.default_rng(11)
+    B, T, S, D = 8, 16, 256, 256
+    x = (g.standard_normal((B, T, S, D)) * 1.5).astype(np.float32)
+    sd = {"p.qkv.weight": (g.standard_normal((768, 256)) * 0.06).astype(np.float32),
+          "p.proj.weight": (g.standard_normal((256, 256)) * 0.06).astype(np.float32),
+          "p.proj.bias": (g.standard_normal(256) * 0.05).astype(np.float32)}
+    xd = dev(x)
+    x16 = xd.to(torch.bfloat16)
+    qw, pw, pb = dev(sd["p.qkv.weight"]), dev(sd["p.proj.weight"]), dev(sd["p.proj.bias"])
+    tf = torch.empty(_lib.TEMPORAL_FUSED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_pack_temporal_fused_bf16(qw.data_ptr(), pw.data_ptr(), tf.data_ptr(), st), "pack")
+    aw = _lib.AttnWeights()
+    aw.fused_w16, aw.proj_b = tf.data_ptr(), pb.data_ptr()
+    _lib.check(lib.genie_temporal_fused_bf16(cfg, aw, x16.data_ptr(), xd.data_ptr(), B, st), "temporal")
+    got = xd.cpu().numpy()
+    x_tc = x.transpose(0, 2, 1, 3).reshape(B * S, T, D)
+    ref = x_tc + O.self_attention(x_tc, sd, "p.", c, True, O.BF16_MFMA, chunk=4096)
+    ref = ref.reshape(B, S, T, D).transpose(0, 2, 1, 3)
+    upd = np.abs(ref - x).max()                       # size of the update itself
+    d = np.abs(got - ref)
+    print("temporal unit: update", upd, "max err", d.max(), "median", np.median(d))
+    assert np.isfinite(got).all() and d.max() < 2e-2 * upd and np.median(d) < 1e-3 * upd
+    # fewer clips than the kernel takes: the entry point must say so, not compute garbage
+    assert lib.genie_temporal_fused_bf16(cfg, aw, x16.data_ptr(), xd.data_ptr(), 2, st) != 0
+
+
+@pytest.mark.parametrize("lnout", [False, True])
+def test_mlp_fused_entry_point_vs_oracle(lnout):
+    """x += fc2(gelu(fc1(LayerNorm(x))))  (st_transformer.py:81, 16-25) and its bf16 output: the copy of x, or the next block's norm1(x)."""
+    _lib, lib, c, cfg, st = _unit_setup()
+    g = np.random.default_rng(12)
+    rows = 32768
+    x = (g.standard_normal((rows, 256)) * 2.0 + g.standard_normal((rows, 1))).astype(np.float32)
+    sd = {"p.fc1.weight": (g.standard_normal((1024, 256)) * 0.06).astype(np.float32), "p.fc1.bias": (g.standard_normal(1024) * 0.1).astype(np.float32),
+          "p.fc2.weight": (g.standard_normal((256, 1024)) * 0.04).astype(np.float32), "p.fc2.bias": (g.standard_normal(256) * 0.1).astype(np.float32)}
+    ln_g, ln_b = (1 + 0.2 * g.standard_normal(256)).astype(np.float32), (0.1 * g.standard_normal(256)).astype(np.float32)
+    nx_g, nx_b = (1 + 0.2 * g.standard_normal(256)).astype(np.float32), (0.1 * g.standard_normal(256)).astype(np.float32)
+    t = {k: dev(v) for k, v in sd.items()}
+    lg, lb, ng, nb = dev(ln_g), dev(ln_b), dev(nx_g), dev(nx_b)
+    mf = torch.empty(_lib.MLP_FUSED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_pack_mlp_fused_bf16(t["p.fc1.weight"].data_ptr(), t["p.fc2.weight"].data_ptr(), mf.data_ptr(), st), "pack")
+    lw = _lib.LayerWeights()
+    lw.mlp_fused_w16 = mf.data_ptr()
+    lw.norm2_w, lw.norm2_b, lw.fc1_b, lw.fc2_b = lg.data_ptr(), lb.data_ptr(), t["p.fc1.bias"].data_ptr(), t["p.fc2.bias"].data_ptr()
+    xd = dev(x)
+    x16 = torch.zeros(rows, 256, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_mlp_fused_bf16(cfg, lw, xd.data_ptr(), x16.data_ptr(), rows, ng.data_ptr() if lnout else 0,
+                                        nb.data_ptr() if lnout else 0, st), "mlp")
+    got, got16 = xd.cpu().numpy(), _bf16_bits_to_f32(x16)
+    ref = x + O.mlp(O.layer_norm(x, ln_g, ln_b), sd, "p.", c, O.BF16_MFMA)
+    upd = np.abs(ref - x).max()
+    d = np.abs(got - ref)
+    print("mlp unit: update", upd, "max err", d.max(), "median", np.median(d))
+    assert np.isfinite(got).all() and d.max() < 2e-2 * upd and np.median(d) < 1e-3 * upd
+    # the 16-bit output is a function of the kernel's OWN f32 result: exact bf16 rounding of it (copy), or of its LayerNorm
+    want16 = O.round_bf16(O.layer_norm(got, nx_g, nx_b) if lnout else got)
+    d16 = np.abs(got16 - want16)
+    ulp = np.maximum(np.abs(want16), 2.0 ** -126) * 2.0 ** -7
+    if lnout:
+        # statistics summed in another order: rare one-ulp differences (plus f32 cancellation noise where the normalised value is ~0)
+        assert (d16 <= ulp + 4e-6).all() and np.mean(d16 > 0) < 0.02
+    else:
+        assert (d16 == 0).all()
+    assert lib.genie_mlp_fused_bf16(cfg, lw, xd.data_ptr(), 0, 100, 0, 0, st) != 0     # rows % 128 != 0: refused

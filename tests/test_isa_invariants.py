@@ -76,3 +76,8 @@ def test_fused_subblock_kernels_have_no_scratch(rows):
         for name, r in pick(rows, sub).items():
             assert r[6] == 0, f"{name}: {r[6]} bytes of scratch per lane"
             assert r[7] <= 256 and r[5] >= 64, (name, r)
+    # the spatial kernel holds 8 dwords of loop-invariant addresses in scratch OUTSIDE its head loop (reloaded once per sequence);
+    # more than that means the head loop itself started to spill
+    for name, r in pick(rows, "spatial_attn_proj_bf16_kernel").items():
+        assert r[6] <= 64, f"{name}: {r[6]} bytes of scratch per lane"
+        assert r[7] <= 256 and r[5] >= 48, (name, r)
