@@ -85,6 +85,18 @@ __device__ __forceinline__ f32x16 mma16(const s16x8& a, const s16x8& b, const f3
 // 2 no in-loop fragment reads, 4 no vmcnt waits, 8 no output stores, 16 no matrix instructions
 // EPI >= 0: the epilogue's flag word (G16X_*) is a compile-time constant (the model's four Linear flavours get their own
 // instantiation: straight-line epilogue, loads hoisted, no per-row branches); EPI = -1: flags are read at run time.
+// GELU of an epilogue.  LOWP (bf16 operands, the value leaves only as bf16): the polynomial form -- its 1.3e-5 is 0.7 % of a bf16
+// half-ulp (common.hpp); otherwise the 1.5e-7 form.
+template <bool LOWP>
+__device__ __forceinline__ genie_f2 pp_gelu2(genie_f2 z) {
+#ifdef GENIE_VAR_PP_GELU_AS   // (variant: the 1.5e-7 form everywhere)
+    return gelu_erf_fast2(z);
+#else
+    if constexpr (LOWP) return gelu_erf_poly2(z);
+    else return gelu_erf_fast2(z);
+#endif
+}
+
 template <int NPL, int TERMS, bool F16, int ABL = 0, int SCHED = 0, int EPI = -1>
 __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __restrict__ A, long lda, long planeA,
                                                             const uint16_t* __restrict__ W, long ldw, long planeW,
@@ -367,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     float* ct = reinterpret_cast<float*>(smem + PP_BUF + wid * 8192);
     const int fl = EPI >= 0 ? EPI : flags;
     const bool do_gelu = fl & G16X_GELU, do_acc = fl & G16X_ACCUM;
+    constexpr bool kBf16 = NPL == 1 && !F16;   // bf16 operands (GENIE_PREC_BF16)
     const bool out16 = fl & G16X_OUT16, outf = fl & G16X_OUTF32, nts = fl & G16X_NT;
     const float ascale = NPL == 2 ? alpha * (1.0f / 2048.0f) : alpha;
 
@@ -604,11 +617,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     float4 u = lds_ld4(ct + rl * 64 + ((c8 + 4) ^ sw));
                     v.x = v.x * ascale + b0.x; v.y = v.y * ascale + b0.y; v.z = v.z * ascale + b0.z; v.w = v.w * ascale + b0.w;
                     u.x = u.x * ascale + b1.x; u.y = u.y * ascale + b1.y; u.z = u.z * ascale + b1.z; u.w = u.w * ascale + b1.w;
-                    auto gelu4 = [](float4& t) {
-                        const genie_f2 g0 = gelu_erf_fast2(genie_f2{t.x, t.y}), g1 = gelu_erf_fast2(genie_f2{t.z, t.w});
+                    auto gelu4 = [](float4& t, auto lowp) {
+                        const genie_f2 g0 = pp_gelu2<decltype(lowp)::value>(genie_f2{t.x, t.y}), g1 = pp_gelu2<decltype(lowp)::value>(genie_f2{t.z, t.w});
                         t.x = g0[0]; t.y = g0[1]; t.z = g1[0]; t.w = g1[1];
                     };
-                    if (do_gelu) { gelu4(v); gelu4(u); }
+                    if (do_gelu) {
+                        if (kBf16 && !outf) { gelu4(v, std::true_type{}); gelu4(u, std::true_type{}); }
+                        else { gelu4(v, std::false_type{}); gelu4(u, std::false_type{}); }
+                    }
                     const size_t idx = (size_t)row * ldc + col8;
                     if (do_acc) {
                         const float4 o0 = *reinterpret_cast<const float4*>(Rsrc + idx);
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                         }
                     }
                     if (out16) {
-                        if (fl & G16X_GELU16) { gelu4(v); gelu4(u); }
+                        if (fl & G16X_GELU16) { gelu4(v, std::integral_constant<bool, kBf16>{}); gelu4(u, std::integral_constant<bool, kBf16>{}); }
                         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
                         auto st4 = [&](uint16_t* p_, uint32_t a, uint32_t b, uint32_t c, uint32_t dd) {
                             u4v t = {a, b, c, dd};
@@ -695,8 +711,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     float4 v = lds_ld4(ct + rl * 64 + c4);
                     v.x = v.x * ascale + bv.x; v.y = v.y * ascale + bv.y; v.z = v.z * ascale + bv.z; v.w = v.w * ascale + bv.w;
                     if (do_gelu) {
-                        const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
-                        v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+                        if (kBf16 && !outf) {
+                            const genie_f2 g0 = pp_gelu2<true>(genie_f2{v.x, v.y}), g1 = pp_gelu2<true>(genie_f2{v.z, v.w});
+                            v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+                        } else {
+                            const genie_f2 g0 = pp_gelu2<false>(genie_f2{v.x, v.y}), g1 = pp_gelu2<false>(genie_f2{v.z, v.w});
+                            v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+                        }
                     }
                     const size_t idx = (size_t)row * ldc + col;
                     if (do_acc) {
@@ -718,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     }
                     if (out16) {
                         if (fl & G16X_GELU16) {
-                            const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+                            const genie_f2 g0 = pp_gelu2<kBf16>(genie_f2{v.x, v.y}), g1 = pp_gelu2<kBf16>(genie_f2{v.z, v.w});
                             v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
                         }
                         typedef unsigned int u2v __attribute__((ext_vector_type(2)));
