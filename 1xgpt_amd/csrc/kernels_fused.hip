@@ -394,6 +394,40 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
         // issued behind a store would also wait for the store).
         FS_STAMP(blk_i, 2);
         if (FS_ABL(2)) continue;
+#ifndef GENIE_VAR_T_NO_TILE
+        // Through a wave-private LDS tile (16 tokens x 32 columns, rows padded to 144 bytes): the accumulators hold 64-byte pieces of
+        // 16 rows per instruction; row-major, an instruction moves 8 whole 128-byte lines (requests, not bytes, are what this
+        // kernel's memory side costs).  lane -> token 8 half + (lane >> 3), columns 4 (lane & 7) .. + 3 of the 32-column slab.
+        {
+            float* tile = reinterpret_cast<float*>(smem + FS_RING + 4096 + wid * 2304);
+            const int tt = lane >> 3, cc = (lane & 7) * 4;
+            // row of (group grp, token 8 half + tt): ((b T + 8 half + tt) S + s0 + grp) D
+            float* xb = x + (((size_t)b * T + tt) * S + s0) * D + cc;
+            const size_t half_stride = (size_t)8 * S * D;
+            f32x4 rs[2][2];
+            auto load_slab = [&](int i, f32x4* dst) {   // slab i = (grp = i >> 3, columns 32 (i & 7) ..)
+                const float* p = xb + (i >> 3) * D + 32 * (i & 7);
+                dst[0] = *reinterpret_cast<const f32x4*>(p);
+                dst[1] = *reinterpret_cast<const f32x4*>(p + half_stride);
+            };
+            load_slab(0, rs[0]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int grp = i >> 3, sl = i & 7;
+                if (i + 1 < 16) load_slab(i + 1, rs[(i + 1) & 1]);
+                *reinterpret_cast<f32x4*>(tile + r * 36 + 4 * g) = out[grp][2 * sl];
+                *reinterpret_cast<f32x4*>(tile + r * 36 + 16 + 4 * g) = out[grp][2 * sl + 1];
+                __builtin_amdgcn_wave_barrier();
+                float* p = xb + grp * D + 32 * sl;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (8 * hf + tt) * 36 + cc);
+                    *reinterpret_cast<f32x4*>(p + hf * half_stride) = rs[i & 1][hf] + v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#else
         float* xr0 = x + row0 * D + 4 * g;
         f32x4 res[2][8];
         auto load_round = [&](int k, f32x4* dst) {
@@ -411,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
 #pragma unroll
             for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(xr + c * 16) = res[k & 1][c];
         }
+#endif
         FS_STAMP(blk_i, 3);
     }
     FS_CYC_DUMP();
@@ -1076,7 +1111,11 @@ int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw,
     const double M = (double)B * c.T * c.S;
     ProfScope prof(GENIE_KC_FUSED, M * (2.0 * 256 * 1024 + 4.0 * 16 * 256), M * (512.0 + 2048.0), st,
                    "temporal_fused_bf16_kernel (qkv + causal attention over T + proj + residual)");
+#ifndef GENIE_VAR_T_NO_TILE
+    const size_t lds = FS_RING + 4096 + 4 * 2304;   // ring, biases, one 16 x 36-float tile per wave
+#else
     const size_t lds = FS_RING + 4096;
+#endif
     fs_stamps_prepare();
     const float sl2e = c.attn_scale * 1.4426950408889634f;
     if (c.qkv_bias && aw.qkv_b) {
