@@ -132,6 +132,13 @@ __device__ __forceinline__ void fs_lds_wait(s16x8& frag) {
 __device__ __forceinline__ unsigned fs_lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
+// Lanes of one wave exchanging data through LDS: the compiler reasons per thread and may move a lane's read of another lane's
+// slot above its own write -- nothing may cross this point, and every LDS operation issued so far has completed.
+__device__ __forceinline__ void fs_wave_lds_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 #ifndef GENIE_VAR_T_ABL
 #define GENIE_VAR_T_ABL 0   // variant builds only (results wrong): 4 no matrix instructions, 8 no fragment reads, 16 no barriers
 #endif
@@ -287,12 +294,41 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
         // this lane's token of group grp: frame r, position s0 + grp
         const size_t row0 = ((size_t)b * T + r) * S + s0;
         s16x8 xf[2][8];
+#ifdef GENIE_VAR_T_XTILE
+        {   // operand rows as whole 128-byte lines (8 tokens x 64 columns per request), re-laid through the wave's tile
+            unsigned char* tile = smem + FS_RING + 4096 + wid * 2304;
+            const int tt = lane >> 3, c8 = (lane & 7) * 8;
+            const uint16_t* xb = x16 + (((size_t)b * T + tt) * S + s0) * D + c8;
+            const size_t half_stride = (size_t)8 * S * D;
+            s16x8 raw[2][4][2];
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        raw[grp][c][hf] = *reinterpret_cast<const s16x8*>(xb + grp * D + 64 * c + hf * half_stride);
+            fs_wait_vm<0>();
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) *reinterpret_cast<s16x8*>(tile + (8 * hf + tt) * 144 + c8 * 2) = raw[grp][c][hf];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) xf[grp][2 * c + k2] = *reinterpret_cast<const s16x8*>(tile + r * 144 + (32 * k2 + 8 * g) * 2);
+                    __builtin_amdgcn_wave_barrier();
+                }
+        }
+#else
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
                 xf[grp][ks] = *reinterpret_cast<const s16x8*>(x16 + (row0 + grp) * D + 32 * ks + 8 * g);
         fs_wait_vm<0>();
+#endif
         FS_STAMP(blk_i, 1);
         FS_CYC_RESET();
 
@@ -417,14 +453,14 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
                 if (i + 1 < 16) load_slab(i + 1, rs[(i + 1) & 1]);
                 *reinterpret_cast<f32x4*>(tile + r * 36 + 4 * g) = out[grp][2 * sl];
                 *reinterpret_cast<f32x4*>(tile + r * 36 + 16 + 4 * g) = out[grp][2 * sl + 1];
-                __builtin_amdgcn_wave_barrier();
+                fs_wave_lds_fence();
                 float* p = xb + grp * D + 32 * sl;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (8 * hf + tt) * 36 + cc);
                     *reinterpret_cast<f32x4*>(p + hf * half_stride) = rs[i & 1][hf] + v;
                 }
-                __builtin_amdgcn_wave_barrier();
+                fs_wave_lds_fence();
             }
         }
 #else
@@ -594,12 +630,44 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         s16x8 xf[16];
         {
             f32x4 v[32];
+#ifndef GENIE_VAR_M_NO_TILE
+            {   // rows as whole 128-byte lines (8 tokens x 32 columns per request), re-laid through the wave's tile in ring slot 1
+                // (free from this block's last region barrier to the next block's first one)
+                float* tile = reinterpret_cast<float*>(smem + 2 * FS_STAGE + wid * 8192);
+                const int rr = lane >> 3, cc = (lane & 7) * 4;
+                const float* xw = x + ((size_t)blk * 128 + wid * 32 + rr) * D + cc;
+                f32x4 raw[8][4];
+                auto load_slab = [&](int ct) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) raw[ct][i2] = *reinterpret_cast<const f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct);
+                };
+#ifndef GENIE_VAR_M_TILE_PF
+#define GENIE_VAR_M_TILE_PF 2   // slabs requested ahead (4 measured the same)
+#endif
+#pragma unroll
+                for (int ct = 0; ct < GENIE_VAR_M_TILE_PF; ++ct) load_slab(ct);
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {
+                    if (ct + GENIE_VAR_M_TILE_PF < 8) load_slab(ct + GENIE_VAR_M_TILE_PF);
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) *reinterpret_cast<f32x4*>(tile + (rr + 8 * i2) * 36 + cc) = raw[ct][i2];
+                    fs_wave_lds_fence();
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        v[2 * (2 * ct + k2)] = *reinterpret_cast<const f32x4*>(tile + r * 36 + 16 * k2 + 8 * h);
+                        v[2 * (2 * ct + k2) + 1] = *reinterpret_cast<const f32x4*>(tile + r * 36 + 16 * k2 + 8 * h + 4);
+                    }
+                    fs_wave_lds_fence();
+                }
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const float* src = FS_ABL(8) ? x + (size_t)lane * D : xrow;
                 v[2 * ks] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 8 * h);
                 v[2 * ks + 1] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 8 * h + 4);
             }
+#endif
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 32; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -721,6 +789,84 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         // ---- residual update in place: lane = token, columns 32 ct + 8 j + 4 h .. + 3; rounds of 8 pieces, next round's reads first
         FS_STAMP(blk_i, 2);
         if (FS_ABL(2)) { asm volatile("" :: "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7])); continue; }
+#ifndef GENIE_VAR_M_NO_TILE
+        if constexpr (LNOUT) {
+            // Row-major through the wave's tile (ring slot 1): residual rows in, updated rows and the next block's norm1 output out,
+            // 8 whole row segments per request instead of 32 pieces of 32 (16) bytes.
+            float* tile = reinterpret_cast<float*>(smem + 2 * FS_STAGE + wid * 8192);
+            float* stat = tile + 32 * 36;      // (mean, rstd) of the wave's 32 tokens
+            const int rr = lane >> 3, cc = (lane & 7) * 4;
+            size_t roff = ((size_t)blk * 128 + wid * 32 + rr) * D + cc;
+            asm volatile("" : "+v"(roff));     // the row addresses are formed HERE: hoisted above the region loop they are 16 spilled registers
+            float* xw = x + roff;
+            uint16_t* xw16 = x16_out + roff;
+            f32x4 rs[2][4];
+            auto load_res = [&](int ct, f32x4* dst) {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) dst[i2] = *reinterpret_cast<const f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct);
+            };
+            load_res(0, rs[0]);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {       // out += residual, accumulator layout
+                if (ct + 1 < 8) load_res(ct + 1, rs[(ct + 1) & 1]);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) *reinterpret_cast<f32x4*>(tile + (rr + 8 * i2) * 36 + cc) = rs[ct & 1][i2];
+                fs_wave_lds_fence();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * j + 4 * h);
+                    out[ct][4 * j] += t4.x; out[ct][4 * j + 1] += t4.y; out[ct][4 * j + 2] += t4.z; out[ct][4 * j + 3] += t4.w;
+                }
+                fs_wave_lds_fence();
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) sum += (out[ct][i] + out[ct][i + 1]) + (out[ct][i + 2] + out[ct][i + 3]);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / D);
+            float sq = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const float d0 = out[ct][i] - mean, d1 = out[ct][i + 1] - mean, d2 = out[ct][i + 2] - mean, d3 = out[ct][i + 3] - mean;
+                    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
+            {
+                int rl = r;
+                asm volatile("" : "+v"(rl));   // (its address is formed here, not kept in a spilled register since kernel entry)
+                if (h == 0) { stat[2 * rl] = mean; stat[2 * rl + 1] = rstd; }
+            }
+            fs_wave_lds_fence();
+            float mu[4], rs_[4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) { mu[i2] = stat[2 * (rr + 8 * i2)]; rs_[i2] = stat[2 * (rr + 8 * i2) + 1]; }
+            const float* s_ng = reinterpret_cast<const float*>(smem + ML_OFF_NXG) + cc;
+            const float* s_nb = reinterpret_cast<const float*>(smem + ML_OFF_NXB) + cc;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(tile + r * 36 + 8 * j + 4 * h) = f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]};
+                fs_wave_lds_fence();
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(s_ng + 32 * ct), bv = *reinterpret_cast<const f32x4*>(s_nb + 32 * ct);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc);
+                    *reinterpret_cast<f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct) = vv;
+                    const f32x4 y = (vv - mu[i2]) * rs_[i2] * gv + bv;
+                    *reinterpret_cast<s16x4*>(xw16 + (size_t)(8 * i2) * D + 32 * ct) = pack4(y);
+                }
+                fs_wave_lds_fence();
+            }
+            FS_STAMP(blk_i, 3);
+            continue;
+        }
+#endif
         f32x4 res[2][8];
         float* xrowh = xrow + 4 * h;
         auto load_round = [&](int k, f32x4* dst) {   // round k = column tiles 2k, 2k + 1
@@ -964,7 +1110,11 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
         for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+#ifdef GENIE_VAR_S_RESEND
+                const f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};   // (variant: the residual joins in the epilogue, row-major)
+#else
                 const f32x4 xv = (GENIE_VAR_S_ABL & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(xrow + 32 * ct + 8 * j);
+#endif
                 out[ct][4 * j] = xv.x; out[ct][4 * j + 1] = xv.y; out[ct][4 * j + 2] = xv.z; out[ct][4 * j + 3] = xv.w;
             }
 #pragma unroll 1
@@ -1044,11 +1194,24 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
         fs_barrier();
         {
             float* tile = reinterpret_cast<float*>(smem + (buf ^ 1) * SA_BUF + wid * 8192);   // (buf was toggled after the last head)
-            float* xw = x + ((size_t)seq * 256 + wid * 32) * D;
-            uint16_t* xw16 = x16 + ((size_t)seq * 256 + wid * 32) * D;
+            size_t soff = ((size_t)seq * 256 + wid * 32) * D;
+            asm volatile("" : "+s"(soff));   // (address arithmetic stays here: hoisted above the head loop it is spilled)
+            float* xw = x + soff;
+            uint16_t* xw16 = x16 + soff;
             const int rr = lane >> 3, cc = (lane & 7) * 4;        // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
+#ifdef GENIE_VAR_S_RESEND
+            f32x4 rs[2][4];
+            auto load_res = [&](int ct_, f32x4* dst) {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) dst[i2] = *reinterpret_cast<const f32x4*>(xw + (size_t)(rr + 8 * i2) * D + 32 * ct_ + cc);
+            };
+            load_res(0, rs[0]);
+#endif
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
+#ifdef GENIE_VAR_S_RESEND
+                if (ct + 1 < 8) load_res(ct + 1, rs[(ct + 1) & 1]);
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     *reinterpret_cast<f32x4*>(tile + r * 36 + 8 * j + 4 * h) =
@@ -1059,7 +1222,11 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) {
+#ifdef GENIE_VAR_S_RESEND
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc) + rs[ct & 1][i2];
+#else
                     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc);
+#endif
                     *reinterpret_cast<f32x4*>(xw + (size_t)(rr + 8 * i2) * D + 32 * ct + cc) = v;
                     *reinterpret_cast<s16x4*>(xw16 + (size_t)(rr + 8 * i2) * D + 32 * ct + cc) = pack4(v);
                 }
