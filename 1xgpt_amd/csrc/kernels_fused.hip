@@ -1021,6 +1021,9 @@ int launch_pack_spatial_proj(const float* proj_w, uint16_t* out, hipStream_t st)
     return GENIE_OK;
 }
 
+#ifndef GENIE_VAR_S_RES_AT_START
+#define GENIE_VAR_S_RESEND 1   // the residual row joins in the epilogue, row-major (variant: as the accumulators' initial value)
+#endif
 __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const uint16_t* __restrict__ qkv16, long P,
                                                                         const uint16_t* __restrict__ wstream,
                                                                         const float* __restrict__ proj_b, float* __restrict__ x,
@@ -1099,11 +1102,9 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
     issue_item(seq0, 0, 0);
     int buf = 0;
     for (long seq = seq0; seq < n_seq; seq += step) {
-        // The output row STARTS as the residual row: out = x (+ bias), the heads' projections accumulate on top, and the epilogue only
-        // stores.  The 32 row pieces are requested here -- right behind the previous sequence's stores -- and are first needed by
-        // the out-projection at the END of head 0, a whole attention later: the residual read (268 MB per layer at 64 clips) costs
-        // no time of its own, where an epilogue that reads, adds and stores cost 140 us of 344 (every workgroup of the chip in its
-        // epilogue at once, HBM-bound, all matrix pipes idle).
+        // The residual row: either the accumulators' initial value (GENIE_VAR_S_RES_AT_START: 32 row PIECES of 32 bytes per request, issued
+        // here and first needed at the end of head 0 -- fully hidden, 320-325 us), or -- shipped -- added in the epilogue from row-major
+        // loads (8 whole 128-byte segments per request, one column tile ahead of its use: 317-318 us, config 2 -0.5 % same-box).
         float* xrow = x + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
         f32x16 out[8];
 #pragma unroll
@@ -1198,7 +1199,8 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
             asm volatile("" : "+s"(soff));   // (address arithmetic stays here: hoisted above the head loop it is spilled)
             float* xw = x + soff;
             uint16_t* xw16 = x16 + soff;
-            const int rr = lane >> 3, cc = (lane & 7) * 4;        // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
+            int rr = lane >> 3, cc = (lane & 7) * 4;              // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
+            asm volatile("" : "+v"(rr), "+v"(cc));            // (everything derived from them is formed here, not hoisted and spilled)
 #ifdef GENIE_VAR_S_RESEND
             f32x4 rs[2][4];
             auto load_res = [&](int ct_, f32x4* dst) {

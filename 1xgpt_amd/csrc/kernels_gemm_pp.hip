@@ -489,11 +489,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 // earlier store.)  head_dim is a power of two (32 / 64 on this path): shifts, no integer division.
                 const float qs = which == 0 ? qscale : 1.0f;
                 const int c8 = (lane & 7) << 3;
+                const int lrow = lane >> 3;
                 const int colq = n0e - which * dm + wn * 64 + c8;
                 const int hq = colq >> hd_shift, fq = colq & (head_dim - 1);
                 const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)(m0e >> 8) * 256 * dm), 0, -1, 0x00020000);
                 const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(base + P + (size_t)(m0e >> 8) * 256 * dm), 0, -1, 0x00020000);
-                const int voff = ((((hq << 8) + wm * 128 + (lane >> 3)) << hd_shift) + fq) * 2;
+                const int voff = ((((hq << 8) + wm * 128 + lrow) << hd_shift) + fq) * 2;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (bias) { b0 = lds_ld4(bl + c8); b1 = lds_ld4(bl + c8 + 4); }
 #pragma unroll
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
-                        const int rl = it * 8 + (lane >> 3);
+                        const int rl = it * 8 + lrow;
                         // head-major: [(sequence, head)][row of the sequence][feature] -- a head's 256 rows are one contiguous
                         // 256 * head_dim block, which is what the attention kernel's LDS-DMA pieces walk
                         // (element index ((sequence * heads + hq) * 256 + row) * head_dim + fq, row = wm * 128 + q * 32 + rl)
