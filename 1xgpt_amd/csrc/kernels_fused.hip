@@ -440,17 +440,22 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
             // row of (group grp, token 8 half + tt): ((b T + 8 half + tt) S + s0 + grp) D
             float* xb = x + (((size_t)b * T + tt) * S + s0) * D + cc;
             const size_t half_stride = (size_t)8 * S * D;
-            f32x4 rs[2][2];
+#ifndef GENIE_VAR_T_EPF
+#define GENIE_VAR_T_EPF 1      // residual slabs requested ahead of their use
+#endif
+            constexpr int EPF = GENIE_VAR_T_EPF;
+            f32x4 rs[EPF + 1][2];
             auto load_slab = [&](int i, f32x4* dst) {   // slab i = (grp = i >> 3, columns 32 (i & 7) ..)
                 const float* p = xb + (i >> 3) * D + 32 * (i & 7);
                 dst[0] = *reinterpret_cast<const f32x4*>(p);
                 dst[1] = *reinterpret_cast<const f32x4*>(p + half_stride);
             };
-            load_slab(0, rs[0]);
+#pragma unroll
+            for (int i = 0; i < EPF; ++i) load_slab(i, rs[i % (EPF + 1)]);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int grp = i >> 3, sl = i & 7;
-                if (i + 1 < 16) load_slab(i + 1, rs[(i + 1) & 1]);
+                if (i + EPF < 16) load_slab(i + EPF, rs[(i + EPF) % (EPF + 1)]);
                 *reinterpret_cast<f32x4*>(tile + r * 36 + 4 * g) = out[grp][2 * sl];
                 *reinterpret_cast<f32x4*>(tile + r * 36 + 16 + 4 * g) = out[grp][2 * sl + 1];
                 fs_wave_lds_fence();
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (8 * hf + tt) * 36 + cc);
-                    *reinterpret_cast<f32x4*>(p + hf * half_stride) = rs[i & 1][hf] + v;
+                    *reinterpret_cast<f32x4*>(p + hf * half_stride) = rs[i % (EPF + 1)][hf] + v;
                 }
                 fs_wave_lds_fence();
             }
