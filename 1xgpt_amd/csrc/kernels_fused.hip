@@ -549,7 +549,9 @@ __global__ void pack_mlp_fused_kernel(const float* __restrict__ fc1_w, const flo
     const int c = n >> 1;   // stage 2c = A_c, stage 2c + 1 = B_c
     float v;
     if (!(n & 1)) {
-        v = fc1_w[(size_t)(32 * c + rr) * 256 + 16 * f + 8 * h + e];                      // fragment f = K-step
+        // fragment f = 2 ct + kk contracts the features a lane holds in registers 8 kk .. 8 kk + 7 of accumulator tile ct
+        // (the LayerNorm output is packed straight from accumulator-layout registers, as the GELU output is for fc2)
+        v = fc1_w[(size_t)(32 * c + rr) * 256 + 32 * (f >> 1) + 16 * (f & 1) + (e & 3) + 8 * (e >> 2) + 4 * h];
     } else {
         const int kk = f >> 3, ct = f & 7;                                                 // fragment f = 8 kk + ct
         v = fc2_w[(size_t)(32 * ct + rr) * 1024 + 32 * c + 16 * kk + (e & 3) + 8 * (e >> 2) + 4 * h];
@@ -630,80 +632,75 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
     [[maybe_unused]] int blk_i = 0;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x, ++blk_i) {
         FS_STAMP(blk_i, 0);
-        float* xrow = x + ((size_t)blk * 128 + wid * 32 + r) * D;   // this lane's token
-        // ---- LayerNorm of the wave's 32 rows, straight into the K-step fragments
+        // ---- the wave's 32 rows: row-major from HBM (8 whole 128-byte segments per request), through the wave's tile (ring slot 1: free
+        // from this block's last region barrier to the next block's first one) into ACCUMULATOR layout.  They stay there: `out` starts as
+        // the residual row and fc2 accumulates on top, so the epilogue reads nothing (the rows were read twice before: 268 MB per launch).
+        // LayerNorm from the same registers; its output is packed per accumulator half-tile -- fc1's fragments are packed in that K order.
+        f32x16 out[8];
         s16x8 xf[16];
         {
-            f32x4 v[32];
-#ifndef GENIE_VAR_M_NO_TILE
-            {   // rows as whole 128-byte lines (8 tokens x 32 columns per request), re-laid through the wave's tile in ring slot 1
-                // (free from this block's last region barrier to the next block's first one)
-                float* tile = reinterpret_cast<float*>(smem + 2 * FS_STAGE + wid * 8192);
-                const int rr = lane >> 3, cc = (lane & 7) * 4;
-                const float* xw = x + ((size_t)blk * 128 + wid * 32 + rr) * D + cc;
-                f32x4 raw[8][4];
-                auto load_slab = [&](int ct) {
+            float* tile = reinterpret_cast<float*>(smem + 2 * FS_STAGE + wid * 8192);
+            int rr = lane >> 3, cc = (lane & 7) * 4;
+            asm volatile("" : "+v"(rr), "+v"(cc));   // (addresses derived from them are formed here, per block -- not hoisted and spilled)
+            const float* xw = x + ((size_t)blk * 128 + wid * 32 + rr) * D + cc;
+            f32x4 raw[8][4];
+            auto load_slab = [&](int ct) {
 #pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) raw[ct][i2] = *reinterpret_cast<const f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct);
-                };
+                for (int i2 = 0; i2 < 4; ++i2) raw[ct][i2] = *reinterpret_cast<const f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct);
+            };
 #ifndef GENIE_VAR_M_TILE_PF
 #define GENIE_VAR_M_TILE_PF 2   // slabs requested ahead (4 measured the same)
 #endif
 #pragma unroll
-                for (int ct = 0; ct < GENIE_VAR_M_TILE_PF; ++ct) load_slab(ct);
+            for (int ct = 0; ct < GENIE_VAR_M_TILE_PF; ++ct) load_slab(ct);
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct) {
-                    if (ct + GENIE_VAR_M_TILE_PF < 8) load_slab(ct + GENIE_VAR_M_TILE_PF);
+            for (int ct = 0; ct < 8; ++ct) {
+                if (ct + GENIE_VAR_M_TILE_PF < 8) load_slab(ct + GENIE_VAR_M_TILE_PF);
 #pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) *reinterpret_cast<f32x4*>(tile + (rr + 8 * i2) * 36 + cc) = raw[ct][i2];
-                    fs_wave_lds_fence();
+                for (int i2 = 0; i2 < 4; ++i2) *reinterpret_cast<f32x4*>(tile + (rr + 8 * i2) * 36 + cc) = raw[ct][i2];
+                fs_wave_lds_fence();
 #pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        v[2 * (2 * ct + k2)] = *reinterpret_cast<const f32x4*>(tile + r * 36 + 16 * k2 + 8 * h);
-                        v[2 * (2 * ct + k2) + 1] = *reinterpret_cast<const f32x4*>(tile + r * 36 + 16 * k2 + 8 * h + 4);
-                    }
-                    fs_wave_lds_fence();
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * j + 4 * h);
+                    out[ct][4 * j] = t4.x; out[ct][4 * j + 1] = t4.y; out[ct][4 * j + 2] = t4.z; out[ct][4 * j + 3] = t4.w;
                 }
+                fs_wave_lds_fence();
             }
-#else
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const float* src = FS_ABL(8) ? x + (size_t)lane * D : xrow;
-                v[2 * ks] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 8 * h);
-                v[2 * ks + 1] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 8 * h + 4);
-            }
-#endif
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) sum += (out[ct][i] + out[ct][i + 1]) + (out[ct][i + 2] + out[ct][i + 3]);
             sum += __shfl_xor(sum, 32);
             const float mean = sum * (1.0f / D);
             float sq = 0.f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                v[i] -= mean;
-                sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-            }
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const float d0 = out[ct][i] - mean, d1 = out[ct][i + 1] - mean, d2 = out[ct][i + 2] - mean, d3 = out[ct][i + 3] - mean;
+                    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
             sq += __shfl_xor(sq, 32);
             const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
+            const float* s_g4 = s_g + 4 * h;
+            const float* s_b4 = s_b + 4 * h;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(s_g + 16 * ks + 8 * h), g1 = *reinterpret_cast<const f32x4*>(s_g + 16 * ks + 8 * h + 4);
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(s_b + 16 * ks + 8 * h), c1 = *reinterpret_cast<const f32x4*>(s_b + 16 * ks + 8 * h + 4);
-                xf[ks] = pack8(v[2 * ks] * rstd * g0 + c0, v[2 * ks + 1] * rstd * g1 + c1);
-            }
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    f32x4 y[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int j = 2 * kk + q;
+                        const f32x4 gv = *reinterpret_cast<const f32x4*>(s_g4 + 32 * ct + 8 * j), bv = *reinterpret_cast<const f32x4*>(s_b4 + 32 * ct + 8 * j);
+                        y[q] = (f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]} - mean) * rstd * gv + bv;
+                    }
+                    xf[2 * ct + kk] = pack8(y[0], y[1]);
+                }
         }
         fs_wait_vm<0>();
         FS_STAMP(blk_i, 1);
-
-        f32x16 out[8];
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(s_b2 + 32 * ct + 8 * j + 4 * h);
-                out[ct][4 * j] = bv.x; out[ct][4 * j + 1] = bv.y; out[ct][4 * j + 2] = bv.z; out[ct][4 * j + 3] = bv.w;
-            }
         auto bias1 = [&](int c) {
             f32x16 a;
 #pragma unroll
@@ -794,142 +791,79 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         // ---- residual update in place: lane = token, columns 32 ct + 8 j + 4 h .. + 3; rounds of 8 pieces, next round's reads first
         FS_STAMP(blk_i, 2);
         if (FS_ABL(2)) { asm volatile("" :: "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7])); continue; }
-#ifndef GENIE_VAR_M_NO_TILE
-        if constexpr (LNOUT) {
-            // Row-major through the wave's tile (ring slot 1): residual rows in, updated rows and the next block's norm1 output out,
-            // 8 whole row segments per request instead of 32 pieces of 32 (16) bytes.
+        {
+            // `out` holds x + fc2(...); + bias = the updated row.  Out row-major through the wave's tile (ring slot 1): 8 whole row
+            // segments per request instead of 32 pieces of 32 (16) bytes; LNOUT: also the row normalised with the next block's norm1.
             float* tile = reinterpret_cast<float*>(smem + 2 * FS_STAGE + wid * 8192);
             float* stat = tile + 32 * 36;      // (mean, rstd) of the wave's 32 tokens
-            const int rr = lane >> 3, cc = (lane & 7) * 4;
+            int rr = lane >> 3, cc = (lane & 7) * 4;
             size_t roff = ((size_t)blk * 128 + wid * 32 + rr) * D + cc;
             asm volatile("" : "+v"(roff));     // the row addresses are formed HERE: hoisted above the region loop they are 16 spilled registers
             float* xw = x + roff;
             uint16_t* xw16 = x16_out + roff;
-            f32x4 rs[2][4];
-            auto load_res = [&](int ct, f32x4* dst) {
+            [[maybe_unused]] int w16 = x16_out != nullptr;
+            asm volatile("" : "+v"(w16));   // a per-lane predicate: the store loop is masked, not duplicated (the duplicate spilled)
+            float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs_[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (LNOUT) {   // LayerNorm statistics of the updated row (two-pass, as layer_norm_fast_kernel)
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) dst[i2] = *reinterpret_cast<const f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct);
-            };
-            load_res(0, rs[0]);
+                for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {       // out += residual, accumulator layout
-                if (ct + 1 < 8) load_res(ct + 1, rs[(ct + 1) & 1]);
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(s_b2 + 32 * ct + 8 * j + 4 * h);
+                        out[ct][4 * j] += bv.x; out[ct][4 * j + 1] += bv.y; out[ct][4 * j + 2] += bv.z; out[ct][4 * j + 3] += bv.w;
+                    }
+                float sum = 0.f;
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) *reinterpret_cast<f32x4*>(tile + (rr + 8 * i2) * 36 + cc) = rs[ct & 1][i2];
-                fs_wave_lds_fence();
+                for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * j + 4 * h);
-                    out[ct][4 * j] += t4.x; out[ct][4 * j + 1] += t4.y; out[ct][4 * j + 2] += t4.z; out[ct][4 * j + 3] += t4.w;
+                    for (int i = 0; i < 16; i += 4) sum += (out[ct][i] + out[ct][i + 1]) + (out[ct][i + 2] + out[ct][i + 3]);
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum * (1.0f / D);
+                float sq = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        const float d0 = out[ct][i] - mean, d1 = out[ct][i + 1] - mean, d2 = out[ct][i + 2] - mean, d3 = out[ct][i + 3] - mean;
+                        sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                    }
+                sq += __shfl_xor(sq, 32);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
+                {
+                    int rl = r;
+                    asm volatile("" : "+v"(rl));   // (its address is formed here, not kept in a spilled register since kernel entry)
+                    if (h == 0) { stat[2 * rl] = mean; stat[2 * rl + 1] = rstd; }
                 }
                 fs_wave_lds_fence();
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) { mu[i2] = stat[2 * (rr + 8 * i2)]; rs_[i2] = stat[2 * (rr + 8 * i2) + 1]; }
             }
-            float sum = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-                for (int i = 0; i < 16; i += 4) sum += (out[ct][i] + out[ct][i + 1]) + (out[ct][i + 2] + out[ct][i + 3]);
-            sum += __shfl_xor(sum, 32);
-            const float mean = sum * (1.0f / D);
-            float sq = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-                for (int i = 0; i < 16; i += 4) {
-                    const float d0 = out[ct][i] - mean, d1 = out[ct][i + 1] - mean, d2 = out[ct][i + 2] - mean, d3 = out[ct][i + 3] - mean;
-                    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                }
-            sq += __shfl_xor(sq, 32);
-            const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
-            {
-                int rl = r;
-                asm volatile("" : "+v"(rl));   // (its address is formed here, not kept in a spilled register since kernel entry)
-                if (h == 0) { stat[2 * rl] = mean; stat[2 * rl + 1] = rstd; }
-            }
-            fs_wave_lds_fence();
-            float mu[4], rs_[4];
-#pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) { mu[i2] = stat[2 * (rr + 8 * i2)]; rs_[i2] = stat[2 * (rr + 8 * i2) + 1]; }
             const float* s_ng = reinterpret_cast<const float*>(smem + ML_OFF_NXG) + cc;
             const float* s_nb = reinterpret_cast<const float*>(smem + ML_OFF_NXB) + cc;
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f32x4*>(tile + r * 36 + 8 * j + 4 * h) = f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]};
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 o4 = f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]};
+                    if constexpr (!LNOUT) o4 += *reinterpret_cast<const f32x4*>(s_b2 + 32 * ct + 8 * j + 4 * h);   // (LNOUT: added above, for the statistics)
+                    *reinterpret_cast<f32x4*>(tile + r * 36 + 8 * j + 4 * h) = o4;
+                }
                 fs_wave_lds_fence();
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(s_ng + 32 * ct), bv = *reinterpret_cast<const f32x4*>(s_nb + 32 * ct);
+                f32x4 gv = {1.f, 1.f, 1.f, 1.f}, bv = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (LNOUT) { gv = *reinterpret_cast<const f32x4*>(s_ng + 32 * ct); bv = *reinterpret_cast<const f32x4*>(s_nb + 32 * ct); }
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) {
                     const f32x4 vv = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc);
                     *reinterpret_cast<f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct) = vv;
-                    const f32x4 y = (vv - mu[i2]) * rs_[i2] * gv + bv;
-                    *reinterpret_cast<s16x4*>(xw16 + (size_t)(8 * i2) * D + 32 * ct) = pack4(y);
+                    if constexpr (LNOUT) {
+                        const f32x4 y = (vv - mu[i2]) * rs_[i2] * gv + bv;
+                        *reinterpret_cast<s16x4*>(xw16 + (size_t)(8 * i2) * D + 32 * ct) = pack4(y);
+                    } else {
+                        if (w16) *reinterpret_cast<s16x4*>(xw16 + (size_t)(8 * i2) * D + 32 * ct) = pack4(vv);
+                    }
                 }
                 fs_wave_lds_fence();
             }
-            FS_STAMP(blk_i, 3);
-            continue;
-        }
-#endif
-        f32x4 res[2][8];
-        float* xrowh = xrow + 4 * h;
-        auto load_round = [&](int k, f32x4* dst) {   // round k = column tiles 2k, 2k + 1
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xrowh + 32 * (2 * k + (q >> 2)) + 8 * (q & 3));
-        };
-        uint16_t* x16row = x16_out + ((size_t)blk * 128 + wid * 32 + r) * D;
-        load_round(0, res[0]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k + 1 < 4) load_round(k + 1, res[(k + 1) & 1]);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f32x16& o = out[2 * k + (q >> 2)];
-                const int j = q & 3;
-                res[k & 1][q] += f32x4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
-                if constexpr (LNOUT) {   // the accumulators keep the updated row for the statistics below
-                    o[4 * j] = res[k & 1][q].x; o[4 * j + 1] = res[k & 1][q].y; o[4 * j + 2] = res[k & 1][q].z; o[4 * j + 3] = res[k & 1][q].w;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                *reinterpret_cast<f32x4*>(xrowh + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = res[k & 1][q];
-                if constexpr (!LNOUT) {
-                    if (x16_out) *reinterpret_cast<s16x4*>(x16row + 4 * h + 32 * (2 * k + (q >> 2)) + 8 * (q & 3)) = pack4(res[k & 1][q]);
-                }
-            }
-        }
-        if constexpr (LNOUT) {   // LayerNorm of the updated row (two-pass, as layer_norm_fast_kernel) -> bf16
-            const float* s_ng4 = reinterpret_cast<const float*>(smem + ML_OFF_NXG) + 4 * h;
-            const float* s_nb4 = reinterpret_cast<const float*>(smem + ML_OFF_NXB) + 4 * h;
-            uint16_t* x16h = x16row + 4 * h;
-            float sum = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-                for (int i = 0; i < 16; i += 4) sum += (out[ct][i] + out[ct][i + 1]) + (out[ct][i + 2] + out[ct][i + 3]);
-            sum += __shfl_xor(sum, 32);
-            const float mean = sum * (1.0f / D);
-            float sq = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-                for (int i = 0; i < 16; i += 4) {
-                    out[ct][i] -= mean; out[ct][i + 1] -= mean; out[ct][i + 2] -= mean; out[ct][i + 3] -= mean;
-                    sq += (out[ct][i] * out[ct][i] + out[ct][i + 1] * out[ct][i + 1]) + (out[ct][i + 2] * out[ct][i + 2] + out[ct][i + 3] * out[ct][i + 3]);
-                }
-            sq += __shfl_xor(sq, 32);
-            const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = 32 * ct + 8 * j;   // (+ 4 h: in the lane's base pointers, so every access is base + immediate)
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(s_ng4 + col), bv = *reinterpret_cast<const f32x4*>(s_nb4 + col);
-                    const f32x4 y = f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]} * rstd * gv + bv;
-                    *reinterpret_cast<s16x4*>(x16h + col) = pack4(y);
-                }
         }
         FS_STAMP(blk_i, 3);
     }
@@ -1110,7 +1044,7 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
         // The residual row: either the accumulators' initial value (GENIE_VAR_S_RES_AT_START: 32 row PIECES of 32 bytes per request, issued
         // here and first needed at the end of head 0 -- fully hidden, 320-325 us), or -- shipped -- added in the epilogue from row-major
         // loads (8 whole 128-byte segments per request, one column tile ahead of its use: 317-318 us, config 2 -0.5 % same-box).
-        float* xrow = x + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
+        [[maybe_unused]] float* xrow = x + ((size_t)seq * 256 + wid * 32 + r) * D + 4 * h;
         f32x16 out[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
