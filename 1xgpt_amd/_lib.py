@@ -44,7 +44,8 @@ class Weights(C.Structure):
                 ("out_b", c_ptr), ("out_w16", c_ptr), ("layers_host", C.POINTER(LayerWeights)), ("out_w16_wide", C.c_int32)]
 
 WIDE_QKV, WIDE_PROJ, WIDE_FC1, WIDE_FC2 = 1, 2, 1, 2          # bits of the w16_wide fields (genie_hip.h)
-TEMPORAL_FUSED_ELEMS, MLP_FUSED_ELEMS, SPATIAL_PROJ_FUSED_ELEMS = 262144, 524288, 65536        # bf16 values of the fused kernels' weight streams
+FUSED_QKV_STREAM = 4                                        # spatial attention: fused_w16 = [proj stream | qkv stream]
+TEMPORAL_FUSED_ELEMS, MLP_FUSED_ELEMS, SPATIAL_PROJ_FUSED_ELEMS, SPATIAL_QKV_FUSED_ELEMS = 262144, 524288, 65536, 196608        # bf16 values of the fused kernels' weight streams
 ABI_VERSION = 2
 
 
@@ -117,6 +118,7 @@ SIGNATURES = {
     "genie_pack_temporal_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_pack_mlp_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_pack_spatial_proj_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
+    "genie_pack_spatial_qkv_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "genie_spatial_attn_proj_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
     "genie_temporal_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, c_ptr]),
     "genie_mlp_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(LayerWeights), c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),

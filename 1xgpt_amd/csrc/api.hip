@@ -207,6 +207,7 @@ static int st_block(const genie_cfg& c, const genie_layer_weights& lw, float* x,
 static int decoder(const genie_cfg& c, const genie_weights& wt, float* x, Workspace& w, int B, hipStream_t st) {
     if (c.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c, x, w, B, st));
     if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, x, w, B, st));
+    w.ln1_done = w.qkv_planes_done = false;   // (hand-offs between consecutive blocks of ONE pass; a failed pass must not leave them set)
     for (int i = 0; i < c.num_layers; ++i) {
         w.skip_shadow_mlp = !c.qk_norm && i + 1 < c.num_layers;
         w.next_layer = i + 1 < c.num_layers ? &wt.layers_host[i + 1] : nullptr;
@@ -402,6 +403,7 @@ static int prefix_forward(const genie_cfg& c, const genie_weights& wt, const int
     GENIE_TRY(launch_embed(c, wt, ids, B, w.x, st));
     if (c.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c, w.x, w, B, st));
     if (c.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c, w.x, w, B, st));
+    w.ln1_done = w.qkv_planes_done = false;
     for (int i = 0; i < c.num_layers; ++i) {
         if (clean) { w.tqkv = cache + i * per_layer; w.tcache = nullptr; w.tq_frames = cache_frames; }
         else { w.tqkv = nullptr; w.tcache = cache + i * per_layer; w.tshift = tshift; }
@@ -699,6 +701,10 @@ int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, fl
 int genie_pack_spatial_proj_fused_bf16(const float* proj_w, uint16_t* dst, void* stream) {
     GENIE_CHECK_ARG(proj_w && dst, "pack_spatial_proj_fused: NULL pointer");
     return launch_pack_spatial_proj(proj_w, dst, as_stream(stream));
+}
+int genie_pack_spatial_qkv_fused_bf16(const float* qkv_w, uint16_t* dst, void* stream) {
+    GENIE_CHECK_ARG(qkv_w && dst, "pack_spatial_qkv_fused: NULL pointer");
+    return launch_pack_spatial_qkv(qkv_w, dst, as_stream(stream));
 }
 int genie_spatial_attn_proj_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* qkv_planes, float* x,
                                        uint16_t* x16, int64_t n_seq, void* stream) {

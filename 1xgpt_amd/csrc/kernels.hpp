@@ -41,6 +41,7 @@ struct Workspace {
     // MLP epilogue and `ln1_done` tells that block to skip its own LayerNorm launch.
     const genie_layer_weights* next_layer = nullptr;
     bool ln1_done = false;
+    bool qkv_planes_done = false;   // ... or even its spatial operand planes (in `big`): that block goes straight to its attention kernel
 };
 
 // GENIE_PREC_BF16: the temporal qkv buffer and the temporal KV cache hold bf16 values (half the bytes of the HBM-bound temporal
@@ -60,7 +61,9 @@ int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& 
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
                                hipStream_t st);
 int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,
-                          const float* nx_g = nullptr, const float* nx_b = nullptr);
+                          const float* nx_g = nullptr, const float* nx_b = nullptr, const uint16_t* nx_qkv_stream = nullptr,
+                          uint16_t* planes = nullptr);
+int launch_pack_spatial_qkv(const float* qkv_w, uint16_t* out, hipStream_t st);
 
 // Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
 // tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.

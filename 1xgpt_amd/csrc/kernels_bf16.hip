@@ -857,7 +857,12 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     const uint16_t* u = x16;
     int rc = GENIE_E_UNSUPPORTED;
     bool qkv_done = false, proj_done = false;
-    if (!c.qk_norm) {  // one-frame passes: LayerNorm inside the small GEMM's fragment path (no LayerNorm launch)
+    if (w.qkv_planes_done) {   // the previous block's fused MLP kernel left this block's operand planes in `big`
+        w.qkv_planes_done = false;
+        GENIE_TRY(launch_spatial_attn_proj_bf16(c, lw.spatial, (const uint16_t*)w.big, x, x16, (long)B * c.T, st));
+        qkv_done = true; proj_done = true; rc = GENIE_OK;
+    }
+    if (!qkv_done && !c.qk_norm) {  // one-frame passes: LayerNorm inside the small GEMM's fragment path (no LayerNorm launch)
         const int r2 = launch_gemm16_sm_ln(1, x, d, lw.norm1_w, lw.norm1_b, 1e-5f, lw.spatial.qkv_w16, d, 0,
                                            c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, qkv, nullptr, 0, 3 * d, M, 3 * d, d,
                                            G16_OUTF32, 1.0f, st);
@@ -957,8 +962,17 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
         constexpr int lnout = 1;
 #endif
         if (lnout && nx && nx->norm1_w && nx->norm1_b && w.skip_shadow_mlp) {
-            rc = launch_mlp_fused_bf16(c, lw, x, xn16, (long)M, st, nx->norm1_w, nx->norm1_b);
-            if (rc == GENIE_OK) w.ln1_done = true;
+            rc = GENIE_E_UNSUPPORTED;
+            if (nx->spatial.fused_w16 && (nx->spatial.w16_wide & GENIE_FUSED_QKV_STREAM)) {
+                // ... and the next block's spatial qkv Linear too: its operand planes (in `big`, where its qkv GEMM would put them)
+                rc = launch_mlp_fused_bf16(c, lw, x, nullptr, (long)M, st, nx->norm1_w, nx->norm1_b,
+                                           nx->spatial.fused_w16 + GENIE_SPATIAL_PROJ_FUSED_ELEMS, (uint16_t*)w.big);
+                if (rc == GENIE_OK) w.qkv_planes_done = true;
+            }
+            if (rc == GENIE_E_UNSUPPORTED) {
+                rc = launch_mlp_fused_bf16(c, lw, x, xn16, (long)M, st, nx->norm1_w, nx->norm1_b);
+                if (rc == GENIE_OK) w.ln1_done = true;
+            }
         } else {
             rc = launch_mlp_fused_bf16(c, lw, x, w.skip_shadow_mlp ? nullptr : x16, (long)M, st);
         }

@@ -577,12 +577,16 @@ constexpr int ML_LDS = FS_RING + 9216;
 // x16_out (optional) receives a bf16 copy of the updated rows: the plain shadow of x (LNOUT = false; the readout's operand after
 // the last block), or -- LNOUT = true -- LayerNorm(x; nx_g, nx_b), i.e. the NEXT block's norm1 output, the operand of its
 // spatial qkv Linear (st_transformer.py:73): the row is complete in this lane pair's registers, so that LayerNorm launch goes.
-template <bool LNOUT>
+// MODE 2: instead of that bf16 row, the next block's spatial q | k | v^T operand planes (its LayerNorm AND its qkv Linear happen here:
+// 24 more 16 KB weight stages per block through the region ring's idle halves; the planes leave through a wave tile as whole lines).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restrict__ x, const uint16_t* __restrict__ wstream,
                                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                                 const float* __restrict__ b1, const float* __restrict__ b2,
                                                                 uint16_t* __restrict__ x16_out, const float* __restrict__ nx_g,
-                                                                const float* __restrict__ nx_b, int n_blocks, float eps, int abl) {
+                                                                const float* __restrict__ nx_b, int n_blocks, float eps, int abl,
+                                                                const uint16_t* __restrict__ qstream, long P, float qscale) {
+    constexpr bool LNOUT = MODE >= 1, QKV = MODE == 2;   // (MODE 2: x16_out = the plane buffer)
     // abl (study build only, GENIE_FUSED_ABL; results are WRONG when set): 1 no in-loop LDS-DMA, 2 no residual read / store,
     // 4 no GELU, 8 no LayerNorm prologue loads
     constexpr int D = 256;
@@ -788,7 +792,19 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         issue_region(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[i & 7] = mma32x32(frag(lbase + FS_STAGE, i), (i >> 3) ? hk1 : hk0, out[i & 7]);
-        // ---- residual update in place: lane = token, columns 32 ct + 8 j + 4 h .. + 3; rounds of 8 pieces, next round's reads first
+        [[maybe_unused]] auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qstream, 0, 24 * FS_STAGE, 0x00020000);
+        // qkv stage n (part n / 8 of q | k | v, head n % 8; 16 fragments) into slot 0's second half (even n) or slot 1's first half (odd n)
+        [[maybe_unused]] auto issue_q = [&](int n) {
+            unsigned char* dst = smem + ((n & 1) ? 2 * FS_STAGE : FS_STAGE) + wid * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, voff,
+                                                         n * FS_STAGE + wid * 4096 + q * 1024, 0, 0);
+        };
+        if constexpr (QKV) {
+            fs_barrier();      // every wave is done with region 32's fragments (slot 0, second half)
+            issue_q(0);
+        }
         FS_STAMP(blk_i, 2);
         if (FS_ABL(2)) { asm volatile("" :: "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7])); continue; }
         {
@@ -804,6 +820,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
             [[maybe_unused]] int w16 = x16_out != nullptr;
             asm volatile("" : "+v"(w16));   // a per-lane predicate: the store loop is masked, not duplicated (the duplicate spilled)
             float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs_[4] = {1.f, 1.f, 1.f, 1.f};
+            [[maybe_unused]] s16x8 yk[16];
             if constexpr (LNOUT) {   // LayerNorm statistics of the updated row (two-pass, as layer_norm_fast_kernel)
 #pragma unroll
                 for (int ct = 0; ct < 8; ++ct)
@@ -829,14 +846,32 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                     }
                 sq += __shfl_xor(sq, 32);
                 const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + eps);
-                {
-                    int rl = r;
-                    asm volatile("" : "+v"(rl));   // (its address is formed here, not kept in a spilled register since kernel entry)
-                    if (h == 0) { stat[2 * rl] = mean; stat[2 * rl + 1] = rstd; }
-                }
-                fs_wave_lds_fence();
+                if constexpr (QKV) {   // the normalised row as K-step fragments, straight from accumulator layout (as the prologue's)
+                    const float* s_ng4 = reinterpret_cast<const float*>(smem + ML_OFF_NXG) + 4 * h;
+                    const float* s_nb4 = reinterpret_cast<const float*>(smem + ML_OFF_NXB) + 4 * h;
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) { mu[i2] = stat[2 * (rr + 8 * i2)]; rs_[i2] = stat[2 * (rr + 8 * i2) + 1]; }
+                    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            f32x4 y[2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int j = 2 * kk + q;
+                                const f32x4 gv = *reinterpret_cast<const f32x4*>(s_ng4 + 32 * ct + 8 * j), bv = *reinterpret_cast<const f32x4*>(s_nb4 + 32 * ct + 8 * j);
+                                y[q] = (f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]} - mean) * rstd * gv + bv;
+                            }
+                            yk[2 * ct + kk] = pack8(y[0], y[1]);
+                        }
+                } else {
+                    {
+                        int rl = r;
+                        asm volatile("" : "+v"(rl));   // (its address is formed here, not kept in a spilled register since kernel entry)
+                        if (h == 0) { stat[2 * rl] = mean; stat[2 * rl + 1] = rstd; }
+                    }
+                    fs_wave_lds_fence();
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) { mu[i2] = stat[2 * (rr + 8 * i2)]; rs_[i2] = stat[2 * (rr + 8 * i2) + 1]; }
+                }
             }
             const float* s_ng = reinterpret_cast<const float*>(smem + ML_OFF_NXG) + cc;
             const float* s_nb = reinterpret_cast<const float*>(smem + ML_OFF_NXB) + cc;
@@ -850,12 +885,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                 }
                 fs_wave_lds_fence();
                 f32x4 gv = {1.f, 1.f, 1.f, 1.f}, bv = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (LNOUT) { gv = *reinterpret_cast<const f32x4*>(s_ng + 32 * ct); bv = *reinterpret_cast<const f32x4*>(s_nb + 32 * ct); }
+                if constexpr (LNOUT && !QKV) { gv = *reinterpret_cast<const f32x4*>(s_ng + 32 * ct); bv = *reinterpret_cast<const f32x4*>(s_nb + 32 * ct); }
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) {
                     const f32x4 vv = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc);
                     *reinterpret_cast<f32x4*>(xw + (size_t)(8 * i2) * D + 32 * ct) = vv;
-                    if constexpr (LNOUT) {
+                    if constexpr (QKV) {
+                    } else if constexpr (LNOUT) {
                         const f32x4 y = (vv - mu[i2]) * rs_[i2] * gv + bv;
                         *reinterpret_cast<s16x4*>(xw16 + (size_t)(8 * i2) * D + 32 * ct) = pack4(y);
                     } else {
@@ -864,6 +900,58 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                 }
                 fs_wave_lds_fence();
             }
+            if constexpr (QKV) {
+                // ---- the next block's spatial qkv Linear on the normalised rows (attention.py:37 of st_transformer.py:74's call), written as the
+                // operand planes spatial_attn_proj_bf16_kernel streams: Q (x scale log2 e) and K head-major [(seq, head)][pos][32],
+                // V^T [(seq, head)][feature][256 keys, each 16-group stored {0-3, 8-11, 4-7, 12-15}] -- the formats of gemm16_pp's G16X_QKV.
+                short* tl = reinterpret_cast<short*>(smem + 3 * FS_STAGE + wid * 4096);   // 32 rows x 40 shorts (64 bytes + pad)
+                const long row0 = (long)blk * 128 + wid * 32;
+                const long seq = row0 >> 8;
+                const int pos0 = (int)(row0 & 255);
+                uint16_t* planes = x16_out;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));       // (everything lane-derived below is formed here, per block: hoisted to kernel entry it is spilled)
+                const int t4 = ln >> 2, pc = (ln & 3) * 8, rq = ln & 31, hq = ln >> 5;
+                for (int n = 0; n < 24; ++n) {
+                    fs_wait_vm<0>();
+                    fs_barrier();      // stage n landed for every wave; the other half is free (n = 0: everyone's phase above is over too)
+                    if (n + 1 < 24) issue_q(n + 1);
+                    const unsigned char* sb = smem + ((n & 1) ? 2 * FS_STAGE : FS_STAGE) + ln * 16;
+                    const int part = n >> 3, ht = n & 7;
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    if (part < 2) {    // swapped: D[feature][token]
+#pragma unroll
+                        for (int f = 0; f < 16; ++f) acc = mma32x32(frag(sb, f), yk[f], acc);
+                        const float sc = part == 0 ? qscale : 1.0f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<s16x4*>(tl + rq * 40 + 8 * j + 4 * hq) = pack4(f32x4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]} * sc);
+                        fs_wave_lds_fence();
+                        uint16_t* dst = planes + (size_t)part * P + ((size_t)(seq * 8 + ht) * 256 + pos0) * 32;
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps)
+                            *reinterpret_cast<s16x8*>(dst + (t4 + 16 * ps) * 32 + pc) = *reinterpret_cast<const s16x8*>(tl + (t4 + 16 * ps) * 40 + pc);
+                        fs_wave_lds_fence();
+                    } else {           // plain: D[token][feature] -- a lane holds 16 keys of ONE feature, in the planes' key order
+#pragma unroll
+                        for (int f = 0; f < 16; ++f) acc = mma32x32(yk[f], frag(sb, f), acc);
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2)
+                            *reinterpret_cast<s16x8*>(tl + rq * 40 + 16 * g2 + 8 * hq) =
+                                pack8(f32x4{acc[8 * g2], acc[8 * g2 + 1], acc[8 * g2 + 2], acc[8 * g2 + 3]},
+                                      f32x4{acc[8 * g2 + 4], acc[8 * g2 + 5], acc[8 * g2 + 6], acc[8 * g2 + 7]});
+                        fs_wave_lds_fence();
+                        uint16_t* dst = planes + (size_t)2 * P + ((size_t)(seq * 8 + ht) * 32) * 256 + pos0;
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps)
+                            *reinterpret_cast<s16x8*>(dst + (size_t)(t4 + 16 * ps) * 256 + pc) = *reinterpret_cast<const s16x8*>(tl + (t4 + 16 * ps) * 40 + pc);
+                        fs_wave_lds_fence();
+                    }
+                }
+                fs_barrier();          // slot 1 and the tiles are free before anyone's next prologue writes its tile there
+            }
         }
         FS_STAMP(blk_i, 3);
     }
@@ -871,33 +959,60 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
     fs_wait_vm<0>();
 }
 
+// the next block's spatial qkv weights (768, 256) as 24 stages of 16 fragments (stage = part x head; fragment f = 2 ct + kk contracts the
+// features of accumulator half-tile (ct, kk), as pack_mlp_fused_kernel's fc1 fragments)
+__global__ void pack_spatial_qkv_kernel(const float* __restrict__ qkv_w, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 24 * 16 * 64 * 8) return;
+    const int e = i & 7, l = (i >> 3) & 63, f = (i >> 9) & 15, n = i >> 13;
+    const int h = l >> 5, rr = l & 31;
+    out[i] = f32_to_bf16(qkv_w[(size_t)((n >> 3) * 256 + (n & 7) * 32 + rr) * 256 + 32 * (f >> 1) + 16 * (f & 1) + (e & 3) + 8 * (e >> 2) + 4 * h]);
+}
+
+int launch_pack_spatial_qkv(const float* qkv_w, uint16_t* out, hipStream_t st) {
+    pack_spatial_qkv_kernel<<<(24 * 16 * 64 * 8) / 256, 256, 0, st>>>(qkv_w, out);
+    GENIE_LAUNCH_CHECK("pack_spatial_qkv");
+    return GENIE_OK;
+}
+
 // x += Mlp(LayerNorm(x)) on (rows, 256); x16_out (optional): bf16 shadow of the result, or -- when nx_g / nx_b are given --
 // LayerNorm(result; nx_g, nx_b) as bf16.  GENIE_E_UNSUPPORTED outside the geometry.
 int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,
-                          const float* nx_g, const float* nx_b) {
+                          const float* nx_g, const float* nx_b, const uint16_t* nx_qkv_stream, uint16_t* planes) {
     if (!lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < 128 * 256 || !lw.norm2_w ||
         !lw.norm2_b)
         return GENIE_E_UNSUPPORTED;
-    GENIE_CHECK_ARG((nx_g == nullptr) == (nx_b == nullptr) && (!nx_g || x16_out), "mlp_fused: next-norm parameters need both pointers and x16_out");
+    GENIE_CHECK_ARG((nx_g == nullptr) == (nx_b == nullptr) && (!nx_g || x16_out || planes), "mlp_fused: next-norm parameters need both pointers and an output");
+    // planes: the next block's spatial operand planes instead of its norm1 output (needs its qkv fragment stream, no qkv bias,
+    // sequences of 256 tokens -- a wave's 32 rows never straddle one -- and the scalar offsets of the planes inside 2^31)
+    const bool qkv = planes && nx_qkv_stream && nx_g && !c.qkv_bias && c.S == 256 && c.num_heads == 8 && c.head_dim == 32 && rows % 256 == 0 &&
+                     (double)rows * 256 * 2 * 3 < 2.0e9 * 4;
+    if (planes && !qkv) return GENIE_E_UNSUPPORTED;
     const int n_blocks = (int)(rows / 128);
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = n_blocks < 2 * cus ? n_blocks : 2 * cus;
-    ProfScope prof(GENIE_KC_FUSED, (double)rows * 4.0 * 256 * 1024, (double)rows * (2048.0 + (x16_out ? 512.0 : 0.0)), st,
-                   "mlp_fused_bf16_kernel (LayerNorm + fc1 + GELU + fc2 + residual)");
+    ProfScope prof(GENIE_KC_FUSED, (double)rows * (4.0 * 256 * 1024 + (qkv ? 2.0 * 256 * 768 : 0.0)),
+                   (double)rows * (2048.0 + (qkv ? 1536.0 : x16_out ? 512.0 : 0.0)), st,
+                   qkv ? "mlp_fused_bf16_kernel<2> (LayerNorm + fc1 + GELU + fc2 + residual + next block's LayerNorm + spatial qkv planes)"
+                       : "mlp_fused_bf16_kernel (LayerNorm + fc1 + GELU + fc2 + residual)");
     const float* fb1 = c.mlp_bias ? lw.fc1_b : nullptr;
     const float* fb2 = c.mlp_bias ? lw.fc2_b : nullptr;
     const int abl = study_env("GENIE_FUSED_ABL", 0);
     fs_stamps_prepare();
-    if (nx_g) {
-        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
-        mlp_fused_bf16_kernel<true><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nx_g, nx_b,
-                                                               n_blocks, 1e-5f, abl);
+    if (qkv) {
+        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        mlp_fused_bf16_kernel<2><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, planes, nx_g, nx_b, n_blocks,
+                                                            1e-5f, abl, nx_qkv_stream, rows * 256, c.attn_scale * 1.4426950408889634f);
+    } else if (nx_g) {
+        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        mlp_fused_bf16_kernel<1><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nx_g, nx_b,
+                                                            n_blocks, 1e-5f, abl, nullptr, 0, 0.f);
     } else {
-        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
-        mlp_fused_bf16_kernel<false><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nullptr,
-                                                                nullptr, n_blocks, 1e-5f, abl);
+        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        mlp_fused_bf16_kernel<0><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nullptr,
+                                                            nullptr, n_blocks, 1e-5f, abl, nullptr, 0, 0.f);
     }
     GENIE_LAUNCH_CHECK("mlp_fused_bf16");
     return GENIE_OK;

@@ -98,9 +98,12 @@ class _Packer:
     def spatial_fused(self, attn):
         if not (self._fused_geometry() and self.config.S == 256):
             return 0
-        t = torch.empty(_lib.SPATIAL_PROJ_FUSED_ELEMS, dtype=torch.bfloat16, device=self.dev)
+        # [out-projection stream | qkv stream]: the second part lets the previous block's fused MLP kernel write this block's operand planes
+        t = torch.empty(_lib.SPATIAL_PROJ_FUSED_ELEMS + _lib.SPATIAL_QKV_FUSED_ELEMS, dtype=torch.bfloat16, device=self.dev)
         _lib.check(self.lib.genie_pack_spatial_proj_fused_bf16(attn.proj.weight.data_ptr(), t.data_ptr(), self._stream()),
                    "genie_pack_spatial_proj_fused_bf16")
+        _lib.check(self.lib.genie_pack_spatial_qkv_fused_bf16(attn.qkv.weight.data_ptr(), t.data_ptr() + 2 * _lib.SPATIAL_PROJ_FUSED_ELEMS,
+                                                              self._stream()), "genie_pack_spatial_qkv_fused_bf16")
         self.keep.append(t)
         return t.data_ptr()
 

@@ -4,6 +4,7 @@ Same constructors and parameter names as the reference.  ``forward`` takes and r
 reference's ``(B, T, S, C)`` tensor; internally nothing is permuted: the temporal kernel reads
 frame-strided rows instead of materialising ``(B S) T C`` (reference :77,:82).
 """
+import os
 import torch
 import torch.nn as nn
 
@@ -38,6 +39,8 @@ def _attn_struct(a: SelfAttention, packed=None, temporal=False) -> _lib.AttnWeig
         s.qkv_w16, s.proj_w16 = packed(a.qkv.weight), packed(a.proj.weight)
         s.w16_wide = (_lib.WIDE_QKV if packed.is_wide(s.qkv_w16) else 0) | (_lib.WIDE_PROJ if packed.is_wide(s.proj_w16) else 0)
         s.fused_w16 = packed.temporal_fused(a) if temporal else packed.spatial_fused(a)
+        if not temporal and s.fused_w16 and os.environ.get("GENIE_NO_FUSED_QKV", "0") != "1":
+            s.w16_wide |= _lib.FUSED_QKV_STREAM
     return s
 
 

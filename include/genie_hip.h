@@ -137,7 +137,8 @@ int genie_pack_split_f16(const float* src, uint16_t* dst, size_t n, void* stream
  * tensor then runs on the two-accumulator kernels, which scale nothing (same f32-class result, lower rate for that tensor
  * only).  The flag travels with the weight table: there is no process-global state.
  * Reference counterpart: none (the reference's Linear layers are f32: st_transformer.py:16-25, attention.py:27-29). */
-enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_FC2 = 2 };
+enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_FC2 = 2,
+       GENIE_FUSED_QKV_STREAM = 4 /* genie_attn_weights.w16_wide of a SPATIAL attention: fused_w16 also holds the qkv fragment stream (below) */ };
 
 /* Fragment streams of the fused sub-block kernels (GENIE_PREC_BF16, magvit_n32_h8_d256 geometry; csrc/kernels_fused.hip).
  * temporal: qkv_w (768, 256) and proj_w (256, 256) f32 -> 262,144 bf16 values;  mlp: fc1_w (1024, 256) and fc2_w (256, 1024)
@@ -145,6 +146,11 @@ enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_F
 #define GENIE_TEMPORAL_FUSED_ELEMS 262144
 #define GENIE_MLP_FUSED_ELEMS 524288
 #define GENIE_SPATIAL_PROJ_FUSED_ELEMS 65536 /* spatial: proj_w (256, 256) f32 -> the out-projection's fragments per head */
+/* spatial, optional second part of the same buffer (at element GENIE_SPATIAL_PROJ_FUSED_ELEMS): qkv_w (768, 256) f32 -> 24 stages of 16
+ * fragments.  With it (and GENIE_FUSED_QKV_STREAM set) the PREVIOUS block's fused MLP kernel also runs this block's norm1 and spatial qkv
+ * Linear (st_transformer.py:74, attention.py:37) and writes the attention kernel's operand planes: no LayerNorm, no qkv GEMM launch. */
+#define GENIE_SPATIAL_QKV_FUSED_ELEMS 196608
+#define GENIE_SPATIAL_FUSED_ELEMS (GENIE_SPATIAL_PROJ_FUSED_ELEMS + GENIE_SPATIAL_QKV_FUSED_ELEMS)
 int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream);
 /* Unit entry points of the fused sub-blocks (parity tests, tuning).  Both update the f32 residual stream x in place and return
  * GENIE_E_UNSUPPORTED outside the geometry above (the layer drivers then run the unfused launches).
@@ -164,6 +170,7 @@ int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, fl
                          const float* next_norm_w, const float* next_norm_b, void* stream);
 int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream);
 int genie_pack_spatial_proj_fused_bf16(const float* proj_w, uint16_t* dst, void* stream);
+int genie_pack_spatial_qkv_fused_bf16(const float* qkv_w, uint16_t* dst, void* stream);   /* dst: GENIE_SPATIAL_QKV_FUSED_ELEMS values */
 
 /* ---- unit entry points (one reference op each; used by the parity tests) -------------------------- */
 
