@@ -859,8 +859,12 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     bool qkv_done = false, proj_done = false;
     if (w.qkv_planes_done) {   // the previous block's fused MLP kernel left this block's operand planes in `big`
         w.qkv_planes_done = false;
-        GENIE_TRY(launch_spatial_attn_proj_bf16(c, lw.spatial, (const uint16_t*)w.big, x, x16, (long)B * c.T, st));
-        qkv_done = true; proj_done = true; rc = GENIE_OK;
+        rc = launch_spatial_attn_proj_bf16(c, lw.spatial, (const uint16_t*)w.big, x, x16, (long)B * c.T, st);
+        if (rc == GENIE_OK) proj_done = true;
+        else if (rc == GENIE_E_UNSUPPORTED)   // (fewer than 256 sequences: the stand-alone attention kernel reads the same planes, proj GEMM below)
+            rc = launch_attn_spatial_dma(1, (uint16_t*)w.big, (long)B * c.T, d, c.num_heads, c.head_dim, xn16, 0, st);
+        GENIE_TRY(rc);
+        qkv_done = true;
     }
     if (!qkv_done && !c.qk_norm) {  // one-frame passes: LayerNorm inside the small GEMM's fragment path (no LayerNorm launch)
         const int r2 = launch_gemm16_sm_ln(1, x, d, lw.norm1_w, lw.norm1_b, 1e-5f, lw.spatial.qkv_w16, d, 0,

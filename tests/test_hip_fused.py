@@ -153,3 +153,33 @@ def test_mlp_fused_entry_point_vs_oracle(lnout):
     else:
         assert (d16 == 0).all()
     assert lib.genie_mlp_fused_bf16(cfg, lw, xd.data_ptr(), 0, 100, 0, 0, st) != 0     # rows % 128 != 0: refused
+
+
+def test_qkv_planes_from_the_mlp_kernel_match_the_qkv_gemm(monkeypatch):
+    """Mode 2 of the fused MLP kernel (the next block's norm1 + spatial qkv Linear, st_transformer.py:74 / attention.py:37, written as the
+    attention kernel's operand planes) against the same model with that hand-off switched off (LayerNorm'd row out, qkv GEMM launch):
+    the same bf16 operands and rounding points, another summation order."""
+    cfg = pkg("config").GenieConfig(num_layers=3, num_heads=8, d_model=256, T=16, S=256, num_factored_vocabs=2, qk_norm=False,
+                                    use_mup=False)
+    synth = pkg("synthetic")
+    sd = synth.make_state_dict(cfg, seed=91, law="conditioned")
+    B = 9
+    ids = synth.make_clips(B, cfg, seed=92)
+    x = ids.reshape(B, 16, 16, 16).copy()
+    x[:, 10:] = cfg.image_vocab_size
+    monkeypatch.setenv("GENIE_NO_FUSED_QKV", "0")
+    ma = _model(cfg, sd, True, monkeypatch)
+    assert all(l.spatial.w16_wide & pkg("_lib").FUSED_QKV_STREAM for l in ma._weights()[2])
+    ha = ma.hidden_states(dev(x)).cpu().numpy().copy()
+    monkeypatch.setenv("GENIE_NO_FUSED_QKV", "1")
+    mb = _model(cfg, sd, True, monkeypatch)
+    assert not any(l.spatial.w16_wide & pkg("_lib").FUSED_QKV_STREAM for l in mb._weights()[2])
+    hb = mb.hidden_states(dev(x)).cpu().numpy().copy()
+    scale = np.abs(hb).max()
+    d = np.abs(ha - hb)
+    print("planes from the MLP kernel vs qkv GEMM: max", d.max(), "median", np.median(d), "scale", scale)
+    assert np.isfinite(ha).all() and d.max() < 5e-2 * scale and np.median(d) < 1e-3 * scale
+    ref = O.hidden_states(x[:1], sd, cfg, O.BF16_MFMA)[0]
+    ea, eb = np.abs(ha[0] - ref), np.abs(hb[0] - ref)
+    print("vs oracle: with", ea.max(), np.median(ea), " without", eb.max(), np.median(eb))
+    assert np.median(ea) < 2.0 * np.median(eb) + 1e-6
