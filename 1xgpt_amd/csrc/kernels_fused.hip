@@ -6,8 +6,18 @@
 //   temporal_fused_bf16_kernel   x += proj_t( causal-attention_T( qkv_t( bf16(x) ) ) )   (st_transformer.py:77-78,
 //                                attention.py:36-61): replaces qkv GEMM + temporal attention + proj GEMM
 //                                (403 + 403 MB of qkv written and re-read, 134 + 134 MB of attention output per layer at 64 clips).
+//   mlp_fused_bf16_kernel<MODE>  x += fc2( gelu( fc1( LayerNorm(x) ) ) )   (st_transformer.py:81, 16-25); MODE 1 also writes the NEXT
+//                                block's norm1(x) as bf16, MODE 2 instead runs that block's norm1 AND spatial qkv Linear
+//                                (st_transformer.py:74, attention.py:37) and writes its attention operand planes.
+//   spatial_attn_proj_bf16_kernel  x += proj_s( softmax(q k^T) v )  over the 256 positions of a frame, from those planes
+//                                (st_transformer.py:73-74, attention.py:48-60); also the bf16 shadow of x for the temporal kernel.
+//   => three launches per block.  Two rules shaped all three: (1) an accumulator layout is made the next
+//   product's operand layout (weights packed in the matching K order), so nothing is re-laid between products; (2) every exposed row
+//   access to HBM goes row-major through a wave-private LDS tile -- an instruction that touches 32 row PIECES costs like one that
+//   moves 8 whole 128-byte lines -- and addresses used only in an epilogue are formed there (behind an empty asm), or the compiler
+//   hoists them above the main loop and spills them.
 //
-// Common structure ("lane = token"):
+// The temporal kernel ("lane = token"):
 //   * every matrix instruction is v_mfma_f32_16x16x32_bf16 (16x16x16 for the 16-key P.V product).  A 16-token group is one
 //     spatial position's 16 frames; a wave owns G = 2 groups.  A group's operand fragment (lane: token l & 15, k-group l >> 4,
 //     8 consecutive k) is loaded ONCE from the bf16 shadow of x and serves as the B operand of the "swapped" products
