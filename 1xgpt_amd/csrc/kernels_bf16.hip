@@ -861,7 +861,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
         w.qkv_planes_done = false;
         rc = launch_spatial_attn_proj_bf16(c, lw.spatial, (const uint16_t*)w.big, x, x16, (long)B * c.T, st);
         if (rc == GENIE_OK) proj_done = true;
-        else if (rc == GENIE_E_UNSUPPORTED)   // (fewer than 256 sequences: the stand-alone attention kernel reads the same planes, proj GEMM below)
+        else if (rc == GENIE_E_UNSUPPORTED)   // (fewer sequences than the fused kernel takes: the stand-alone attention kernel reads the same planes, proj GEMM below)
             rc = launch_attn_spatial_dma(1, (uint16_t*)w.big, (long)B * c.T, d, c.num_heads, c.head_dim, xn16, 0, st);
         GENIE_TRY(rc);
         qkv_done = true;

@@ -987,9 +987,12 @@ int launch_pack_spatial_qkv(const float* qkv_w, uint16_t* out, hipStream_t st) {
 
 // x += Mlp(LayerNorm(x)) on (rows, 256); x16_out (optional): bf16 shadow of the result, or -- when nx_g / nx_b are given --
 // LayerNorm(result; nx_g, nx_b) as bf16.  GENIE_E_UNSUPPORTED outside the geometry.
+#ifndef GENIE_VAR_M_MIN_CLIPS
+#define GENIE_VAR_M_MIN_CLIPS 2   // fewest clips' worth of rows (4,096 each; same measurement)
+#endif
 int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,
                           const float* nx_g, const float* nx_b, const uint16_t* nx_qkv_stream, uint16_t* planes) {
-    if (!lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < 128 * 256 || !lw.norm2_w ||
+    if (!lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < GENIE_VAR_M_MIN_CLIPS * 4096 || !lw.norm2_w ||
         !lw.norm2_b)
         return GENIE_E_UNSUPPORTED;
     GENIE_CHECK_ARG((nx_g == nullptr) == (nx_b == nullptr) && (!nx_g || x16_out || planes), "mlp_fused: next-norm parameters need both pointers and an output");
@@ -1306,9 +1309,12 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
 }
 
 // x += proj_s(attention_S(planes)) and x16 = bf16(x) for n_seq sequences of 256 tokens; GENIE_E_UNSUPPORTED outside d 256 / 8 x 32
+#ifndef GENIE_VAR_S_MIN_SEQ
+#define GENIE_VAR_S_MIN_SEQ 128   // fewest sequences the fused spatial kernel takes (one workgroup each; measured: 64 sequences lose 15 %, 128 gain 5 %, 192 gain 9 % over attention + proj GEMM)
+#endif
 int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* qkv16, float* x, uint16_t* x16,
                                   long n_seq, hipStream_t st) {
-    if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.S != 256 || c.qk_norm || n_seq < 256)
+    if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.S != 256 || c.qk_norm || n_seq < GENIE_VAR_S_MIN_SEQ)
         return GENIE_E_UNSUPPORTED;
     const long P = n_seq * 256 * 256;
     if ((double)P * 2 + 4096.0 * 256 >= 2.0e9) return GENIE_E_UNSUPPORTED;   // 32-bit scalar offsets inside the plane descriptors
@@ -1330,11 +1336,14 @@ int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& 
     return GENIE_OK;
 }
 
+#ifndef GENIE_VAR_T_MIN_CLIPS
+#define GENIE_VAR_T_MIN_CLIPS 2   // (measured at 1 / 2 / 3 / 4 / 6 clips: 1 clip is 14 % slower fused, from 2 clips on 6-30 % faster)
+#endif
 // x += proj_t(attention_T(qkv_t(x16))) on dense (B, 16, S, 256) buffers; GENIE_E_UNSUPPORTED for any other geometry
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
                                hipStream_t st) {
     if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.T != 16 || c.S % 8 || c.qk_norm ||
-        (long)B * c.S < 8 * 256)
+        (long)B * c.S < GENIE_VAR_T_MIN_CLIPS * 256)
         return GENIE_E_UNSUPPORTED;
     const int n_blocks = B * c.S / 8;
     int dev = 0, cus = 256;
