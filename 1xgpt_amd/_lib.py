@@ -119,6 +119,7 @@ SIGNATURES = {
     "genie_pack_mlp_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_pack_spatial_proj_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "genie_pack_spatial_qkv_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
+    "genie_mlp_fused_qkv_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(LayerWeights), C.POINTER(LayerWeights), c_ptr, c_ptr, C.c_int64, c_ptr]),
     "genie_spatial_attn_proj_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
     "genie_temporal_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, c_ptr]),
     "genie_mlp_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(LayerWeights), c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),

@@ -698,6 +698,15 @@ int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, fl
     GENIE_CHECK_ARG(lw && x && rows >= 0, "mlp_fused: bad argument");
     return launch_mlp_fused_bf16(*cfg, *lw, x, x16_out, (long)rows, as_stream(stream), next_norm_w, next_norm_b);
 }
+int genie_mlp_fused_qkv_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, const genie_layer_weights* next, float* x,
+                             uint16_t* planes, int64_t rows, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(lw && next && x && planes && rows >= 0, "mlp_fused_qkv: bad argument");
+    if (!next->spatial.fused_w16 || !(next->spatial.w16_wide & GENIE_FUSED_QKV_STREAM) || !next->norm1_w || !next->norm1_b)
+        return GENIE_E_UNSUPPORTED;
+    return launch_mlp_fused_bf16(*cfg, *lw, x, nullptr, (long)rows, as_stream(stream), next->norm1_w, next->norm1_b,
+                                 next->spatial.fused_w16 + GENIE_SPATIAL_PROJ_FUSED_ELEMS, planes);
+}
 int genie_pack_spatial_proj_fused_bf16(const float* proj_w, uint16_t* dst, void* stream) {
     GENIE_CHECK_ARG(proj_w && dst, "pack_spatial_proj_fused: NULL pointer");
     return launch_pack_spatial_proj(proj_w, dst, as_stream(stream));

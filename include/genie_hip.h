@@ -168,6 +168,15 @@ int genie_spatial_attn_proj_fused_bf16(const genie_cfg* cfg, const genie_attn_we
                                        uint16_t* x16, int64_t n_seq, void* stream);
 int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, float* x, uint16_t* x16_out, int64_t rows,
                          const float* next_norm_w, const float* next_norm_b, void* stream);
+/* The same kernel in the form the block driver uses between two blocks: besides x += mlp(...) it runs the NEXT block's norm1 and spatial qkv
+ * Linear (next->norm1_*, next->spatial.fused_w16 with GENIE_FUSED_QKV_STREAM) and writes that block's attention operand planes into
+ * `planes` (3 * rows * 256 bf16 values: [Q | K | V^T]; sequences of 256 consecutive rows, 8 heads of 32):
+ *   Q[((seq * 8 + head) * 256 + pos) * 32 + f]   = q * attn_scale * log2(e)          K likewise, unscaled
+ *   V^T[((seq * 8 + head) * 32 + f) * 256 + p']  with p' = 16 * (pos / 16) + perm(pos % 16), perm = {0-3 -> 0-3, 8-11 -> 4-7, 4-7 -> 8-11, 12-15 -> 12-15}
+ * (the formats genie_spatial_attn_proj_fused_bf16 consumes).  GENIE_E_UNSUPPORTED with qkv_bias or outside the geometry.
+ * Reference: st_transformer.py:81 then :74 (norm1) and attention.py:37 (qkv) of the following block. */
+int genie_mlp_fused_qkv_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, const genie_layer_weights* next, float* x,
+                             uint16_t* planes, int64_t rows, void* stream);
 int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream);
 int genie_pack_spatial_proj_fused_bf16(const float* proj_w, uint16_t* dst, void* stream);
 int genie_pack_spatial_qkv_fused_bf16(const float* qkv_w, uint16_t* dst, void* stream);   /* dst: GENIE_SPATIAL_QKV_FUSED_ELEMS values */

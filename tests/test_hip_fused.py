@@ -183,3 +183,59 @@ def test_qkv_planes_from_the_mlp_kernel_match_the_qkv_gemm(monkeypatch):
     ea, eb = np.abs(ha[0] - ref), np.abs(hb[0] - ref)
     print("vs oracle: with", ea.max(), np.median(ea), " without", eb.max(), np.median(eb))
     assert np.median(ea) < 2.0 * np.median(eb) + 1e-6
+
+
+def test_mlp_fused_qkv_entry_point_planes_vs_oracle():
+    """genie_mlp_fused_qkv_bf16: x += mlp(norm2(x)) and, from the result, the NEXT block's norm1 + spatial qkv Linear as the attention
+    kernel's operand planes (st_transformer.py:81, then :74 / attention.py:37 of the following block).  Every plane element is
+    compared with the oracle's value at the index the header documents (Q x scale x log2 e, K, V^T with its key order)."""
+    _lib, lib, c, cfg, st = _unit_setup()
+    g = np.random.default_rng(13)
+    rows = 2 * 4096                      # 32 sequences of 256 rows
+    x = (g.standard_normal((rows, 256)) * 2.0 + g.standard_normal((rows, 1))).astype(np.float32)
+    sd = {"p.fc1.weight": (g.standard_normal((1024, 256)) * 0.06).astype(np.float32), "p.fc1.bias": (g.standard_normal(1024) * 0.1).astype(np.float32),
+          "p.fc2.weight": (g.standard_normal((256, 1024)) * 0.04).astype(np.float32), "p.fc2.bias": (g.standard_normal(256) * 0.1).astype(np.float32)}
+    ln_g, ln_b = (1 + 0.2 * g.standard_normal(256)).astype(np.float32), (0.1 * g.standard_normal(256)).astype(np.float32)
+    nx_g, nx_b = (1 + 0.2 * g.standard_normal(256)).astype(np.float32), (0.1 * g.standard_normal(256)).astype(np.float32)
+    wqkv = (g.standard_normal((768, 256)) * 0.08).astype(np.float32)
+    t = {k: dev(v) for k, v in sd.items()}
+    lg, lb, ng, nb, wq = dev(ln_g), dev(ln_b), dev(nx_g), dev(nx_b), dev(wqkv)
+    mf = torch.empty(_lib.MLP_FUSED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_pack_mlp_fused_bf16(t["p.fc1.weight"].data_ptr(), t["p.fc2.weight"].data_ptr(), mf.data_ptr(), st), "pack")
+    sf = torch.zeros(_lib.SPATIAL_PROJ_FUSED_ELEMS + _lib.SPATIAL_QKV_FUSED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_pack_spatial_qkv_fused_bf16(wq.data_ptr(), sf.data_ptr() + 2 * _lib.SPATIAL_PROJ_FUSED_ELEMS, st), "pack qkv")
+    lw = _lib.LayerWeights()
+    lw.mlp_fused_w16 = mf.data_ptr()
+    lw.norm2_w, lw.norm2_b, lw.fc1_b, lw.fc2_b = lg.data_ptr(), lb.data_ptr(), t["p.fc1.bias"].data_ptr(), t["p.fc2.bias"].data_ptr()
+    nx = _lib.LayerWeights()
+    nx.norm1_w, nx.norm1_b = ng.data_ptr(), nb.data_ptr()
+    nx.spatial.fused_w16, nx.spatial.w16_wide = sf.data_ptr(), _lib.FUSED_QKV_STREAM
+    xd = dev(x)
+    planes = torch.zeros(3, rows, 256, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_mlp_fused_qkv_bf16(cfg, lw, nx, xd.data_ptr(), planes.data_ptr(), rows, st), "mlp_fused_qkv")
+    got = xd.cpu().numpy()
+    ref = x + O.mlp(O.layer_norm(x, ln_g, ln_b), sd, "p.", c, O.BF16_MFMA)
+    upd = np.abs(ref - x).max()
+    assert np.abs(got - ref).max() < 2e-2 * upd
+    # the planes are a function of the kernel's own f32 rows: norm1 -> bf16 operands -> qkv -> bf16
+    y = O.round_bf16(O.layer_norm(got, nx_g, nx_b))
+    qkv = y @ O.round_bf16(wqkv).T                                    # (rows, 768): q | k | v, each 8 heads x 32
+    pl = _bf16_bits_to_f32(planes).reshape(3, rows // 256, 8, -1)     # [part][seq][head][...]
+    n_seq = rows // 256
+    qk_scale = c.attn_scale * 1.4426950408889634
+    want_q = (qkv[:, :256] * qk_scale).reshape(n_seq, 256, 8, 32).transpose(0, 2, 1, 3)      # [seq][head][pos][f]
+    want_k = qkv[:, 256:512].reshape(n_seq, 256, 8, 32).transpose(0, 2, 1, 3)
+    v = qkv[:, 512:].reshape(n_seq, 256, 8, 32).transpose(0, 2, 3, 1)                         # [seq][head][f][pos]
+    perm = np.array([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])                   # stored position p' holds key perm[p'] of its 16-group
+    want_v = v.reshape(n_seq, 8, 32, 16, 16)[..., perm].reshape(n_seq, 8, 32, 256)
+    for name, gotp, want in (("q", pl[0].reshape(n_seq, 8, 256, 32), want_q), ("k", pl[1].reshape(n_seq, 8, 256, 32), want_k),
+                             ("v^T", pl[2].reshape(n_seq, 8, 32, 256), want_v)):
+        d = np.abs(gotp - want)
+        tol = np.abs(want) * 2.0 ** -7 + 1e-2 * np.abs(want).max() * 2.0 ** -7     # one bf16 ulp of the value + a sliver of the scale
+        bad = np.mean(d > tol)
+        print(name, "plane: max err", d.max(), "beyond one ulp:", bad)
+        assert bad < 2e-3 and d.max() < 0.05 * np.abs(want).max(), name
+    # with a qkv bias the kernel must refuse (the driver then runs LayerNorm'd row + qkv GEMM)
+    cb = _lib.make_cfg(pkg("config").GenieConfig(num_layers=32, num_heads=8, d_model=256, T=16, S=256, num_factored_vocabs=2,
+                                                 qk_norm=False, use_mup=False, qkv_bias=True), _lib.PREC_BF16)
+    assert lib.genie_mlp_fused_qkv_bf16(cb, lw, nx, xd.data_ptr(), planes.data_ptr(), rows, st) != 0

@@ -65,6 +65,17 @@ def main():
     timed("mlp_fused +LN ", lambda: _lib.check(lib.genie_mlp_fused_bf16(cfg, lw, x.data_ptr(), x16.data_ptr(), rows, lg.data_ptr(),
                                                                          lb.data_ptr(), st), "m"),
           rows * 4.0 * 256 * 1024, rows * 2560.0)
+    # mode 2: also the next block's norm1 + spatial qkv planes
+    wq = r(768, 256) * 0.05
+    sf = torch.zeros(_lib.SPATIAL_PROJ_FUSED_ELEMS + _lib.SPATIAL_QKV_FUSED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_pack_spatial_qkv_fused_bf16(wq.data_ptr(), sf.data_ptr() + 2 * _lib.SPATIAL_PROJ_FUSED_ELEMS, st), "pack_q")
+    nx = _lib.LayerWeights()
+    nx.norm1_w, nx.norm1_b = lg.data_ptr(), lb.data_ptr()
+    nx.spatial.fused_w16, nx.spatial.w16_wide = sf.data_ptr(), _lib.FUSED_QKV_STREAM
+    planes = torch.empty(3, rows, 256, dtype=torch.bfloat16, device="cuda")
+    x.copy_(r(rows, 256))
+    timed("mlp_fused +QKV", lambda: _lib.check(lib.genie_mlp_fused_qkv_bf16(cfg, lw, nx, x.data_ptr(), planes.data_ptr(), rows, st), "mq"),
+          rows * (4.0 * 256 * 1024 + 2.0 * 256 * 768), rows * (2048.0 + 1536.0))
 
 
 if __name__ == "__main__":
