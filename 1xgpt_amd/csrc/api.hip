@@ -689,7 +689,7 @@ int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint
 }
 int genie_temporal_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* x16, float* x, int B, void* stream) {
     GENIE_TRY(check_cfg(cfg));
-    GENIE_CHECK_ARG(aw && x16 && x && B >= 1, "temporal_fused: bad argument");
+    GENIE_CHECK_ARG(aw && x && B >= 1, "temporal_fused: bad argument");   // x16 == NULL: operands rounded from x itself
     return launch_temporal_fused_bf16(*cfg, *aw, x16, x, B, as_stream(stream));
 }
 int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, float* x, uint16_t* x16_out, int64_t rows,
@@ -718,7 +718,7 @@ int genie_pack_spatial_qkv_fused_bf16(const float* qkv_w, uint16_t* dst, void* s
 int genie_spatial_attn_proj_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* qkv_planes, float* x,
                                        uint16_t* x16, int64_t n_seq, void* stream) {
     GENIE_TRY(check_cfg(cfg));
-    GENIE_CHECK_ARG(aw && qkv_planes && x && x16 && n_seq >= 1, "spatial_attn_proj_fused: bad argument");
+    GENIE_CHECK_ARG(aw && qkv_planes && x && n_seq >= 1, "spatial_attn_proj_fused: bad argument");   // x16 == NULL: no bf16 shadow written
     return launch_spatial_attn_proj_bf16(*cfg, *aw, qkv_planes, x, x16, (long)n_seq, as_stream(stream));
 }
 int genie_pack_mlp_fused_bf16(const float* fc1_w, const float* fc2_w, uint16_t* dst, void* stream) {

@@ -64,6 +64,7 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
                           const float* nx_g = nullptr, const float* nx_b = nullptr, const uint16_t* nx_qkv_stream = nullptr,
                           uint16_t* planes = nullptr);
 int launch_pack_spatial_qkv(const float* qkv_w, uint16_t* out, hipStream_t st);
+bool temporal_fused_takes(const genie_cfg& c, const genie_attn_weights& aw, int B);   // will launch_temporal_fused_bf16 run this problem?
 
 // Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
 // tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.

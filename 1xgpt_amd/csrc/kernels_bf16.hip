@@ -811,7 +811,7 @@ __global__ void cast16_kernel(const float* __restrict__ src, uint16_t* __restric
 // kernels_fused.hip's spatial_attn_proj kernel (x, x16 updated, *proj_done = true: the caller skips its proj GEMM)
 static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_layer_weights& lw, const uint16_t* u, size_t planeA,
                                    size_t planeW, Workspace& w, int B, uint16_t* out16, size_t out_plane, hipStream_t st,
-                                   float* x = nullptr, uint16_t* x16 = nullptr, bool* proj_done = nullptr) {
+                                   float* x = nullptr, uint16_t* x16 = nullptr, bool* proj_done = nullptr, bool shadow16 = true) {
     static const int on = study_env("GENIE_ATTN_DMA", 1);
     const int d = c.d_model;
 #ifdef GENIE_STUDY
@@ -828,7 +828,7 @@ static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_laye
                                     G16X_OUT16 | G16X_QKV, 1.0f, st, 1, 0, 0, 0, c.attn_scale * 1.4426950408889634f, c.head_dim);
     if (rc != GENIE_OK) return rc;
     if (npl == 1 && x && x16 && proj_done) {   // shipped geometry, bf16: attention over all heads + out-projection + residual in one kernel
-        const int rf = launch_spatial_attn_proj_bf16(c, lw.spatial, qkv16, x, x16, n_seq, st);
+        const int rf = launch_spatial_attn_proj_bf16(c, lw.spatial, qkv16, x, shadow16 ? x16 : nullptr, n_seq, st);
         if (rf == GENIE_OK) { *proj_done = true; return GENIE_OK; }
         if (rf != GENIE_E_UNSUPPORTED) return rf;
     }
@@ -853,13 +853,19 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     const float* nbs = c.qk_norm ? lw.spatial.norm_b : nullptr;
     const float* nwt = c.qk_norm ? lw.temporal.norm_w : nullptr;
     const float* nbt = c.qk_norm ? lw.temporal.norm_b : nullptr;
+    // Will the temporal sub-block run as the fused kernel?  Then it rounds its operands from the f32 rows itself and the spatial kernel in
+    // front need not write the bf16 shadow of x (134 MB per layer at 64 clips it would write and the temporal kernel read).
+    static const int no_shadow_env = [] { const char* e = getenv("GENIE_T_FROM_F32"); return e ? atoi(e) : 1; }();
+    const bool fused_t = w.frame_t < 0 && !w.tqkv && !w.tcache && !w.stop_after_tqkv && temporal_qkv16(c, w.model_T) &&
+                         temporal_fused_takes(c, lw.temporal, B);
+    const bool shadow16 = !(fused_t && no_shadow_env);
     // spatial
     const uint16_t* u = x16;
     int rc = GENIE_E_UNSUPPORTED;
     bool qkv_done = false, proj_done = false;
     if (w.qkv_planes_done) {   // the previous block's fused MLP kernel left this block's operand planes in `big`
         w.qkv_planes_done = false;
-        rc = launch_spatial_attn_proj_bf16(c, lw.spatial, (const uint16_t*)w.big, x, x16, (long)B * c.T, st);
+        rc = launch_spatial_attn_proj_bf16(c, lw.spatial, (const uint16_t*)w.big, x, shadow16 ? x16 : nullptr, (long)B * c.T, st);
         if (rc == GENIE_OK) proj_done = true;
         else if (rc == GENIE_E_UNSUPPORTED)   // (fewer sequences than the fused kernel takes: the stand-alone attention kernel reads the same planes, proj GEMM below)
             rc = launch_attn_spatial_dma(1, (uint16_t*)w.big, (long)B * c.T, d, c.num_heads, c.head_dim, xn16, 0, st);
@@ -879,7 +885,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
                 GENIE_TRY(launch_layer_norm_bf16(x, lw.norm1_w, lw.norm1_b, xn16, M, d, 1e-5f, st));
             u = xn16;
         }
-        rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st, x, x16, &proj_done);
+        rc = spatial_attention_fused(1, c, lw, u, 0, 0, w, B, xn16, 0, st, x, x16, &proj_done, shadow16);
     }
     w.ln1_done = false;
     if (rc == GENIE_E_UNSUPPORTED) {
@@ -909,7 +915,8 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     if (w.frame_t < 0 && !w.tqkv && !w.tcache && !w.stop_after_tqkv && t16) {
         // plain full-clip forward of the shipped geometry: qkv + attention + proj + residual in ONE kernel, the qkv never
         // leaves the registers (kernels_fused.hip); same rounding points as the launches below
-        rc = launch_temporal_fused_bf16(c, lw.temporal, x16, x, B, st);
+        // (the bf16 shadow of x exists unless the fused spatial kernel ran and was told not to write it)
+        rc = launch_temporal_fused_bf16(c, lw.temporal, (proj_done && !shadow16) ? nullptr : x16, x, B, st);
         if (rc == GENIE_OK) temporal_done = true;
         else if (rc != GENIE_E_UNSUPPORTED) return rc;
     }

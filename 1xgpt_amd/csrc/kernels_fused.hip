@@ -207,7 +207,9 @@ __global__ void pack_temporal_fused_kernel(const float* __restrict__ qkv_w, cons
 
 // x16: (B, 16, S, 256) bf16 shadow of x (read);  x: (B, 16, S, 256) f32, updated in place.
 // A block = 8 consecutive spatial positions of one clip x 16 frames; wave w owns positions 2 w, 2 w + 1.
-template <bool QKV_BIAS>
+// XF32: the operand fragments come from the f32 rows of x themselves (row-major loads through the wave tile, rounded here) -- no bf16
+// shadow of x is read, so the spatial kernel in front need not write one.
+template <bool QKV_BIAS, bool XF32>
 __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint16_t* __restrict__ x16, float* __restrict__ x,
                                                                      const uint16_t* __restrict__ wstream,
                                                                      const float* __restrict__ qkv_b,
@@ -304,6 +306,31 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
         // this lane's token of group grp: frame r, position s0 + grp
         const size_t row0 = ((size_t)b * T + r) * S + s0;
         s16x8 xf[2][8];
+        if constexpr (XF32) {
+            float* tile = reinterpret_cast<float*>(smem + FS_RING + 4096 + wid * 2304);
+            int tt = lane >> 3, cc = (lane & 7) * 4;
+            asm volatile("" : "+v"(tt), "+v"(cc));
+            const float* xb = x + (((size_t)b * T + tt) * S + s0) * D + cc;
+            const size_t half_stride = (size_t)8 * S * D;
+            f32x4 raw[16][2];
+            auto load_slab = [&](int i) {   // slab i = (grp = i >> 3, K-step i & 7: columns 32 (i & 7) ..)
+                const float* p = xb + (i >> 3) * D + 32 * (i & 7);
+                raw[i][0] = *reinterpret_cast<const f32x4*>(p);
+                raw[i][1] = *reinterpret_cast<const f32x4*>(p + half_stride);
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_slab(i);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i + 4 < 16) load_slab(i + 4);
+                *reinterpret_cast<f32x4*>(tile + tt * 36 + cc) = raw[i][0];
+                *reinterpret_cast<f32x4*>(tile + (8 + tt) * 36 + cc) = raw[i][1];
+                fs_wave_lds_fence();
+                xf[i >> 3][i & 7] = pack8(*reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * g), *reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * g + 4));
+                fs_wave_lds_fence();
+            }
+            fs_wait_vm<0>();
+        } else {
 #ifdef GENIE_VAR_T_XTILE
         {   // operand rows as whole 128-byte lines (8 tokens x 64 columns per request), re-laid through the wave's tile
             unsigned char* tile = smem + FS_RING + 4096 + wid * 2304;
@@ -339,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void temporal_fused_bf16_kernel(const uint1
                 xf[grp][ks] = *reinterpret_cast<const s16x8*>(x16 + (row0 + grp) * D + 32 * ks + 8 * g);
         fs_wait_vm<0>();
 #endif
+        }
         FS_STAMP(blk_i, 1);
         FS_CYC_RESET();
 
@@ -1266,6 +1294,8 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
             asm volatile("" : "+s"(soff));   // (address arithmetic stays here: hoisted above the head loop it is spilled)
             float* xw = x + soff;
             uint16_t* xw16 = x16 + soff;
+            int w16 = x16 != nullptr;
+            asm volatile("" : "+v"(w16));   // per-lane predicate: the store is masked, the loop not duplicated
             int rr = lane >> 3, cc = (lane & 7) * 4;              // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
             asm volatile("" : "+v"(rr), "+v"(cc));            // (everything derived from them is formed here, not hoisted and spilled)
 #ifdef GENIE_VAR_S_RESEND
@@ -1297,7 +1327,7 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
                     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc);
 #endif
                     *reinterpret_cast<f32x4*>(xw + (size_t)(rr + 8 * i2) * D + 32 * ct + cc) = v;
-                    *reinterpret_cast<s16x4*>(xw16 + (size_t)(rr + 8 * i2) * D + 32 * ct + cc) = pack4(v);
+                    if (w16) *reinterpret_cast<s16x4*>(xw16 + (size_t)(rr + 8 * i2) * D + 32 * ct + cc) = pack4(v);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_wave_barrier();
@@ -1340,11 +1370,14 @@ int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& 
 #define GENIE_VAR_T_MIN_CLIPS 2   // (measured at 1 / 2 / 3 / 4 / 6 clips: 1 clip is 14 % slower fused, from 2 clips on 6-30 % faster)
 #endif
 // x += proj_t(attention_T(qkv_t(x16))) on dense (B, 16, S, 256) buffers; GENIE_E_UNSUPPORTED for any other geometry
+bool temporal_fused_takes(const genie_cfg& c, const genie_attn_weights& aw, int B) {
+    return aw.fused_w16 && c.d_model == 256 && c.num_heads == 8 && c.head_dim == 32 && c.T == 16 && c.S % 8 == 0 && !c.qk_norm &&
+           (long)B * c.S >= GENIE_VAR_T_MIN_CLIPS * 256;
+}
+
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,
                                hipStream_t st) {
-    if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.T != 16 || c.S % 8 || c.qk_norm ||
-        (long)B * c.S < GENIE_VAR_T_MIN_CLIPS * 256)
-        return GENIE_E_UNSUPPORTED;
+    if (!temporal_fused_takes(c, aw, B)) return GENIE_E_UNSUPPORTED;
     const int n_blocks = B * c.S / 8;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -1360,15 +1393,17 @@ int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw,
 #endif
     fs_stamps_prepare();
     const float sl2e = c.attn_scale * 1.4426950408889634f;
-    if (c.qkv_bias && aw.qkv_b) {
-        (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        temporal_fused_bf16_kernel<true><<<grid, 256, lds, st>>>(x16, x, aw.fused_w16, aw.qkv_b, c.proj_bias ? aw.proj_b : nullptr,
-                                                                 n_blocks, c.S, sl2e, study_env("GENIE_FUSED_ABL", 0));
-    } else {
-        (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        temporal_fused_bf16_kernel<false><<<grid, 256, lds, st>>>(x16, x, aw.fused_w16, nullptr, c.proj_bias ? aw.proj_b : nullptr,
-                                                                  n_blocks, c.S, sl2e, study_env("GENIE_FUSED_ABL", 0));
-    }
+    const int abl = study_env("GENIE_FUSED_ABL", 0);
+    const float* pb = c.proj_bias ? aw.proj_b : nullptr;
+#define T_LAUNCH(QB_, XF_)                                                                                                        \
+    do {                                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)temporal_fused_bf16_kernel<QB_, XF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        temporal_fused_bf16_kernel<QB_, XF_><<<grid, 256, lds, st>>>(x16, x, aw.fused_w16, QB_ ? aw.qkv_b : nullptr, pb, n_blocks, c.S, sl2e, abl); \
+    } while (0)
+    const bool qb = c.qkv_bias && aw.qkv_b;
+    if (!x16) { if (qb) T_LAUNCH(true, true); else T_LAUNCH(false, true); }     // x16 == NULL: operands from the f32 rows
+    else { if (qb) T_LAUNCH(true, false); else T_LAUNCH(false, false); }
+#undef T_LAUNCH
     GENIE_LAUNCH_CHECK("temporal_fused_bf16");
     return GENIE_OK;
 }
