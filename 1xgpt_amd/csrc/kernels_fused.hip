@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
 #ifdef GENIE_VAR_M_GELU_AS   // (variant: the 1.5e-7 GELU of the GEMM epilogues)
                 gz[i] = FS_ABL(4) ? a[i] : gelu_erf_fast(a[i]); gz[i + 1] = FS_ABL(4) ? a[i + 1] : gelu_erf_fast(a[i + 1]);
 #else
-                const genie_f2 g2 = FS_ABL(4) ? genie_f2{a[i], a[i + 1]} : gelu_erf_poly2(genie_f2{a[i], a[i + 1]});
+                const genie_f2 g2 = (FS_ABL(4) || (GENIE_VAR_M_ABL & 8)) ? genie_f2{a[i], a[i + 1]} : gelu_erf_poly2(genie_f2{a[i], a[i + 1]});
                 gz[i] = g2[0]; gz[i + 1] = g2[1];
 #endif
             }
@@ -781,11 +781,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         gelu_pack(acc1, hk0, hk1);
         FS_CYC(3);
         // regions 1..31: fc1 of chunk j next to fc2 of chunk j - 1
+#ifndef GENIE_VAR_M_ABL
+#define GENIE_VAR_M_ABL 0   // timing variants of the region loop (results WRONG): 1 no barrier, 2 no LDS-DMA, 4 no vmcnt wait, 8 no GELU
+#endif
         for (int j = 1; j < 32; ++j) {
-            fs_wait_vm<0>();
-            fs_barrier();
+            if constexpr (!(GENIE_VAR_M_ABL & 4)) fs_wait_vm<0>();
+            if constexpr (!(GENIE_VAR_M_ABL & 1)) fs_barrier();
             FS_CYC(0);
-            issue_region(j + 1);
+            if constexpr (!(GENIE_VAR_M_ABL & 2)) issue_region(j + 1);
             FS_CYC(1);
             const unsigned char* sa = lbase + (j & 1) * 2 * FS_STAGE;
             acc1 = bias1(j);
