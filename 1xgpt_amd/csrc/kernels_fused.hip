@@ -119,6 +119,9 @@ __device__ __forceinline__ void fs_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+#ifndef GENIE_VAR_M_ABL
+#define GENIE_VAR_M_ABL 0   // timing variants of the region loop (results WRONG): 1 no barrier, 2 no LDS-DMA, 4 no vmcnt wait, 8 no GELU
+#endif
 #ifndef GENIE_VAR_M_PF
 #define GENIE_VAR_M_PF 2   // fragment prefetch depth of the mlp kernel's region loop (0: compiler-scheduled reads; 3 = 256 registers)
 #endif
@@ -781,9 +784,6 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
         gelu_pack(acc1, hk0, hk1);
         FS_CYC(3);
         // regions 1..31: fc1 of chunk j next to fc2 of chunk j - 1
-#ifndef GENIE_VAR_M_ABL
-#define GENIE_VAR_M_ABL 0   // timing variants of the region loop (results WRONG): 1 no barrier, 2 no LDS-DMA, 4 no vmcnt wait, 8 no GELU
-#endif
         for (int j = 1; j < 32; ++j) {
             if constexpr (!(GENIE_VAR_M_ABL & 4)) fs_wait_vm<0>();
             if constexpr (!(GENIE_VAR_M_ABL & 1)) fs_barrier();
