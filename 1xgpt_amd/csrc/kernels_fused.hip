@@ -120,7 +120,7 @@ __device__ __forceinline__ void fs_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 #ifndef GENIE_VAR_M_ABL
-#define GENIE_VAR_M_ABL 0   // timing variants of the region loop (results WRONG): 1 no barrier, 2 no LDS-DMA, 4 no vmcnt wait, 8 no GELU
+#define GENIE_VAR_M_ABL 0   // timing variants of the region loop (results WRONG): 1 no barrier, 2 no LDS-DMA, 4 no vmcnt wait, 8 no GELU, 16 no fragment reads, 32 no MFMA
 #endif
 #ifndef GENIE_VAR_M_PF
 #define GENIE_VAR_M_PF 2   // fragment prefetch depth of the mlp kernel's region loop (0: compiler-scheduled reads; 3 = 256 registers)
@@ -800,13 +800,15 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
 #define ML_OFF(n) ((((n) & 1) ? FS_STAGE : 0) + ((n) >> 1) * 1024)
 #define ML_STEP(n)                                                                                                       \
     {                                                                                                                    \
-        fs_lds_wait<((31 - (n)) < (PF - 1) ? (31 - (n)) : (PF - 1))>(fb[(n) % PF]);                                       \
-        if constexpr (((n) & 1) != 0) out[((n) >> 1) & 7] = mma32x32(fb[(n) % PF], ((n) >> 4) ? hk1 : hk0, out[((n) >> 1) & 7]); \
+        if constexpr (!(GENIE_VAR_M_ABL & 16)) fs_lds_wait<((31 - (n)) < (PF - 1) ? (31 - (n)) : (PF - 1))>(fb[(n) % PF]); \
+        if constexpr ((GENIE_VAR_M_ABL & 32) != 0) { asm volatile("" : "+v"(acc1) : "v"(fb[(n) % PF])); }              \
+        else if constexpr (((n) & 1) != 0) out[((n) >> 1) & 7] = mma32x32(fb[(n) % PF], ((n) >> 4) ? hk1 : hk0, out[((n) >> 1) & 7]); \
         else acc1 = mma32x32(fb[(n) % PF], xf[(n) >> 1], acc1);                                                         \
-        if constexpr ((n) + PF < 32) fs_lds_rd<ML_OFF(((n) + PF) & 31)>(fb[(n) % PF], la);                              \
+        if constexpr ((n) + PF < 32 && !(GENIE_VAR_M_ABL & 16)) fs_lds_rd<ML_OFF(((n) + PF) & 31)>(fb[(n) % PF], la);   \
     }
-                fs_lds_rd<ML_OFF(0)>(fb[0], la);
-                if constexpr (PF > 1) fs_lds_rd<ML_OFF(1)>(fb[1 % PF], la);
+                if constexpr ((GENIE_VAR_M_ABL & 16) != 0) { fb[0] = xf[0]; fb[1 % PF] = xf[1]; }   /* (timing variant: no fragment reads) */
+                else fs_lds_rd<ML_OFF(0)>(fb[0], la);
+                if constexpr (PF > 1 && !(GENIE_VAR_M_ABL & 16)) fs_lds_rd<ML_OFF(1)>(fb[1 % PF], la);
                 if constexpr (PF > 2) fs_lds_rd<ML_OFF(2)>(fb[2 % PF], la);
                 if constexpr (PF > 3) fs_lds_rd<ML_OFF(3)>(fb[3 % PF], la);
                 ML_STEP(0) ML_STEP(1) ML_STEP(2) ML_STEP(3) ML_STEP(4) ML_STEP(5) ML_STEP(6) ML_STEP(7)
