@@ -1304,17 +1304,22 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
             int rr = lane >> 3, cc = (lane & 7) * 4;              // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
             asm volatile("" : "+v"(rr), "+v"(cc));            // (everything derived from them is formed here, not hoisted and spilled)
 #ifdef GENIE_VAR_S_RESEND
-            f32x4 rs[2][4];
+#ifndef GENIE_VAR_S_EPF
+#define GENIE_VAR_S_EPF 1      // residual column tiles requested ahead of their use
+#endif
+            constexpr int EPF = GENIE_VAR_S_EPF;
+            f32x4 rs[EPF + 1][4];
             auto load_res = [&](int ct_, f32x4* dst) {
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) dst[i2] = *reinterpret_cast<const f32x4*>(xw + (size_t)(rr + 8 * i2) * D + 32 * ct_ + cc);
             };
-            load_res(0, rs[0]);
+#pragma unroll
+            for (int i = 0; i < EPF; ++i) load_res(i, rs[i % (EPF + 1)]);
 #endif
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
 #ifdef GENIE_VAR_S_RESEND
-                if (ct + 1 < 8) load_res(ct + 1, rs[(ct + 1) & 1]);
+                if (ct + EPF < 8) load_res(ct + EPF, rs[(ct + EPF) % (EPF + 1)]);
 #endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1327,7 +1332,7 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) {
 #ifdef GENIE_VAR_S_RESEND
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc) + rs[ct & 1][i2];
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc) + rs[ct % (EPF + 1)][i2];
 #else
                     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * i2) * 36 + cc);
 #endif
