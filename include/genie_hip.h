@@ -152,15 +152,17 @@ enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_F
 #define GENIE_SPATIAL_QKV_FUSED_ELEMS 196608
 #define GENIE_SPATIAL_FUSED_ELEMS (GENIE_SPATIAL_PROJ_FUSED_ELEMS + GENIE_SPATIAL_QKV_FUSED_ELEMS)
 int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream);
-/* Unit entry points of the fused sub-blocks (parity tests, tuning).  Both update the f32 residual stream x in place and return
- * GENIE_E_UNSUPPORTED outside the geometry above (the layer drivers then run the unfused launches).
+/* Unit entry points of the fused sub-blocks (parity tests, tuning).  All update the f32 residual stream x in place and return
+ * GENIE_E_UNSUPPORTED outside the geometry above or below their size thresholds -- temporal / mlp: 2 clips' worth of rows (8,192), spatial:
+ * 128 sequences; measured break-evens, DESIGN.md section 4 -- (the layer drivers then run the unfused launches).
  *   temporal: x (B,16,S,256) += proj(causal_attention_T(qkv(x16))), x16 = bf16 copy of x (B,16,S,256), or NULL: the kernel rounds its
  *             operands from x itself (same values, no second buffer read); needs aw->fused_w16.
  *             Reference: st_transformer.py:77-78 (the permute to (B S) T C is never materialised), attention.py:36-61.
  *   spatial:  x (n_seq*256, 256) += proj(softmax(q k^T) v) from the operand planes [Q scale log2e | K | V^T] of the spatial qkv GEMM
  *             (n_seq sequences of 256 tokens, 8 heads of 32), x16 = bf16 copy of the result (NULL: not written); needs aw->fused_w16.
  *             Reference: st_transformer.py:73-74, attention.py:48-60.  (The planes are an internal format of the block driver:
- *             this entry exists for tuning -- tools/bench_fused.py -- the parity tests go through the block.)
+ *             this entry exists for tuning -- tools/bench_spatial_fused.py; tests/test_hip_fused.py checks the planes' formats
+ *             element-wise at their producer, genie_mlp_fused_qkv_bf16, and this kernel through the block.)
  *   mlp:      x (rows,256) += fc2(gelu(fc1(LayerNorm(x; norm2)))), rows % 128 == 0; x16_out (or NULL) receives the bf16 copy
  *             of the result, or -- when next_norm_w / next_norm_b are given -- LayerNorm(result; next_norm_*) in bf16 (the next
  *             block's norm1 output, st_transformer.py:73); needs lw->mlp_fused_w16.  Reference: st_transformer.py:81, 16-25. */
