@@ -30,23 +30,25 @@ class GenieCfg(C.Structure):
 
 class AttnWeights(C.Structure):
     _fields_ = [(n, c_ptr) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "norm_w", "norm_b", "qkv_w16", "proj_w16",
-                                     "fused_w16")] + [("w16_wide", C.c_int32)]
+                                     "fused_w16")] + [("w16_wide", C.c_int32), ("frame_w16", c_ptr)]
 
 
 class LayerWeights(C.Structure):
     _fields_ = [("norm1_w", c_ptr), ("norm1_b", c_ptr), ("spatial", AttnWeights), ("temporal", AttnWeights),
                 ("norm2_w", c_ptr), ("norm2_b", c_ptr), ("fc1_w", c_ptr), ("fc1_b", c_ptr), ("fc2_w", c_ptr),
-                ("fc2_b", c_ptr), ("fc1_w16", c_ptr), ("fc2_w16", c_ptr), ("mlp_fused_w16", c_ptr), ("w16_wide", C.c_int32)]
+                ("fc2_b", c_ptr), ("fc1_w16", c_ptr), ("fc2_w16", c_ptr), ("mlp_fused_w16", c_ptr), ("w16_wide", C.c_int32),
+                ("mlp_frame_w16", c_ptr)]
 
 
 class Weights(C.Structure):
     _fields_ = [("pos_embed", c_ptr), ("mask_embed", c_ptr), ("embed", c_ptr * 4), ("out_w", c_ptr),
-                ("out_b", c_ptr), ("out_w16", c_ptr), ("layers_host", C.POINTER(LayerWeights)), ("out_w16_wide", C.c_int32)]
+                ("out_b", c_ptr), ("out_w16", c_ptr), ("layers_host", C.POINTER(LayerWeights)), ("out_w16_wide", C.c_int32),
+                ("out_frame_w16", c_ptr)]
 
 WIDE_QKV, WIDE_PROJ, WIDE_FC1, WIDE_FC2 = 1, 2, 1, 2          # bits of the w16_wide fields (genie_hip.h)
 FUSED_QKV_STREAM = 4                                        # spatial attention: fused_w16 = [proj stream | qkv stream]
 TEMPORAL_FUSED_ELEMS, MLP_FUSED_ELEMS, SPATIAL_PROJ_FUSED_ELEMS, SPATIAL_QKV_FUSED_ELEMS = 262144, 524288, 65536, 196608        # bf16 values of the fused kernels' weight streams
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 # name -> (restype, argtypes); must list every symbol include/genie_hip.h declares
@@ -82,6 +84,9 @@ SIGNATURES = {
                                              C.c_size_t, c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_frame_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, c_ptr, C.c_size_t,
                                    c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_frames_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_size_t,
+                                    c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_pack_frame_w16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     "genie_metric_hits": (C.c_int, [c_ptr, C.c_int64, c_ptr, C.c_int64, C.c_int, C.c_int64, c_ptr, C.c_double, C.c_double,
                                     C.c_double, c_ptr, c_ptr]),
     "genie_factored_ce": (C.c_int, [C.POINTER(GenieCfg), c_ptr, C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int,

@@ -251,12 +251,13 @@ extern "C" {
 
 int genie_version(void) { return GENIE_ABI_VERSION; }
 int genie_abi_layout(size_t* out_host, int n) {
-    const size_t v[9] = {sizeof(genie_cfg), sizeof(genie_attn_weights), offsetof(genie_attn_weights, fused_w16),
-                         offsetof(genie_attn_weights, w16_wide), sizeof(genie_layer_weights),
-                         offsetof(genie_layer_weights, mlp_fused_w16), offsetof(genie_layer_weights, w16_wide),
-                         sizeof(genie_weights), offsetof(genie_weights, out_w16_wide)};
-    for (int i = 0; i < n && i < 9 && out_host; ++i) out_host[i] = v[i];
-    return 9;
+    const size_t v[12] = {sizeof(genie_cfg), sizeof(genie_attn_weights), offsetof(genie_attn_weights, fused_w16),
+                          offsetof(genie_attn_weights, w16_wide), sizeof(genie_layer_weights),
+                          offsetof(genie_layer_weights, mlp_fused_w16), offsetof(genie_layer_weights, w16_wide),
+                          sizeof(genie_weights), offsetof(genie_weights, out_w16_wide), offsetof(genie_attn_weights, frame_w16),
+                          offsetof(genie_layer_weights, mlp_frame_w16), offsetof(genie_weights, out_frame_w16)};
+    for (int i = 0; i < n && i < 12 && out_host; ++i) out_host[i] = v[i];
+    return 12;
 }
 const char* genie_last_error(void) { return g_err; }
 int genie_check_config(const genie_cfg* cfg) { return check_cfg(cfg); }
@@ -477,35 +478,58 @@ int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* wt, co
     return readout(c2, w2, w.x, w, B, 0, nframes, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
 }
 
-int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frame_ids, int B, int t, float* cache,
-                     size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+int genie_frames_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frame_ids, int B, int t0, int nf, float* cache,
+                      size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
     GENIE_TRY(check_cfg(cfg));
-    GENIE_CHECK_ARG(wt && wt->layers_host && frame_ids && cache, "frame_pass: NULL pointer");
-    GENIE_CHECK_ARG(t >= 0 && t < cfg->T, "frame_pass: frame %d out of range", t);
-    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "frame_pass: cache too small");
+    GENIE_CHECK_ARG(wt && wt->layers_host && frame_ids && cache, "frames_pass: NULL pointer");
+    GENIE_CHECK_ARG(nf >= 1 && t0 >= 0 && t0 + nf <= cfg->T, "frames_pass: frames [%d, %d) out of range", t0, t0 + nf);
+    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "frames_pass: cache too small");
     GENIE_TRY(check_ws(*cfg, B, workspace, workspace_bytes));
     genie_cfg c1 = *cfg;
-    c1.T = 1;  // every buffer of this pass is a dense (B, 1, S, *) tensor
+    c1.T = nf;  // every buffer of this pass is a dense (B, nf, S, *) tensor
+    // the fragment-order kernels (kernels_frame.hip) take the pass when they cover every layer; several frames per pass exist
+    // only there
+    bool fr = cfg->precision == GENIE_PREC_F16X3 && wt->out_frame_w16;
+    for (int i = 0; fr && i < c1.num_layers; ++i) fr = frame_path_takes(c1, wt->layers_host[i], (long)B * nf * cfg->S);
+    if (nf > 1 && !fr) {
+        set_error("frames_pass: %d frames per pass need the fragment-order kernels (f16x3, head_dim 64, LayerNorm blocks, frame_w16 "
+                  "streams, B * nf <= 4)", nf);
+        return GENIE_E_UNSUPPORTED;
+    }
     Workspace w = carve(c1, B, workspace);
     w.model_T = cfg->T;
     hipStream_t st = as_stream(stream);
     genie_weights w1 = *wt;
-    w1.pos_embed = wt->pos_embed + (size_t)t * cfg->S * cfg->d_model;  // pos_embed_TSC[0, t]
+    w1.pos_embed = wt->pos_embed + (size_t)t0 * cfg->S * cfg->d_model;  // pos_embed_TSC[0, t0 + i]
     GENIE_TRY(launch_embed(c1, w1, frame_ids, B, w.x, st));
-    if (c1.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c1, w.x, w, B, st));
-    if (c1.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c1, w.x, w, B, st));
+    if (!fr) {
+        if (c1.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c1, w.x, w, B, st));
+        if (c1.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c1, w.x, w, B, st));
+    }
     const size_t per_layer = (size_t)B * cfg->T * cfg->S * 3 * cfg->d_model;
     for (int i = 0; i < c1.num_layers; ++i) {
         w.fcache = cache + i * per_layer;
-        w.frame_t = t;
+        w.frame_t = t0;
         w.frame_T = cfg->T;
         w.skip_shadow_mlp = !c1.qk_norm && i + 1 < c1.num_layers;
-        const int rc = st_block(c1, wt->layers_host[i], w.x, w, B, st);
+        const int rc = fr ? st_block_frame_f16x3(c1, wt->layers_host[i], w.x, w, B, nf, logits && !w.skip_shadow_mlp, st)
+                          : st_block(c1, wt->layers_host[i], w.x, w, B, st);
         w.skip_shadow_mlp = false;
         GENIE_TRY(rc);
     }
     if (!logits) return GENIE_OK;
+    if (fr) return readout_frame_f16x3(c1, *wt, w, B, nf, nf - 1, logits, st);
     return readout(c1, *wt, w.x, w, B, 0, 1, GENIE_LAYOUT_TOKEN_MAJOR, logits, st);
+}
+
+int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_t* frame_ids, int B, int t, float* cache,
+                     size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    return genie_frames_pass(cfg, wt, frame_ids, B, t, 1, cache, cache_bytes, logits, workspace, workspace_bytes, stream);
+}
+
+int genie_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, void* stream) {
+    GENIE_CHECK_ARG(src && dst, "pack_frame_w16: NULL pointer");
+    return launch_pack_frame_w16(src, dst, N, K, as_stream(stream));
 }
 
 int genie_factored_ce(const genie_cfg* cfg, const float* logits, int layout, const int64_t* targets,

@@ -220,6 +220,13 @@ int launch_gemm16_sm(int npl, const uint16_t* A, long lda, long planeA, const ui
 int launch_gemm16_sm_ln(int npl, const float* x, long ldx, const float* ln_g, const float* ln_b, float eps, const uint16_t* W,
                         long ldw, long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc,
                         int M, int N, int K, int flags, float alpha, hipStream_t st);
+// kernels_frame.hip: the one-frame passes of generate on fragment-ordered operands (GENIE_PREC_F16X3)
+int launch_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, hipStream_t st);
+bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows);
+int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, int nf, bool want_xs,
+                         hipStream_t st);
+int readout_frame_f16x3(const genie_cfg& c, const genie_weights& wt, Workspace& w, int B, int nf, int f_out, float* logits,
+                        hipStream_t st);
 // kernels_attn_dma.hip: spatial attention over the operand planes written by launch_gemm16_pp(G16X_OUT16 | G16X_QKV)
 int launch_attn_spatial_dma(int npl, const uint16_t* qkv16, long n_seq, int d, int H, int Dh, uint16_t* out16, size_t out_plane,
                             hipStream_t st);

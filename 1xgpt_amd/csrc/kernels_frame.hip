@@ -1,0 +1,712 @@
+// kernels_frame.hip -- the ONE-FRAME passes of generate (genie_frame_pass: 256 rows per clip and frame), GENIE_PREC_F16X3.
+//
+// Reference: generate.py:81-95 calls STMaskGIT.maskgit_generate once per new frame; every MaskGIT step of it is one forward
+// (st_mask_git.py:163-169) through STBlock (st_transformer.py:70-83).  With the temporal KV cache only the rows of the frame being
+// decoded go through the stack: M = 256 rows per clip, so every Linear is a 256 x N x K problem whose weights (4 bytes per
+// parameter as split f16) outweigh its activations, and a launch lasts a few microseconds.
+//
+// What bounded the round-3 kernels of these passes (gemm16_sm, attn_spatial_keysplit, attn_temporal_single) was not bytes but
+// REQUESTS: their operand loads were MFMA-fragment shaped -- lane (r, h) reads 16 bytes of row r -- so ONE load instruction
+// touched 32 (f16 rows) to 64 (f32 rows) different 128-byte lines for 1 KB of data, and the vector memory pipeline charges per
+// line touched (36-40 GB/s per CU measured, bf16 vs f16x3 and K = 512 vs 2048 on one line: profiles/r03_sm_prefetch_ab.txt).
+// Everything here moves WHOLE LINES:
+//
+//   * 16-bit operands live in FRAGMENT ORDER ("fr"): a matrix X[rows][K] is cut into blocks of 32 rows x 64 k; a block is
+//     NPL planes x 4 MFMA steps of one 1 KB FRAGMENT = the 64 lanes' 16-byte operand pieces of v_mfma_f32_32x32x16_f16
+//     (lane 32 h + r: row r, k = 16 step + 8 h .. + 7).  A fragment load is one instruction over 1 KB of contiguous memory
+//     (8 lines), a wave's operands of one block are 8 KB contiguous.  Weights are packed once (genie_pack_frame_w16);
+//     activations are written in this order by the producing kernel's epilogue.
+//   * f32 rows (the residual stream in front of a LayerNorm) are read as whole rows: 16 lanes x 16 bytes per row and 64-k
+//     block, the row statistics stay inside the wave, the normalised row goes through LDS into fragment order.
+//   * the spatial attention reads [Q scale log2e | K | V^T] fragments that the qkv Linear's epilogue wrote for it; the temporal
+//     decode attention reads the KV cache as whole 256-byte head slices (4 frames per instruction).
+//
+// Kernels: gemm16_fr_kernel (nn.Linear with in-workgroup split-K over 8 waves, the whole contraction in flight; epilogues:
+// f32 rows / residual update (+ operand copy) / GELU operand / attention operand planes), attn_spatial_fr_kernel,
+// attn_temporal_fr_kernel, pack_frame_w16_kernel.  Driver: st_block_frame_f16x3 (one STBlock of a frame pass).
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace genie {
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FR = 512;        // 16-bit elements of one fragment (64 lanes x 8)
+constexpr int NPL = 2;         // planes of the split-f16 operands: hi, lo'
+
+__device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// hi / lo' fragments of eight f32 values (element e in half e&1 of dword e>>1)
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+    uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
+    split_f16_x4(v[0], v[1], v[2], v[3], h01, h23, l01, l23);
+    split_f16_x4(v[4], v[5], v[6], v[7], h45, h67, l45, l67);
+    hi = u32x4{h01, h23, h45, h67};
+    lo = u32x4{l01, l23, l45, l67};
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16 i .. 16 i + 15), the same bits in every lane of the row: four row rotations
+// (v_add with a DPP operand each) instead of four ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));  // row_ror:1
+    return v;
+}
+
+// every operand request of these kernels is issued before the first wait; the scheduler must not sink loads below the
+// matrix instructions to save registers (a launch is one memory round trip long)
+#define FR_PIN_LOADS() __builtin_amdgcn_sched_barrier(0)
+
+// element offset of fragment (plane p, step s) of block (rb, kb) in a fragment-ordered operand with KB k-blocks per row block
+__host__ __device__ inline size_t fr_frag(long rb, int kb, int KB, int p, int s) {
+    return ((((size_t)rb * KB + kb) * NPL + p) * 4 + s) * FR;
+}
+}  // namespace
+
+enum { FR_EPI_F32 = 0, FR_EPI_RES = 1, FR_EPI_GELU = 2, FR_EPI_QKVS = 3 };
+
+struct FrGemmArgs {
+    // A operand: fragment-ordered rows (LNF == false) ...
+    const uint16_t* A;
+    int a_group, a_mul, a_off;   // row-block remap: block rb of the problem is block ((rb / a_group) * a_mul + a_off) * a_group + rb % a_group of A
+    // ... or LayerNorm(x) of f32 rows (LNF == true)
+    const float* X;
+    long ldx;
+    const float* ln_g;
+    const float* ln_b;
+    float ln_eps;
+    const uint16_t* W;           // fragment-ordered (N, K)
+    const float* bias;           // (N) or NULL
+    float alpha;
+    int M, N, K;
+    float* Cf;                   // EPI_F32: out rows; EPI_RES: the residual stream, updated in place
+    long ldc, rows_per_batch, strideC;   // row -> Cf + (row / rows_per_batch) * strideC + (row % rows_per_batch) * ldc
+    uint16_t* C16;               // EPI_RES (optional) / EPI_GELU: fragment-ordered operand copy of the output, N / 64 k-blocks
+    uint16_t* qkvs;              // EPI_QKVS: attention operand planes
+    float qscale;                // EPI_QKVS: softmax scale * log2(e), folded into Q
+    int H, S;                    // EPI_QKVS: heads (64 columns each), rows per sequence (256)
+};
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// C = epilogue(alpha * A . W^T + bias): workgroup = 32 rows x (32 NJ) columns, NW waves split K (wave w: 64-k blocks w, w + NW, ..),
+// NKB blocks per wave, RING of them in flight.  Two accumulators per tile as in gemm16_sm (hi.hi | hi.lo' + lo'.hi, the second
+// scaled by 2^-11 at the end: valid for any operand magnitude).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int NW, int NJ, int NKB, int EPI, bool LNF>
+__global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW >= 4 ? NW / 4 : 1, NW >= 4 ? NW / 4 : 1)))
+void gemm16_fr_kernel(const FrGemmArgs a) {
+    constexpr int NT = NW * 64, TN = 32 * NJ, PITCH = TN + 4;
+    constexpr int RING = NKB > 1 ? 2 : 1;
+    static_assert(!LNF || NKB == 1, "LayerNorm-fused A: the waves tile one row of K = 64 NW");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);                                   // [NW][32][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = a.N / TN;
+    const int rb = blockIdx.x / nt, jt = blockIdx.x % nt;
+    const int m0 = rb * 32, n0 = jt * TN;
+    const int KB = a.K / 64;
+
+    // (every kernel argument the request phase needs, in SGPRs before the first request: fetched lazily they were three to four
+    // dependent scalar-cache round trips spread between the requests)
+    asm volatile("" :: "s"(a.A), "s"(a.X), "s"(a.ln_g), "s"(a.ln_b), "s"(a.W), "s"(a.bias), "s"(a.Cf), "s"(a.ldx), "s"(a.ldc),
+                 "s"(a.K), "s"(a.N), "s"(a.a_group), "s"(a.a_mul), "s"(a.a_off));
+    // ---- requests first, oldest = needed first (loads return in order): bias and LayerNorm parameters, (LNF) the f32 rows, the
+    // weight fragments of this wave's first RING blocks, the residual rows
+    constexpr int C4 = TN / 4, ITEMS = 32 * C4, PASSES = (ITEMS + NT - 1) / NT;
+    f32x4 pre_b[PASSES];
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+        const int idx = tid + q * NT;
+        pre_b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias && idx < ITEMS) pre_b[q] = *reinterpret_cast<const f32x4*>(a.bias + n0 + (idx % C4) * 4);
+    }
+    f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNF) {   // gamma | beta: one float4 per thread (K / 2 <= NT float4s), staged through LDS
+        if (tid < a.K / 4) gbv = reinterpret_cast<const f32x4*>(a.ln_g)[tid];
+        else if (tid < a.K / 2) gbv = reinterpret_cast<const f32x4*>(a.ln_b)[tid - a.K / 4];
+    }
+    constexpr int RW = 32 / NW;                 // rows per wave in the LayerNorm prologue
+    constexpr int G = RW / 4 > 0 ? RW / 4 : 1;  // groups of 4 rows (a wave instruction = 4 rows x 64 floats)
+    f32x4 xv[LNF ? G : 1][LNF ? NW : 1];
+    if constexpr (LNF) {
+        static_assert(RW % 4 == 0, "LayerNorm prologue: 4 rows per instruction");
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float* xr = a.X + (size_t)(m0 + RW * wid + 4 * g + (lane >> 4)) * a.ldx + 4 * (lane & 15);
+#pragma unroll
+            for (int kb = 0; kb < NW; ++kb) xv[g][kb] = *reinterpret_cast<const f32x4*>(xr + 64 * kb);
+        }
+    }
+    u32x4 wf[RING][NJ][NPL][4], af[RING][NPL][4];
+    auto load_w = [&](int slot, int kb) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const uint16_t* src = a.W + fr_frag((long)jt * NJ + j, kb, KB, 0, 0) + lane * 8;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wf[slot][j][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * FR);
+        }
+    };
+    const long arb = LNF ? 0 : ((long)(rb / a.a_group) * a.a_mul + a.a_off) * a.a_group + rb % a.a_group;
+    auto load_a = [&](int slot, int kb) {
+        const uint16_t* src = a.A + fr_frag(arb, kb, KB, 0, 0) + lane * 8;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[slot][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * FR);
+    };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) {
+        if constexpr (!LNF) load_a(i, wid + NW * i);
+        load_w(i, wid + NW * i);
+    }
+
+    // the residual rows of the epilogue (EPI_RES) go out now as well: one float4 per thread and pass of the row-major phase
+    f32x4 pre_r[EPI == FR_EPI_RES ? PASSES : 1];
+    if constexpr (EPI == FR_EPI_RES) {
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const int idx = tid + q * NT;
+            const int rl = idx / C4, c4 = (idx % C4) * 4;
+            pre_r[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < ITEMS) pre_r[q] = *reinterpret_cast<const f32x4*>(a.Cf + (size_t)(m0 + rl) * a.ldc + n0 + c4);
+        }
+    }
+
+    FR_PIN_LOADS();
+
+    f32x16 accm[NJ], accc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accm[j][e] = 0.f; accc[j][e] = 0.f; }
+    auto compute = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                accm[j] = mma16(af[slot][0][s], wf[slot][j][0][s], accm[j]);
+                accc[j] = mma16(af[slot][0][s], wf[slot][j][1][s], accc[j]);
+                accc[j] = mma16(af[slot][1][s], wf[slot][j][0][s], accc[j]);
+            }
+    };
+
+    if constexpr (LNF) {
+        // ---- LayerNorm in the wave: lane (row q = lane / 16 of each 4-row group, columns 4 (lane % 16) .. + 3 of every 64-k block);
+        // the normalised rows go to LDS in fragment order (+16 B per half fragment: conflict-free 8-byte stores)
+        constexpr int HS = 528, SS = 2 * HS, KBS = NPL * 4 * SS;            // bytes
+        unsigned char* alds = smem + (size_t)NW * 32 * PITCH * 4;            // [NW blocks][NPL][4 steps][2 halves][32 rows x 16 B (+16)]
+        float* gb = reinterpret_cast<float*>(alds + (size_t)NW * KBS);      // gamma | beta, K floats each
+        if (tid < a.K / 2) reinterpret_cast<f32x4*>(gb)[tid] = gbv;
+        __syncthreads();
+        const float invK = 1.0f / (float)(64 * NW);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float sx = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NW; ++kb) sx += (xv[g][kb][0] + xv[g][kb][1]) + (xv[g][kb][2] + xv[g][kb][3]);
+            sx = row16_sum(sx);
+            const float mean = sx * invK;
+            float q = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[g][kb][e] -= mean; q = fmaf(xv[g][kb][e], xv[g][kb][e], q); }
+            q = row16_sum(q);
+            const float rstd = 1.0f / sqrtf(q * invK + a.ln_eps);
+            const int r = RW * wid + 4 * g + (lane >> 4);                    // row of the tile
+            const int c = lane & 15;                                         // columns 4 c .. 4 c + 3 of the block
+            unsigned char* dst = alds + (c >> 2) * SS + ((c >> 1) & 1) * HS + r * 16 + (c & 1) * 8;
+#pragma unroll
+            for (int kb = 0; kb < NW; ++kb) {
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gb + 64 * kb + 4 * c);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(gb + a.K + 64 * kb + 4 * c);
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = xv[g][kb][e] * rstd * gm[e] + bt[e];
+                uint32_t h01, h23, l01, l23;
+                split_f16_x4(y[0], y[1], y[2], y[3], h01, h23, l01, l23);
+                *reinterpret_cast<u32x2*>(dst + (size_t)kb * KBS) = u32x2{h01, h23};
+                *reinterpret_cast<u32x2*>(dst + (size_t)kb * KBS + 4 * SS) = u32x2{l01, l23};
+            }
+        }
+        __syncthreads();
+        const unsigned char* src = alds + (size_t)wid * KBS + (lane >> 5) * HS + (lane & 31) * 16;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[0][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * SS);
+        compute(0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NKB; ++i) {
+            compute(i % RING);
+            if (i + RING < NKB) {
+                load_a(i % RING, wid + NW * (i + RING));
+                load_w(i % RING, wid + NW * (i + RING));
+            }
+        }
+    }
+
+    // ---- the NW partial tiles meet in LDS (accumulator element e of lane (r, h): row 8 (e >> 2) + 4 h + (e & 3), column r)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        float* mine = red + (size_t)wid * 32 * PITCH;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                mine[(8 * (e >> 2) + 4 * h + (e & 3)) * PITCH + 32 * j + r] = accm[j][e] + accc[j][e] * (1.0f / 2048.0f);
+    }
+    __syncthreads();
+    // ---- row-major phase: thread -> (row, 4 columns); sums the waves in order (bit-reproducible), bias, GELU / residual; f32
+    // rows go out here (whole 128-byte lines), the finished values return to slab 0 for the fragment-order phase
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+        const int idx = tid + q * NT;
+        if (idx < ITEMS) {
+            const int rl = idx / C4, c4 = (idx % C4) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(red + rl * PITCH + c4);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 32 + rl) * PITCH + c4);
+            v = v * a.alpha + pre_b[q];
+            if constexpr (EPI == FR_EPI_GELU) {
+                const genie_f2 g0 = gelu_erf_fast2(genie_f2{v[0], v[1]}), g1 = gelu_erf_fast2(genie_f2{v[2], v[3]});
+                v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+            }
+            if constexpr (EPI == FR_EPI_RES) v += pre_r[q];
+            if constexpr (EPI == FR_EPI_F32 || EPI == FR_EPI_RES) {
+                const long row = m0 + rl;
+                float* dst = a.Cf + (size_t)(row / a.rows_per_batch) * a.strideC + (size_t)(row % a.rows_per_batch) * a.ldc + n0 + c4;
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+            if constexpr (EPI != FR_EPI_F32) *reinterpret_cast<f32x4*>(red + rl * PITCH + c4) = v;
+        }
+    }
+    if constexpr (EPI == FR_EPI_F32) return;
+    if (EPI == FR_EPI_RES && !a.C16) return;
+    __syncthreads();
+    if constexpr (EPI == FR_EPI_RES || EPI == FR_EPI_GELU) {
+        // ---- fragment-order phase: thread -> (step sl of the tile's columns, lane of the fragment): 8 values of one row
+        const int KBo = a.N / 64;
+        for (int idx = tid; idx < (TN / 16) * 64; idx += NT) {
+            const int sl = idx >> 6, fl = idx & 63, r = fl & 31, h = fl >> 5;
+            const float* src = red + r * PITCH + 16 * sl + 8 * h;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            const int col = n0 + 16 * sl;
+            uint16_t* dst = a.C16 + fr_frag(rb, col >> 6, KBo, 0, (col & 63) >> 4) + fl * 8;
+            *reinterpret_cast<u32x4*>(dst) = hi;
+            *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
+        }
+    } else if constexpr (EPI == FR_EPI_QKVS) {
+        // ---- the spatial attention's operand planes.  A 64-column tile is one (q | k | v, head) slice; per (sequence, head):
+        //   Q, K: [block of 32 tokens][plane][step] fragments, lane (r, h): token r, features 16 step + 8 h .. + 7  (Q scaled)
+        //   V^T:  [key tile kt][feature tile dt][step m][plane] fragments, lane (r, h): feature 32 dt + r of keys
+        //         32 kt + 16 m + 4 h + {0..3, 8..11} -- the key order in which the S^T accumulators hold the probabilities
+        static_assert(EPI != FR_EPI_QKVS || TN == 64, "attention operand planes: one head slice (64 columns) per tile");
+        const int dH = a.H * 64;
+        const int which = n0 / dH, head = (n0 % dH) / 64;
+        const int blocks = a.S / 32;                           // 32-token blocks per sequence
+        const long seq = rb / blocks;
+        const int blk = rb % blocks;
+        const size_t unit = (size_t)blocks * NPL * 4 * FR;     // one of Q | K | V^T of a (sequence, head)
+        uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
+        if (which < 2) {
+            const float sc = which == 0 ? a.qscale : 1.0f;
+            for (int idx = tid; idx < 256; idx += NT) {
+                const int sl = idx >> 6, fl = idx & 63, r = fl & 31, h = fl >> 5;
+                const float* src = red + r * PITCH + 16 * sl + 8 * h;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                u32x4 hi, lo;
+                split8(v, hi, lo);
+                uint16_t* dst = base + ((size_t)blk * NPL * 4 + sl) * FR + fl * 8;
+                *reinterpret_cast<u32x4*>(dst) = hi;
+                *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
+            }
+        } else {
+            for (int idx = tid; idx < 256; idx += NT) {
+                const int dm = idx >> 6, fl = idx & 63, r = fl & 31, h = fl >> 5;   // dm = 2 dt + m
+                const int dt = dm >> 1, m = dm & 1;
+                float v[8];
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) v[s8] = red[(16 * m + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + 32 * dt + r];
+                u32x4 hi, lo;
+                split8(v, hi, lo);
+                uint16_t* dst = base + ((size_t)(blk * 2 + dt) * 2 + m) * NPL * FR + fl * 8;
+                *reinterpret_cast<u32x4*>(dst) = hi;
+                *reinterpret_cast<u32x4*>(dst + FR) = lo;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Spatial attention of a frame pass (attention.py:36-61 over the S = 256 positions of one frame, head_dim 64): workgroup =
+// (sequence, head, block of 32 queries), wave kt = the 32-key tile kt.  All 24 operand fragments of a wave (Q block, K tile,
+// V^T tile; hi and lo' planes) are requested at once, nothing is converted or transposed here (the qkv Linear's epilogue did
+// that, FR_EPI_QKVS).  S^T = K Q^T so a lane holds 16 scores of ITS query; exp2 softmax per tile; the eight partial
+// (max, sum, O) triples merge through LDS in wave order; O leaves in the fragment order of the out-projection's A operand.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_spatial_fr_kernel(const uint16_t* __restrict__ qkvs, uint16_t* __restrict__ out16,
+                                                                  int H) {
+    constexpr int DH = 64, PITCH = DH + 4, BLK = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* part = reinterpret_cast<float*>(smem);                               // [8 waves][32 queries][PITCH]
+    float* stat = part + 8 * 32 * PITCH;                                        // [8 waves][32 queries][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kt = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long seq = blockIdx.x;
+    const int head = blockIdx.y, qb = blockIdx.z;
+    const size_t unit = (size_t)BLK * NPL * 4 * FR;
+    const uint16_t* base = qkvs + (size_t)(seq * H + head) * 3 * unit + lane * 8;
+    u32x4 qf[NPL][4], kf[NPL][4], vf[2][2][NPL];
+    {
+        const uint16_t* qp = base + (size_t)qb * NPL * 4 * FR;
+        const uint16_t* kp = base + unit + (size_t)kt * NPL * 4 * FR;
+        const uint16_t* vp = base + 2 * unit + (size_t)kt * 8 * FR;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                kf[p][s] = *reinterpret_cast<const u32x4*>(kp + (p * 4 + s) * FR);
+                qf[p][s] = *reinterpret_cast<const u32x4*>(qp + (p * 4 + s) * FR);
+            }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) vf[dt][m][p] = *reinterpret_cast<const u32x4*>(vp + ((dt * 2 + m) * NPL + p) * FR);
+    }
+    FR_PIN_LOADS();
+    f32x16 a0, c0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { a0[e] = 0.f; c0[e] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a0 = mma16(kf[0][s], qf[0][s], a0);
+        c0 = mma16(kf[0][s], qf[1][s], c0);
+        c0 = mma16(kf[1][s], qf[0][s], c0);
+    }
+    float p[16];
+    float mw = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { p[e] = a0[e] + c0[e] * (1.0f / 2048.0f); mw = fmaxf(mw, p[e]); }
+    mw = fmaxf(mw, __shfl_xor(mw, 32));
+    float lw = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(p[e] - mw); lw += p[e]; }
+    lw += __shfl_xor(lw, 32);
+    if (h == 0) { stat[(kt * 32 + r) * 2] = mw; stat[(kt * 32 + r) * 2 + 1] = lw; }
+    f32x16 oa[2], oc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oa[dt][e] = 0.f; oc[dt][e] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        u32x4 ph, pl;
+        split8(p + 8 * m, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            oa[dt] = mma16(ph, vf[dt][m][0], oa[dt]);
+            oc[dt] = mma16(ph, vf[dt][m][1], oc[dt]);
+            oc[dt] = mma16(pl, vf[dt][m][0], oc[dt]);
+        }
+    }
+    float* op = part + (size_t)kt * 32 * PITCH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            op[((e & 3) + 8 * (e >> 2) + 4 * h) * PITCH + dt * 32 + r] = oa[dt][e] + oc[dt][e] * (1.0f / 2048.0f);
+    __syncthreads();
+    // ---- merge like an online softmax, waves in order; thread -> (step, lane of the output fragment): 8 features of one query
+    if (tid < 256) {
+        const int sl = tid >> 6, fl = tid & 63, q = fl & 31, hh = fl >> 5;
+        float mg = -INFINITY;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) mg = fmaxf(mg, stat[(w8 * 32 + q) * 2]);
+        float l = 0.f;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) {
+            const float sc8 = __builtin_amdgcn_exp2f(stat[(w8 * 32 + q) * 2] - mg);
+            l += stat[(w8 * 32 + q) * 2 + 1] * sc8;
+            const float* src = part + ((size_t)w8 * 32 + q) * PITCH + 16 * sl + 8 * hh;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] += t0[e] * sc8; o[4 + e] += t1[e] * sc8; }
+        }
+        const float invl = 1.0f / l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= invl;
+        u32x4 hi, lo;
+        split8(o, hi, lo);
+        uint16_t* dst = out16 + fr_frag(seq * BLK + qb, head, H, 0, sl) + fl * 8;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Temporal decode attention of a frame pass (attention.py:36-61 with the causal mask, one query frame per row): one wave per
+// (clip, frame of the pass, position, head).  The query frame t = t0 + f attends cache slots 0..t of its position; the cache
+// is the (B, T, S, 3 d) f32 qkv of the earlier passes, slot t written by this pass's qkv Linear.  Whole 256-byte head slices per
+// request: instruction i fetches frames 4 i .. 4 i + 3 (lane = (frame 4 i + lane / 16, features 4 (lane % 16) .. + 3)), so K and
+// V are four loads each; scores are 4-feature partial dot products reduced over 16 lanes, the softmax runs over the four
+// register copies and the four lane groups, P.V reduces over the groups.  head_dim 64, T <= 16, no qk-norm.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __restrict__ cache, uint16_t* __restrict__ out16,
+                                                               long n_items, int T, int S, int t0, int nf, int d, int H, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int head = (int)(item % H);
+    const long row = item / H;                       // (b, f, s) of the dense pass layout
+    const long bf = row / S;
+    const int s = (int)(row - bf * S);
+    const long b = bf / nf;
+    const int f = (int)(bf - b * nf), t = t0 + f;
+    const int g = lane >> 4, c = lane & 15;
+    const size_t tok = (size_t)S * 3 * d;
+    const float* hb = cache + ((size_t)(b * T) * S + s) * 3 * d + head * 64 + 4 * c;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(hb + (size_t)t * tok);
+    f32x4 kv[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = 4 * i + g;
+        const float* src = hb + (size_t)(j <= t ? j : t) * tok;    // (frames past t re-read frame t: their probability is 0)
+        kv[i] = *reinterpret_cast<const f32x4*>(src + d);
+        vv[i] = *reinterpret_cast<const f32x4*>(src + 2 * d);
+    }
+    FR_PIN_LOADS();
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float part = row16_sum(fmaf(qv[3], kv[i][3], fmaf(qv[2], kv[i][2], fmaf(qv[1], kv[i][1], qv[0] * kv[i][0]))));
+        sc[i] = (4 * i + g <= t) ? part * scale : -INFINITY;
+        mx = fmaxf(mx, sc[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sc[i] = (4 * i + g <= t) ? expf(sc[i] - mx) : 0.f; sum += sc[i]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o += vv[i] * (sc[i] * inv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] += __shfl_xor(o[e], 16);
+        o[e] += __shfl_xor(o[e], 32);
+    }
+    if (g != 0) return;
+    // lane c: features 4 c .. 4 c + 3 -> half (c >> 1) & 1 of step c >> 2, elements 4 (c & 1) .. + 3 of the lane's 16-byte piece
+    uint32_t h01, h23, l01, l23;
+    split_f16_x4(o[0], o[1], o[2], o[3], h01, h23, l01, l23);
+    uint16_t* dst = out16 + fr_frag(row >> 5, head, H, 0, c >> 2) + (32 * ((c >> 1) & 1) + (int)(row & 31)) * 8 + 4 * (c & 1);
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
+    *reinterpret_cast<u32x2*>(dst + 4 * FR) = u32x2{l01, l23};
+}
+
+// f32 (N, K) row-major -> fragment order, split f16 planes (the split of genie_pack_split_f16: hi flushed below the f16 normal range)
+__global__ void pack_frame_w16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte piece of the hi plane
+    const int KB = K / 64;
+    const size_t total = (size_t)(N / 32) * KB * 4 * 64;
+    if (i >= total) return;
+    const int fl = (int)(i & 63), s = (int)((i >> 6) & 3);
+    const size_t blk = i >> 8;
+    const int kb = (int)(blk % KB);
+    const long rb = (long)(blk / KB);
+    const int r = fl & 31, h = fl >> 5;
+    const float* p = src + (size_t)(rb * 32 + r) * K + 64 * kb + 16 * s + 8 * h;
+    uint16_t hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split_f16(p[e], hi[e], lo[e]);
+    uint16_t* o = dst + fr_frag(rb, kb, KB, 0, s) + fl * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = hi[e]; o[4 * FR + e] = lo[e]; }
+}
+
+int launch_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, hipStream_t st) {
+    GENIE_CHECK_SHAPE(N % 32 == 0 && K % 64 == 0 && N > 0 && K > 0, "pack_frame_w16: (N, K) = (%d, %d) must be multiples of (32, 64)", N, K);
+    const size_t total = (size_t)(N / 32) * (K / 64) * 256;
+    pack_frame_w16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, dst, N, K);
+    GENIE_LAUNCH_CHECK("pack_frame_w16");
+    return GENIE_OK;
+}
+
+// ---- launchers --------------------------------------------------------------------------------------------------------------
+namespace {
+template <int NW, int NJ, int NKB, int EPI, bool LNF>
+int launch_fr(const FrGemmArgs& a, hipStream_t st) {
+    constexpr int TN = 32 * NJ;
+    size_t lds = (size_t)NW * 32 * (TN + 4) * 4;
+    if (LNF) lds += (size_t)NW * NPL * 4 * 1056 + (size_t)2 * a.K * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm16_fr_kernel<NW, NJ, NKB, EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((a.M / 32) * (a.N / TN));
+    gemm16_fr_kernel<NW, NJ, NKB, EPI, LNF><<<grid, NW * 64, lds, st>>>(a);
+    GENIE_LAUNCH_CHECK("gemm16_fr");
+    return GENIE_OK;
+}
+
+// dispatch on the width: K = 64 NW (NKB = 1) for the Linears fed by d_model, K = 256 NW (NKB = 4) for fc2
+template <int NJ, int NKB, int EPI, bool LNF>
+int launch_fr_w(int nw, const FrGemmArgs& a, hipStream_t st) {
+    switch (nw) {
+        case 8: return launch_fr<8, NJ, NKB, EPI, LNF>(a, st);
+        case 4: return launch_fr<4, NJ, NKB, EPI, LNF>(a, st);
+        case 2: return launch_fr<2, NJ, NKB, EPI, LNF>(a, st);
+        default: break;
+    }
+    set_error("gemm16_fr: width %d not covered", 64 * nw);
+    return GENIE_E_UNSUPPORTED;
+}
+}  // namespace
+
+bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows) {
+    static const int on = study_env("GENIE_FRAME_KERNELS", 1);
+    return on && c.precision == GENIE_PREC_F16X3 && !c.qk_norm && c.S == 256 && c.head_dim == 64 && c.d_model == c.num_heads * 64 &&
+           (c.d_model == 512 || c.d_model == 256 || c.d_model == 128) && c.hidden == 4 * c.d_model && rows % 32 == 0 && rows <= 1024 &&
+           lw.spatial.frame_w16 && lw.temporal.frame_w16 && lw.mlp_frame_w16 && lw.norm1_w && lw.norm2_w;
+}
+
+// One STBlock (st_transformer.py:70-83) of a frame pass: B clips x nf frames (slots t0 .. t0 + nf - 1 of the cache) x S rows.
+//   x   f32 rows (the residual stream)            xs  = w.xn : operand copy of x (fragment order)
+//   as  = w.aux: attention outputs                 big = w.big: spatial attention operand planes, then the MLP hidden
+int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, int nf, bool want_xs,
+                         hipStream_t st) {
+    const int d = c.d_model, S = c.S, H = c.num_heads, hid = c.hidden;
+    const int M = B * nf * S, nw = d / 64;
+    uint16_t* xs = (uint16_t*)w.xn;
+    uint16_t* as = (uint16_t*)w.aux;
+    uint16_t* big = (uint16_t*)w.big;
+    const uint16_t* wq_s = lw.spatial.frame_w16;
+    const uint16_t* wp_s = wq_s + (size_t)3 * d * d * NPL;
+    const uint16_t* wq_t = lw.temporal.frame_w16;
+    const uint16_t* wp_t = wq_t + (size_t)3 * d * d * NPL;
+    const uint16_t* w1 = lw.mlp_frame_w16;
+    const uint16_t* w2 = w1 + (size_t)hid * d * NPL;
+    FrGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a_group = 1; a.a_mul = 1; a.a_off = 0;
+    a.alpha = 1.0f;
+    a.M = M;
+    a.rows_per_batch = M;
+    // ---- spatial: LayerNorm + qkv -> attention operand planes; attention; out-projection + residual (+ operand copy of x)
+    {
+        FrGemmArgs g = a;
+        g.X = x; g.ldx = d; g.ln_g = lw.norm1_w; g.ln_b = lw.norm1_b; g.ln_eps = 1e-5f;
+        g.W = wq_s; g.bias = c.qkv_bias ? lw.spatial.qkv_b : nullptr; g.N = 3 * d; g.K = d;
+        g.qkvs = big; g.qscale = c.attn_scale * 1.4426950408889634f; g.H = H; g.S = S;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
+                       "gemm16_fr_kernel (LayerNorm + qkv -> attention operand planes)");
+        GENIE_TRY((launch_fr_w<2, 1, FR_EPI_QKVS, true>(nw, g, st)));
+    }
+    {
+        ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * 64 * H * (double)(B * nf), (double)B * nf * S * d * 16.0, st,
+                       "attn_spatial_fr_kernel");
+        const size_t lds = (size_t)8 * 32 * 68 * 4 + 8 * 32 * 2 * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_spatial_fr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        attn_spatial_fr_kernel<<<dim3((unsigned)(B * nf), H, 8), 512, lds, st>>>(big, as, H);
+        GENIE_LAUNCH_CHECK("attn_spatial_fr");
+    }
+    {
+        FrGemmArgs g = a;
+        g.A = as; g.W = wp_s; g.bias = c.proj_bias ? lw.spatial.proj_b : nullptr; g.N = d; g.K = d;
+        g.Cf = x; g.ldc = d; g.C16 = xs;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)d * d, 4.0 * M * d * 4 + 4.0 * d * d, st, "gemm16_fr_kernel (proj + residual)");
+        GENIE_TRY((launch_fr_w<1, 1, FR_EPI_RES, false>(nw, g, st)));
+    }
+    // ---- temporal: qkv -> cache slots t0 .. ; decode attention over the cache; out-projection + residual
+    {
+        FrGemmArgs g = a;
+        g.A = xs; g.W = wq_t; g.bias = c.qkv_bias ? lw.temporal.qkv_b : nullptr; g.N = 3 * d; g.K = d;
+        g.Cf = w.fcache + (size_t)w.frame_t * S * 3 * d; g.ldc = 3 * d; g.rows_per_batch = (long)nf * S;
+        g.strideC = (long)w.frame_T * S * 3 * d;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
+                       "gemm16_fr_kernel (temporal qkv -> cache)");
+        GENIE_TRY((launch_fr_w<2, 1, FR_EPI_F32, false>(nw, g, st)));
+    }
+    {
+        const long n = (long)M * H;
+        ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * (w.frame_t + nf) * 64 * (double)n, (double)n * 64 * 4.0 * (2 * (w.frame_t + nf) + 2), st,
+                       "attn_temporal_fr_kernel");
+        attn_temporal_fr_kernel<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale);
+        GENIE_LAUNCH_CHECK("attn_temporal_fr");
+    }
+    {
+        FrGemmArgs g = a;
+        g.A = as; g.W = wp_t; g.bias = c.proj_bias ? lw.temporal.proj_b : nullptr; g.N = d; g.K = d;
+        g.Cf = x; g.ldc = d; g.C16 = nullptr;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)d * d, 4.0 * M * d * 3 + 4.0 * d * d, st, "gemm16_fr_kernel (proj + residual)");
+        GENIE_TRY((launch_fr_w<1, 1, FR_EPI_RES, false>(nw, g, st)));
+    }
+    // ---- MLP: LayerNorm + fc1 + GELU -> hidden operand; fc2 + residual (+ operand copy for the readout)
+    {
+        FrGemmArgs g = a;
+        g.X = x; g.ldx = d; g.ln_g = lw.norm2_w; g.ln_b = lw.norm2_b; g.ln_eps = 1e-5f;
+        g.W = w1; g.bias = c.mlp_bias ? lw.fc1_b : nullptr; g.N = hid; g.K = d; g.C16 = big;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
+                       "gemm16_fr_kernel (LayerNorm + fc1 + GELU)");
+        GENIE_TRY((launch_fr_w<2, 1, FR_EPI_GELU, true>(nw, g, st)));
+    }
+    {
+        FrGemmArgs g = a;
+        g.A = big; g.W = w2; g.bias = c.mlp_bias ? lw.fc2_b : nullptr; g.N = d; g.K = hid;
+        g.Cf = x; g.ldc = d; g.C16 = want_xs ? xs : nullptr;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * hid + 4.0 * hid * d + 4.0 * M * d * 2, st,
+                       "gemm16_fr_kernel (fc2 + residual)");
+        GENIE_TRY((launch_fr_w<1, 4, FR_EPI_RES, false>(nw, g, st)));
+    }
+    return GENIE_OK;
+}
+
+// out_x_proj on frame f_out of a frame pass from the fragment-ordered operand copy of x: logits (B, S, V) f32 token-major
+int readout_frame_f16x3(const genie_cfg& c, const genie_weights& wt, Workspace& w, int B, int nf, int f_out, float* logits, hipStream_t st) {
+    const int d = c.d_model, V = c.factored_vocab * c.num_factored;
+    FrGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const uint16_t*)w.xn; g.a_group = c.S / 32; g.a_mul = nf; g.a_off = f_out;
+    g.W = wt.out_frame_w16; g.bias = wt.out_b; g.alpha = c.readout_mult;
+    g.M = B * c.S; g.N = V; g.K = d;
+    g.Cf = logits; g.ldc = V; g.rows_per_batch = g.M; g.strideC = 0;
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * g.M * (double)V * d, 4.0 * g.M * d + 4.0 * V * d + 4.0 * g.M * V, st, "gemm16_fr_kernel (readout)");
+    return launch_fr_w<2, 1, FR_EPI_F32, false>(d / 64, g, st);
+}
+
+}  // namespace genie

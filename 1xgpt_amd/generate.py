@@ -44,11 +44,13 @@ def generate_frames(model, example_THW: torch.LongTensor, num_prompt_frames=8, m
 
 @torch.no_grad()
 def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_frames=8, maskgit_steps=2, temperature=0.0,
-                           teacher_force_time=False, noise=None, unmask_mode="random"):
+                           teacher_force_time=False, noise=None, unmask_mode="random", merge_commit=True):
     """``generate_frames`` with a temporal KV cache (genie_frame_pass): every pass runs ONE frame through the stack
     against the cached temporal keys/values of the earlier frames instead of the full 16-frame forward --
     one P-frame pass for the prompt + (T-P)*(steps+1) single-frame passes (= 2 full-pass equivalents at P=8, steps=2) instead of (T-P)*steps full
-    forwards (16).  Same outputs (per-row arithmetic is unchanged)."""
+    forwards (16).  Same outputs (per-row arithmetic is unchanged).
+    merge_commit: where the library covers it (genie_frames_pass: f16x3, heads of 64, <= 2 clips) the pass that commits frame t's
+    final tokens also carries MaskGIT step 0 of frame t+1, so a frame costs `steps` passes instead of `steps + 1`."""
     import math
     from . import _lib
     lib = _lib.load()
@@ -70,6 +72,18 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
                                         0 if logits is None else logits.data_ptr(), ws.data_ptr(), ws.numel(), st),
                    "genie_frame_pass")
 
+    def commit_and_open(final_BS, mask_BS, t, logits):
+        """Commit the final tokens of frame t AND run MaskGIT step 0 of frame t + 1 (all-mask tokens) in ONE two-frame pass
+        (genie_frames_pass): frame t + 1 attends the slot the same pass writes.  False = the library does not cover two
+        frames per pass for this model / batch (nothing was enqueued): the caller runs the two passes one by one."""
+        two = torch.stack([final_BS, mask_BS], dim=1).contiguous()
+        rc = lib.genie_frames_pass(cfg, w, two.data_ptr(), B, t, 2, cache.data_ptr(), nbytes, logits.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), st)
+        if rc == _lib.E_UNSUPPORTED:
+            return False
+        _lib.check(rc, "genie_frames_pass")
+        return True
+
     # the prompt fills slots 0..P-1 of the cache in ONE P-frame pass (genie_clean_pass with the cache's T-frame layout);
     # geometries that pass does not cover fill them frame by frame
     rc = lib.genie_clean_pass(cfg, w, ids[:, :P].contiguous().data_ptr(), B, P, T, cache.data_ptr(), nbytes, ws.data_ptr(),
@@ -83,11 +97,13 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
     samples = torch.empty(B, S, dtype=torch.int64, device=dev)
     conf = torch.empty(B, S, dtype=torch.float32, device=dev)
     gen = []
+    opened = False   # step 0 of the current frame already ran inside the previous frame's commit pass
     for k, t in enumerate(range(P, T)):
         cur = torch.full((B, S), model.mask_token_id, dtype=torch.int64, device=dev)
         unmasked = torch.zeros(B, S, dtype=torch.uint8, device=dev)
         for step in range(maskgit_steps):
-            frame_pass(cur, t, logits)
+            if not (step == 0 and opened):
+                frame_pass(cur, t, logits)
             uni = torch.rand(model.config.num_factored_vocabs, B, S, device=dev) if temperature > 1e-8 else None
             _lib.check(lib.genie_sample(cfg, logits.data_ptr(), _lib.LAYOUT_TOKEN_MAJOR, B, float(temperature),
                                         0 if uni is None else uni.data_ptr(), samples.data_ptr(), conf.data_ptr(), st),
@@ -106,8 +122,14 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
                                            unmasked.data_ptr(), samples.data_ptr(), cur.data_ptr(), S, B, S, st),
                        "genie_mask_step")
         gen.append(cur.view(B, model.h, model.w))
+        opened = False
         if t + 1 < T:  # commit frame t (its final tokens, or the ground truth when teacher-forcing in time)
-            frame_pass(ids[:, t].contiguous() if teacher_force_time else cur, t)
+            final = ids[:, t].contiguous() if teacher_force_time else cur
+            if merge_commit:
+                opened = commit_and_open(final, torch.full_like(cur, model.mask_token_id), t, logits)
+                merge_commit = opened   # (unsupported once = unsupported for the whole call)
+            if not opened:
+                frame_pass(final, t)
     outputs = torch.cat([ex[:, :P], torch.stack(gen, dim=1)], dim=1)
     return torch.cat([outputs, ex[:, P:]], dim=1)
 

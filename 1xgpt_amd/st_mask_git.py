@@ -107,6 +107,25 @@ class _Packer:
         self.keep.append(t)
         return t.data_ptr()
 
+    def _frame_geometry(self):
+        # the fragment-order kernels of the one-frame passes (csrc/kernels_frame.hip): f16x3, LayerNorm blocks, heads of 64
+        c = self.config
+        return (self.prec == _lib.PREC_F16X3 and not c.qk_norm and c.S == 256 and c.d_model in (128, 256, 512)
+                and c.d_model == 64 * c.num_heads and os.environ.get("GENIE_NO_FRAME_KERNELS", "0") != "1")
+
+    def frame_stream(self, *weights):
+        """The given Linear weights back to back as split f16 in fragment order (genie_pack_frame_w16), or 0."""
+        if not self._frame_geometry() or any(w.shape[0] % 32 or w.shape[1] % 64 for w in weights):
+            return 0
+        t = torch.empty(sum(2 * w.numel() for w in weights), dtype=torch.float16, device=self.dev)
+        off = 0
+        for w in weights:
+            _lib.check(self.lib.genie_pack_frame_w16(w.data_ptr(), t.data_ptr() + 2 * off, w.shape[0], w.shape[1], self._stream()),
+                       "genie_pack_frame_w16")
+            off += 2 * w.numel()
+        self.keep.append(t)
+        return t.data_ptr()
+
     def mlp_fused(self, mlp):
         if not (self._fused_geometry() and mlp.fc1.weight.shape[0] == 1024):
             return 0
@@ -207,6 +226,7 @@ class STMaskGIT(nn.Module):
         if packed is not None:
             w.out_w16 = packed(self.out_x_proj.weight)
             w.out_w16_wide = int(packed.is_wide(w.out_w16))
+            w.out_frame_w16 = packed.frame_stream(self.out_x_proj.weight)
         w.layers_host = layers
         self._table = (cfg, w, layers, packed)
         self._wide = sorted(packed.wide) if packed is not None else []

@@ -41,6 +41,7 @@ def _attn_struct(a: SelfAttention, packed=None, temporal=False) -> _lib.AttnWeig
         s.fused_w16 = packed.temporal_fused(a) if temporal else packed.spatial_fused(a)
         if not temporal and s.fused_w16 and os.environ.get("GENIE_NO_FUSED_QKV", "0") != "1":
             s.w16_wide |= _lib.FUSED_QKV_STREAM
+        s.frame_w16 = packed.frame_stream(a.qkv.weight, a.proj.weight)
     return s
 
 
@@ -72,6 +73,7 @@ class STBlock(nn.Module):
             lw.fc1_w16, lw.fc2_w16 = packed(self.mlp.fc1.weight), packed(self.mlp.fc2.weight)
             lw.w16_wide = (_lib.WIDE_FC1 if packed.is_wide(lw.fc1_w16) else 0) | (_lib.WIDE_FC2 if packed.is_wide(lw.fc2_w16) else 0)
             lw.mlp_fused_w16 = packed.mlp_fused(self.mlp)
+            lw.mlp_frame_w16 = packed.frame_stream(self.mlp.fc1.weight, self.mlp.fc2.weight)
         return lw
 
     def _cfg(self, T, S, precision=_lib.PREC_EXACT) -> _lib.GenieCfg:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 2
+#define GENIE_ABI_VERSION 3
 
 enum {
     GENIE_OK = 0,
@@ -80,6 +80,9 @@ typedef struct genie_attn_weights {
     /* GENIE_PREC_F16X3 range flags of the packed tensors (bit 0: qkv_w16, bit 1: proj_w16): set when the tensor's hi plane
      * reaches |w| >= 32, see "range contract" below.  0 in the other precisions. */
     int32_t w16_wide;
+    /* GENIE_PREC_F16X3, head_dim 64 (ABI 3), or NULL (the one-frame passes then run the row-major kernels): [qkv | proj] as split
+     * f16 in FRAGMENT ORDER for the one-frame passes of generate (genie_pack_frame_w16, genie_frames_pass). */
+    const uint16_t* frame_w16;
 } genie_attn_weights;
 
 /* STBlock parameters (genie/st_transformer.py:28-68). */
@@ -100,6 +103,7 @@ typedef struct genie_layer_weights {
      * (genie_pack_mlp_fused_bf16), or NULL (unfused launches). */
     const uint16_t* mlp_fused_w16;
     int32_t w16_wide; /* f16x3 range flags: bit 0 fc1_w16, bit 1 fc2_w16 */
+    const uint16_t* mlp_frame_w16; /* GENIE_PREC_F16X3 (ABI 3): [fc1 | fc2] in fragment order (genie_pack_frame_w16), or NULL */
 } genie_layer_weights;
 
 /* STMaskGIT parameters (genie/st_mask_git.py:36-61); `layers` is a HOST array of num_layers entries. */
@@ -112,13 +116,15 @@ typedef struct genie_weights {
     const uint16_t* out_w16;
     const genie_layer_weights* layers_host;
     int32_t out_w16_wide; /* f16x3 range flag of out_w16 */
+    const uint16_t* out_frame_w16; /* GENIE_PREC_F16X3 (ABI 3): out_w in fragment order (genie_pack_frame_w16), or NULL */
 } genie_weights;
 
 int genie_version(void);
 /* The compiler's view of the POD structs above, for bindings to check their own declarations against (tests/test_abi_and_host.py):
  * out[0..8) = sizeof(genie_cfg), sizeof(genie_attn_weights), offsetof(.., fused_w16), offsetof(.., w16_wide),
  * sizeof(genie_layer_weights), offsetof(.., mlp_fused_w16), offsetof(.., w16_wide), sizeof(genie_weights),
- * offsetof(.., out_w16_wide).  Writes min(n, 9) entries, returns 9. */
+ * offsetof(.., out_w16_wide), then (ABI 3) offsetof(genie_attn_weights, frame_w16), offsetof(genie_layer_weights, mlp_frame_w16),
+ * offsetof(genie_weights, out_frame_w16).  Writes min(n, 12) entries, returns 12. */
 int genie_abi_layout(size_t* out_host, int n);
 const char* genie_last_error(void);
 /* 0 if the kernels support this configuration, GENIE_E_SHAPE otherwise (message in genie_last_error). */
@@ -272,6 +278,21 @@ int genie_masked_frames_logits(const genie_cfg* cfg, const genie_weights* w, con
  * to commit them.  Same per-row arithmetic as the full forward restricted to frame t. */
 int genie_frame_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* frame_ids, int B, int t, float* cache,
                      size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for nf CONSECUTIVE frames t0 .. t0 + nf - 1 in one pass (ABI 3): frame_ids (B, nf, S); every layer writes the nf
+ * cache slots and frame t0 + i attends slots 0 .. t0 + i (those of this pass included); `logits` (B, S, V) token-major are those
+ * of the LAST frame of the pass (NULL = not wanted).  generate()'s use: the pass that commits the final tokens of frame t also
+ * carries the first MaskGIT step of frame t + 1 (all-mask tokens), so a new frame costs `steps` passes instead of `steps + 1`
+ * (generate.py:81-95: the reference recomputes everything per step).  nf == 1 is genie_frame_pass; nf > 1 returns
+ * GENIE_E_UNSUPPORTED (nothing enqueued) unless the fragment-order kernels cover the model (GENIE_PREC_F16X3, head_dim 64,
+ * LayerNorm blocks, S 256, frame_w16 streams present, B * nf <= 4): the caller then runs the frames one by one. */
+int genie_frames_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* frame_ids, int B, int t0, int nf, float* cache,
+                      size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* f32 (N, K) row-major weight -> split f16 in FRAGMENT ORDER (2 N K 16-bit values) for the one-frame kernels
+ * (csrc/kernels_frame.hip): blocks of 32 rows x 64 k, per block [plane hi | lo'][MFMA step 0..3] fragments of 1 KB = the 64 lanes'
+ * 16-byte operand pieces (lane 32 h + r: row r, k = 16 step + 8 h .. + 7), so that every operand load of those kernels is a
+ * contiguous 1 KB read.  N % 32 == 0, K % 64 == 0.  Same split as genie_pack_split_f16.
+ * Reference counterpart: none (nn.Linear weights are f32: st_transformer.py:16-25, attention.py:27-29, st_mask_git.py:60-61). */
+int genie_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, void* stream);
 
 /* Factored cross-entropy + accuracy partial sums from token-major or BCTHW logits of frames [t0,t1)
  * (st_mask_git.py:231-253; eval_utils.py:44-77).

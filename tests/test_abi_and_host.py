@@ -27,19 +27,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in genie_hip.h but not exported"
         assert n in lib_mod.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
     assert sorted(lib_mod.SIGNATURES) == names
-    assert L.genie_version() == 2
+    assert L.genie_version() == 3
 
 
 def test_struct_layout_matches_header():
     """The ctypes declarations of _lib.py against the COMPILER's layout of include/genie_hip.h (genie_abi_layout): sizes of the
-    four POD structs and the offsets of the fields ABI version 2 added (fused streams, f16x3 range flags)."""
+    four POD structs and the offsets of the fields ABI versions 2 and 3 added (fused streams, f16x3 range flags, frame streams)."""
     lib_mod = pkg("_lib")
     L = lib_mod.load()
-    out = (ctypes.c_size_t * 9)()
-    assert L.genie_abi_layout(out, 9) == 9
+    out = (ctypes.c_size_t * 12)()
+    assert L.genie_abi_layout(out, 12) == 12
     A, LW, W = lib_mod.AttnWeights, lib_mod.LayerWeights, lib_mod.Weights
     mine = [ctypes.sizeof(lib_mod.GenieCfg), ctypes.sizeof(A), A.fused_w16.offset, A.w16_wide.offset, ctypes.sizeof(LW),
-            LW.mlp_fused_w16.offset, LW.w16_wide.offset, ctypes.sizeof(W), W.out_w16_wide.offset]
+            LW.mlp_fused_w16.offset, LW.w16_wide.offset, ctypes.sizeof(W), W.out_w16_wide.offset, A.frame_w16.offset,
+            LW.mlp_frame_w16.offset, W.out_frame_w16.offset]
     assert list(out) == mine, (list(out), mine)
     assert ctypes.sizeof(lib_mod.GenieCfg) == 18 * 4
 

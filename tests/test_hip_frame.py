@@ -1,0 +1,121 @@
+"""The one-frame passes of generate on the fragment-order kernels (csrc/kernels_frame.hip; generate.py:81-95,
+st_mask_git.py:163-169 restricted to the frame being decoded): weight packing bit-exact, every frame pass equal to the same
+frames of the full 16-frame forward (temporal attention is causal), two frames per pass equal to one by one, the merged
+commit + first-step schedule of generate equal to the plain KV-cache schedule and to the reference goldens.  Needs a GPU: -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def _model(d, heads, layers=2, precision="f16x3", seed=11):
+    cfg = pkg("config").GenieConfig(num_layers=layers, num_heads=heads, d_model=d, T=16, S=256, num_factored_vocabs=2,
+                                    qk_norm=False, use_mup=False)
+    sd = pkg("synthetic").make_state_dict(cfg, seed=seed, law="conditioned")
+    return cfg, pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+
+
+def test_pack_frame_w16_is_the_row_major_split_in_fragment_order():
+    """genie_pack_frame_w16: block (32 rows x 64 k) -> [plane][step] fragments, lane 32 h + r = row r, k = 16 step + 8 h .. + 7;
+    the same hi / lo' values as genie_pack_split_f16 (bit-exact)."""
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    N, K = 96, 192
+    g = torch.Generator(device="cpu").manual_seed(5)
+    W = (torch.randn(N, K, generator=g) * torch.logspace(-6, 1, K)[None, :]).cuda().contiguous()
+    rm = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+    fr = torch.empty(2 * N * K, dtype=torch.float16, device="cuda")
+    _lib.check(lib.genie_pack_split_f16(W.data_ptr(), rm.data_ptr(), W.numel(), st), "pack_split")
+    _lib.check(lib.genie_pack_frame_w16(W.data_ptr(), fr.data_ptr(), N, K, st), "pack_frame")
+    rm = rm.cpu().numpy().view(np.uint16)
+    got = fr.cpu().numpy().view(np.uint16).reshape(N // 32, K // 64, 2, 4, 2, 32, 8)   # rb, kb, plane, step, h, r, e
+    want = rm.reshape(2, N // 32, 32, K // 64, 4, 2, 8).transpose(1, 3, 0, 4, 5, 2, 6)  # p, rb, r, kb, s, h, e -> rb, kb, p, s, h, r, e
+    assert np.array_equal(got, want)
+    assert lib.genie_pack_frame_w16(W.data_ptr(), fr.data_ptr(), 48, 64, st) == _lib.E_SHAPE
+
+
+@pytest.mark.parametrize("d,heads", [(512, 8), (256, 4), (128, 2)])
+def test_frame_passes_equal_full_forward_frames(d, heads):
+    """genie_frame_pass / genie_frames_pass on the fragment-order kernels against the full 16-frame forward of the same model
+    (256x256-tile GEMMs, LDS-DMA attention kernels: validated against the oracle and the reference goldens elsewhere): logits of
+    every decoded frame within f32 accumulation-order noise; one frame per pass, two frames per pass, two clips."""
+    cfg, m = _model(d, heads)
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    c, w = m._weights()[:2]
+    assert w.out_frame_w16 and w.layers_host[0].spatial.frame_w16 and w.layers_host[0].mlp_frame_w16   # the new path is the one that runs
+    T, S = cfg.T, cfg.S
+    V = cfg.factored_vocab_size * cfg.num_factored_vocabs
+    for B in (1, 2):
+        ids = dev(pkg("synthetic").make_clips(B, cfg, seed=70 + B)).view(B, T, S)
+        ids[:, 3, ::3] = cfg.image_vocab_size       # some mask tokens
+        full = m.compute_logits(ids.view(B, T, 16, 16))          # (B, V, T, 16, 16)
+        scale = full.abs().max().item()
+        ws = m._workspace(B)
+        nbytes = lib.genie_prefix_cache_bytes(c, B)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def ref(t):
+            return full[:, :, t].reshape(B, V, S).transpose(1, 2)   # (B, S, V)
+
+        # one frame per pass
+        cache = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+        for t in range(4):
+            lg = torch.full((B, S, V), float("nan"), dtype=torch.float32, device="cuda")
+            _lib.check(lib.genie_frame_pass(c, w, ids[:, t].contiguous().data_ptr(), B, t, cache.data_ptr(), nbytes, lg.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), st), "genie_frame_pass")
+            err = (lg - ref(t)).abs()
+            assert err.max().item() < 3e-5 * max(1.0, scale) and err.median().item() < 1e-5, (B, t, err.max().item(), err.median().item())
+        # two frames per pass: frames (0, 1), then (2, 3) against the slots the first pass wrote; the cache equals the one-by-one cache
+        cache2 = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+        for t0 in (0, 2):
+            lg = torch.full((B, S, V), float("nan"), dtype=torch.float32, device="cuda")
+            _lib.check(lib.genie_frames_pass(c, w, ids[:, t0:t0 + 2].contiguous().data_ptr(), B, t0, 2, cache2.data_ptr(), nbytes,
+                                             lg.data_ptr(), ws.data_ptr(), ws.numel(), st), "genie_frames_pass")
+            err = (lg - ref(t0 + 1)).abs()
+            assert err.max().item() < 3e-5 * max(1.0, scale), (B, t0, err.max().item())
+        L = cfg.num_layers
+        a = cache.view(L, B, T, S, 3 * d)[:, :, :4]
+        b = cache2.view(L, B, T, S, 3 * d)[:, :, :4]
+        assert torch.equal(a, b)   # per-row arithmetic does not depend on how many frames share a pass
+        assert (cache2.view(L, B, T, S, 3 * d)[:, :, 4:] == 0).all()
+
+
+def test_frames_pass_refuses_what_it_does_not_cover():
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    cfg, m = _model(128, 2, precision="exact")
+    c, w = m._weights()[:2]
+    B = 1
+    ids = dev(pkg("synthetic").make_clips(B, cfg, seed=3)).view(B, cfg.T, cfg.S)
+    ws = m._workspace(B)
+    nbytes = lib.genie_prefix_cache_bytes(c, B)
+    cache = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.genie_frames_pass(c, w, ids[:, 0:2].contiguous().data_ptr(), B, 0, 2, cache.data_ptr(), nbytes, 0, ws.data_ptr(), ws.numel(), st)
+    assert rc == _lib.E_UNSUPPORTED and b"frames_pass" in lib.genie_last_error()
+    assert (cache == 0).all()
+    assert lib.genie_frames_pass(c, w, ids.data_ptr(), B, 15, 2, cache.data_ptr(), nbytes, 0, ws.data_ptr(), ws.numel(), st) == _lib.E_ARG
+
+
+@pytest.mark.parametrize("steps", [2, 3])
+def test_merged_commit_schedule_equals_plain_kv_cache_schedule(steps):
+    """generate_frames_cached with the commit pass of frame t carrying step 0 of frame t + 1 (genie_frames_pass, 2 frames) produces
+    the frames of the schedule that runs them as two passes -- same per-row arithmetic, so exactly the same ids."""
+    cfg, m = _model(256, 4, layers=3)
+    G = pkg("generate")
+    for B in (1, 2):
+        ex = dev(pkg("synthetic").make_clips(B, cfg, seed=40 + B)).view(B, 16, 16, 16)
+        noise = torch.rand(8, max(steps - 1, 1), B, cfg.S, device="cuda")
+        for tf in (False, True):
+            plain = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=False)
+            merged = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=True)
+            assert torch.equal(plain, merged)
