@@ -87,6 +87,7 @@ SIGNATURES = {
     "genie_frames_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_size_t,
                                     c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_pack_frame_w16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
+    "genie_frame_linear": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_metric_hits": (C.c_int, [c_ptr, C.c_int64, c_ptr, C.c_int64, C.c_int, C.c_int64, c_ptr, C.c_double, C.c_double,
                                     C.c_double, c_ptr, c_ptr]),
     "genie_factored_ce": (C.c_int, [C.POINTER(GenieCfg), c_ptr, C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int,

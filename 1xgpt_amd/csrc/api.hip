@@ -527,6 +527,11 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_
     return genie_frames_pass(cfg, wt, frame_ids, B, t, 1, cache, cache_bytes, logits, workspace, workspace_bytes, stream);
 }
 
+int genie_frame_linear(const uint16_t* a_fr, const uint16_t* w_fr, const float* bias, float* y, int M, int N, int K, int mode, void* stream) {
+    GENIE_CHECK_ARG(a_fr && w_fr && y && mode >= 0 && mode <= 2, "frame_linear: bad argument");
+    return launch_frame_linear(a_fr, w_fr, bias, y, M, N, K, mode, as_stream(stream));
+}
+
 int genie_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, void* stream) {
     GENIE_CHECK_ARG(src && dst, "pack_frame_w16: NULL pointer");
     return launch_pack_frame_w16(src, dst, N, K, as_stream(stream));

@@ -225,6 +225,7 @@ int launch_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, hipStre
 bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows);
 int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, int nf, bool want_xs,
                          hipStream_t st);
+int launch_frame_linear(const uint16_t* A, const uint16_t* W, const float* bias, float* y, int M, int N, int K, int mode, hipStream_t st);
 int readout_frame_f16x3(const genie_cfg& c, const genie_weights& wt, Workspace& w, int B, int nf, int f_out, float* logits,
                         hipStream_t st);
 // kernels_attn_dma.hip: spatial attention over the operand planes written by launch_gemm16_pp(G16X_OUT16 | G16X_QKV)

@@ -64,6 +64,19 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Hand-placed LDS fragment reads for the LDS-tiled kernel: left to the compiler every group of matrix instructions sits behind an
+// s_waitcnt lgkmcnt(0) (a full LDS round trip per group); fr_lds_rd issues a read the compiler knows nothing about, fr_lds_wait<N>
+// is "all but my N youngest LDS reads have landed", tied to the fragment it guards (LDS reads return in order; no scalar load may
+// be outstanding in such a section: it shares the counter).
+template <int OFF>
+__device__ __forceinline__ void fr_lds_rd(u32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void fr_lds_wait(u32x4& frag) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+}
+
 // every operand request of these kernels is issued before the first wait; the scheduler must not sink loads below the
 // matrix instructions to save registers (a launch is one memory round trip long)
 #define FR_PIN_LOADS() __builtin_amdgcn_sched_barrier(0)
@@ -99,23 +112,26 @@ struct FrGemmArgs {
 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// C = epilogue(alpha * A . W^T + bias): workgroup = 32 rows x (32 NJ) columns, NW waves split K (wave w: 64-k blocks w, w + NW, ..),
+// C = epilogue(alpha * A . W^T + bias): workgroup = (32 MI) rows x (32 NJ) columns, NW waves split K (wave w: 64-k blocks w, w + NW, ..),
 // NKB blocks per wave, RING of them in flight.  Two accumulators per tile as in gemm16_sm (hi.hi | hi.lo' + lo'.hi, the second
-// scaled by 2^-11 at the end: valid for any operand magnitude).
+// scaled by 2^-11 at the end: valid for any operand magnitude).  MI = 2 (two-frame passes, M >= 512): the same number of workgroups as
+// a one-frame pass, every weight fragment feeds both row blocks -- with MI = 1 the 384-512 workgroups of such a pass ran as two rounds
+// (one workgroup per CU: LDS and registers) and the pass cost 1.7x a one-frame pass (profiles/r05b_gen1_kernel_stats.txt).
+// A row's result does not depend on MI (same k order per wave, same wave order in the reduce).
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int NW, int NJ, int NKB, int EPI, bool LNF>
+template <int NW, int MI, int NJ, int NKB, int EPI, bool LNF>
 __global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW >= 4 ? NW / 4 : 1, NW >= 4 ? NW / 4 : 1)))
 void gemm16_fr_kernel(const FrGemmArgs a) {
-    constexpr int NT = NW * 64, TN = 32 * NJ, PITCH = TN + 4;
+    constexpr int NT = NW * 64, TM = 32 * MI, TN = 32 * NJ, PITCH = TN + 4;
     constexpr int RING = NKB > 1 ? 2 : 1;
     static_assert(!LNF || NKB == 1, "LayerNorm-fused A: the waves tile one row of K = 64 NW");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = reinterpret_cast<float*>(smem);                                   // [NW][32][PITCH]
+    float* red = reinterpret_cast<float*>(smem);                                   // [NW][TM][PITCH]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = a.N / TN;
-    const int rb = blockIdx.x / nt, jt = blockIdx.x % nt;
-    const int m0 = rb * 32, n0 = jt * TN;
+    const int rb0 = (blockIdx.x / nt) * MI, jt = blockIdx.x % nt;   // first 32-row block, column tile
+    const int m0 = rb0 * 32, n0 = jt * TN;
     const int KB = a.K / 64;
 
     // (every kernel argument the request phase needs, in SGPRs before the first request: fetched lazily they were three to four
@@ -124,24 +140,20 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
                  "s"(a.K), "s"(a.N), "s"(a.a_group), "s"(a.a_mul), "s"(a.a_off));
     // ---- requests first, oldest = needed first (loads return in order): bias and LayerNorm parameters, (LNF) the f32 rows, the
     // weight fragments of this wave's first RING blocks, the residual rows
-    constexpr int C4 = TN / 4, ITEMS = 32 * C4, PASSES = (ITEMS + NT - 1) / NT;
-    f32x4 pre_b[PASSES];
-#pragma unroll
-    for (int q = 0; q < PASSES; ++q) {
-        const int idx = tid + q * NT;
-        pre_b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias && idx < ITEMS) pre_b[q] = *reinterpret_cast<const f32x4*>(a.bias + n0 + (idx % C4) * 4);
-    }
+    constexpr int C4 = TN / 4, ITEMS = TM * C4, PASSES = (ITEMS + NT - 1) / NT;
+    static_assert(NT % C4 == 0, "a thread keeps its columns over the passes of the row-major phase");
+    f32x4 pre_b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) pre_b = *reinterpret_cast<const f32x4*>(a.bias + n0 + (tid % C4) * 4);
     f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (LNF) {   // gamma | beta: one float4 per thread (K / 2 <= NT float4s), staged through LDS
         if (tid < a.K / 4) gbv = reinterpret_cast<const f32x4*>(a.ln_g)[tid];
         else if (tid < a.K / 2) gbv = reinterpret_cast<const f32x4*>(a.ln_b)[tid - a.K / 4];
     }
-    constexpr int RW = 32 / NW;                 // rows per wave in the LayerNorm prologue
+    constexpr int RW = TM / NW;                 // rows per wave in the LayerNorm prologue
     constexpr int G = RW / 4 > 0 ? RW / 4 : 1;  // groups of 4 rows (a wave instruction = 4 rows x 64 floats)
     f32x4 xv[LNF ? G : 1][LNF ? NW : 1];
     if constexpr (LNF) {
-        static_assert(RW % 4 == 0, "LayerNorm prologue: 4 rows per instruction");
+        static_assert(!LNF || RW % 4 == 0, "LayerNorm prologue: 4 rows per instruction");
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float* xr = a.X + (size_t)(m0 + RW * wid + 4 * g + (lane >> 4)) * a.ldx + 4 * (lane & 15);
@@ -149,7 +161,7 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
             for (int kb = 0; kb < NW; ++kb) xv[g][kb] = *reinterpret_cast<const f32x4*>(xr + 64 * kb);
         }
     }
-    u32x4 wf[RING][NJ][NPL][4], af[RING][NPL][4];
+    u32x4 wf[RING][NJ][NPL][4], af[RING][MI][NPL][4];
     auto load_w = [&](int slot, int kb) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -160,13 +172,17 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
                 for (int s = 0; s < 4; ++s) wf[slot][j][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * FR);
         }
     };
-    const long arb = LNF ? 0 : ((long)(rb / a.a_group) * a.a_mul + a.a_off) * a.a_group + rb % a.a_group;
     auto load_a = [&](int slot, int kb) {
-        const uint16_t* src = a.A + fr_frag(arb, kb, KB, 0, 0) + lane * 8;
 #pragma unroll
-        for (int p = 0; p < NPL; ++p)
+        for (int i = 0; i < MI; ++i) {
+            const int rb = rb0 + i;
+            const long arb = ((long)(rb / a.a_group) * a.a_mul + a.a_off) * a.a_group + rb % a.a_group;
+            const uint16_t* src = a.A + fr_frag(arb, kb, KB, 0, 0) + lane * 8;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) af[slot][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * FR);
+            for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) af[slot][i][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * FR);
+        }
     };
 #pragma unroll
     for (int i = 0; i < RING; ++i) {
@@ -185,31 +201,36 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
             if (idx < ITEMS) pre_r[q] = *reinterpret_cast<const f32x4*>(a.Cf + (size_t)(m0 + rl) * a.ldc + n0 + c4);
         }
     }
-
     FR_PIN_LOADS();
 
-    f32x16 accm[NJ], accc[NJ];
+    f32x16 accm[MI][NJ], accc[MI][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { accm[j][e] = 0.f; accc[j][e] = 0.f; }
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accc[i][j][e] = 0.f; }
+    // column tile j outermost: its weight fragments are dead after its 12 MI instructions, before tile j + 1's accumulators start
     auto compute = [&](int slot) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                accm[j] = mma16(af[slot][0][s], wf[slot][j][0][s], accm[j]);
-                accc[j] = mma16(af[slot][0][s], wf[slot][j][1][s], accc[j]);
-                accc[j] = mma16(af[slot][1][s], wf[slot][j][0][s], accc[j]);
-            }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    accm[i][j] = mma16(af[slot][i][0][s], wf[slot][j][0][s], accm[i][j]);
+                    accc[i][j] = mma16(af[slot][i][0][s], wf[slot][j][1][s], accc[i][j]);
+                    accc[i][j] = mma16(af[slot][i][1][s], wf[slot][j][0][s], accc[i][j]);
+                }
     };
 
     if constexpr (LNF) {
         // ---- LayerNorm in the wave: lane (row q = lane / 16 of each 4-row group, columns 4 (lane % 16) .. + 3 of every 64-k block);
-        // the normalised rows go to LDS in fragment order (+16 B per half fragment: conflict-free 8-byte stores)
+        // the normalised rows go to LDS in fragment order (+16 B per half fragment: conflict-free 8-byte stores).  The staging area
+        // shares its LDS with the partial tiles of the reduce (barrier between the last fragment read and the first partial store).
         constexpr int HS = 528, SS = 2 * HS, KBS = NPL * 4 * SS;            // bytes
-        unsigned char* alds = smem + (size_t)NW * 32 * PITCH * 4;            // [NW blocks][NPL][4 steps][2 halves][32 rows x 16 B (+16)]
-        float* gb = reinterpret_cast<float*>(alds + (size_t)NW * KBS);      // gamma | beta, K floats each
+        unsigned char* alds = smem;                                          // [MI row blocks][NW k-blocks][NPL][4 steps][2 halves][32 rows x 16 B (+16)]
+        float* gb = reinterpret_cast<float*>(smem + (size_t)MI * NW * KBS); // gamma | beta, K floats each
         if (tid < a.K / 2) reinterpret_cast<f32x4*>(gb)[tid] = gbv;
         __syncthreads();
         const float invK = 1.0f / (float)(64 * NW);
@@ -227,9 +248,10 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
                 for (int e = 0; e < 4; ++e) { xv[g][kb][e] -= mean; q = fmaf(xv[g][kb][e], xv[g][kb][e], q); }
             q = row16_sum(q);
             const float rstd = 1.0f / sqrtf(q * invK + a.ln_eps);
-            const int r = RW * wid + 4 * g + (lane >> 4);                    // row of the tile
+            const int rt = RW * wid + 4 * g + (lane >> 4);                   // row of the workgroup's tile
+            const int r = rt & 31;
             const int c = lane & 15;                                         // columns 4 c .. 4 c + 3 of the block
-            unsigned char* dst = alds + (c >> 2) * SS + ((c >> 1) & 1) * HS + r * 16 + (c & 1) * 8;
+            unsigned char* dst = alds + (size_t)(rt >> 5) * NW * KBS + (c >> 2) * SS + ((c >> 1) & 1) * HS + r * 16 + (c & 1) * 8;
 #pragma unroll
             for (int kb = 0; kb < NW; ++kb) {
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(gb + 64 * kb + 4 * c);
@@ -244,12 +266,16 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
             }
         }
         __syncthreads();
-        const unsigned char* src = alds + (size_t)wid * KBS + (lane >> 5) * HS + (lane & 31) * 16;
 #pragma unroll
-        for (int p = 0; p < NPL; ++p)
+        for (int i = 0; i < MI; ++i) {
+            const unsigned char* src = alds + ((size_t)i * NW + wid) * KBS + (lane >> 5) * HS + (lane & 31) * 16;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) af[0][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * SS);
+            for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) af[0][i][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * SS);
+        }
         compute(0);
+        __syncthreads();   // every wave has its A fragments in registers: the staging area becomes the partial tiles
     } else {
 #pragma unroll
         for (int i = 0; i < NKB; ++i) {
@@ -264,12 +290,14 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
     // ---- the NW partial tiles meet in LDS (accumulator element e of lane (r, h): row 8 (e >> 2) + 4 h + (e & 3), column r)
     {
         const int r = lane & 31, h = lane >> 5;
-        float* mine = red + (size_t)wid * 32 * PITCH;
+        float* mine = red + (size_t)wid * TM * PITCH;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                mine[(8 * (e >> 2) + 4 * h + (e & 3)) * PITCH + 32 * j + r] = accm[j][e] + accc[j][e] * (1.0f / 2048.0f);
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    mine[(32 * i + 8 * (e >> 2) + 4 * h + (e & 3)) * PITCH + 32 * j + r] = accm[i][j][e] + accc[i][j][e] * (1.0f / 2048.0f);
     }
     __syncthreads();
     // ---- row-major phase: thread -> (row, 4 columns); sums the waves in order (bit-reproducible), bias, GELU / residual; f32
@@ -281,8 +309,8 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
             const int rl = idx / C4, c4 = (idx % C4) * 4;
             f32x4 v = *reinterpret_cast<const f32x4*>(red + rl * PITCH + c4);
 #pragma unroll
-            for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 32 + rl) * PITCH + c4);
-            v = v * a.alpha + pre_b[q];
+            for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(red + ((size_t)w * TM + rl) * PITCH + c4);
+            v = v * a.alpha + pre_b;
             if constexpr (EPI == FR_EPI_GELU) {
                 const genie_f2 g0 = gelu_erf_fast2(genie_f2{v[0], v[1]}), g1 = gelu_erf_fast2(genie_f2{v[2], v[3]});
                 v = f32x4{g0[0], g0[1], g1[0], g1[1]};
@@ -300,17 +328,18 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
     if (EPI == FR_EPI_RES && !a.C16) return;
     __syncthreads();
     if constexpr (EPI == FR_EPI_RES || EPI == FR_EPI_GELU) {
-        // ---- fragment-order phase: thread -> (step sl of the tile's columns, lane of the fragment): 8 values of one row
+        // ---- fragment-order phase: thread -> (row block, step sl of the tile's columns, lane of the fragment): 8 values of one row
         const int KBo = a.N / 64;
-        for (int idx = tid; idx < (TN / 16) * 64; idx += NT) {
-            const int sl = idx >> 6, fl = idx & 63, r = fl & 31, h = fl >> 5;
-            const float* src = red + r * PITCH + 16 * sl + 8 * h;
+        for (int idx = tid; idx < MI * (TN / 16) * 64; idx += NT) {
+            const int fl = idx & 63, r = fl & 31, h = fl >> 5;
+            const int sl = (idx >> 6) % (TN / 16), i = (idx >> 6) / (TN / 16);
+            const float* src = red + (32 * i + r) * PITCH + 16 * sl + 8 * h;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             u32x4 hi, lo;
             split8(v, hi, lo);
             const int col = n0 + 16 * sl;
-            uint16_t* dst = a.C16 + fr_frag(rb, col >> 6, KBo, 0, (col & 63) >> 4) + fl * 8;
+            uint16_t* dst = a.C16 + fr_frag(rb0 + i, col >> 6, KBo, 0, (col & 63) >> 4) + fl * 8;
             *reinterpret_cast<u32x4*>(dst) = hi;
             *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
         }
@@ -323,38 +352,318 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
         const int dH = a.H * 64;
         const int which = n0 / dH, head = (n0 % dH) / 64;
         const int blocks = a.S / 32;                           // 32-token blocks per sequence
-        const long seq = rb / blocks;
-        const int blk = rb % blocks;
         const size_t unit = (size_t)blocks * NPL * 4 * FR;     // one of Q | K | V^T of a (sequence, head)
-        uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
-        if (which < 2) {
-            const float sc = which == 0 ? a.qscale : 1.0f;
-            for (int idx = tid; idx < 256; idx += NT) {
-                const int sl = idx >> 6, fl = idx & 63, r = fl & 31, h = fl >> 5;
-                const float* src = red + r * PITCH + 16 * sl + 8 * h;
+        const float sc = which == 0 ? a.qscale : 1.0f;
+        for (int idx = tid; idx < MI * 256; idx += NT) {
+            const int i = idx >> 8, sub = (idx >> 6) & 3, fl = idx & 63, r = fl & 31, h = fl >> 5;
+            const int rb = rb0 + i;
+            const long seq = rb / blocks;
+            const int blk = rb % blocks;
+            uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
+            const float* tile = red + (size_t)32 * i * PITCH;
+            float v[8];
+            uint16_t* dst;
+            int lo_off;
+            if (which < 2) {       // sub = step
+                const float* src = tile + r * PITCH + 16 * sub + 8 * h;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                dst = base + ((size_t)blk * NPL * 4 + sub) * FR + fl * 8;
+                lo_off = 4 * FR;
+            } else {               // sub = 2 dt + m
+                const int dt = sub >> 1, m = sub & 1;
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) v[s8] = tile[(16 * m + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + 32 * dt + r];
+                dst = base + ((size_t)(blk * 2 + dt) * 2 + m) * NPL * FR + fl * 8;
+                lo_off = FR;
+            }
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            *reinterpret_cast<u32x4*>(dst) = hi;
+            *reinterpret_cast<u32x4*>(dst + lo_off) = lo;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same Linear for passes of >= 1024 rows (4+ clips per pass, the 8-frame prompt of generate): there the register-direct
+// kernel above re-reads every weight fragment once per 32-64 rows and runs in several rounds, and the row-major mid-size kernels
+// (gemm16_nt / gemm16_v2: two LDS stages of 64 k) wait out one memory round trip per stage (8 stages at K = 512: 24-37 us for
+// 3-6 GFLOP, profiles/r05a_gen{8,16}_kernel_stats.txt).  Here: workgroup tile (32 WM MI) x (32 WN NJ), NST stages of 32 k in an
+// LDS ring filled by LDS-DMA -- a stage's operand pieces ARE fragments (1 KB contiguous in global memory, lane-linear in LDS: no
+// swizzle, conflict-free ds_read_b128), NST - 1 stages in flight, one barrier per stage, counted vmcnt.  Wave (wm, wn) owns a
+// (32 MI) x (32 NJ) tile; epilogues as above but wave-local (no split-K reduce): accumulators -> the wave's LDS tile -> whole rows.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int MI, int NJ, int NST, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, 1) void gemm16_frm_kernel(const FrGemmArgs a) {
+    constexpr int NWV = WM * WN, RBA = WM * MI, RBW = WN * NJ, SLOTS = RBA + RBW;
+    constexpr int STAGE_B = SLOTS * 4096;                 // [slot][plane][step of the half block] x 1 KB
+    constexpr int PIECES = SLOTS * 4, PPW = PIECES / NWV;
+    static_assert(PIECES % NWV == 0, "a stage's pieces divide evenly over the waves");
+    constexpr int TNW = 32 * NJ, PITCH = TNW + 4;         // a wave's epilogue tile: [32 MI][PITCH] floats
+    static_assert(NWV * 32 * MI * PITCH * 4 <= NST * STAGE_B, "the epilogue tiles live in the ring");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int nt = a.N / (32 * RBW);
+    const int rbA0 = (blockIdx.x / nt) * RBA, rbW0 = (blockIdx.x % nt) * RBW;
+    const int KB = a.K / 64, nk = a.K / 32;
+
+    // ---- this wave's share of a stage: PPW pieces (slot, plane, step); global fragment base of half block 0
+    const uint16_t* gp[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wid * PPW + i, slot = q >> 2, pl = (q >> 1) & 1, s2 = q & 1;
+        if (slot < RBA) {
+            const int rb = rbA0 + slot;
+            const long arb = ((long)(rb / a.a_group) * a.a_mul + a.a_off) * a.a_group + rb % a.a_group;
+            gp[i] = a.A + fr_frag(arb, 0, KB, pl, s2) + lane * 8;
+        } else {
+            gp[i] = a.W + fr_frag(rbW0 + slot - RBA, 0, KB, pl, s2) + lane * 8;
+        }
+    }
+    auto issue = [&](int hk) {   // half block hk (32 k) -> ring slot hk % NST
+        const size_t koff = ((size_t)(hk >> 1) * NPL * 4 + 2 * (hk & 1)) * FR;
+        unsigned char* dst = smem + (size_t)(hk % NST) * STAGE_B + (size_t)wid * PPW * 1024;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) issue(s);
+
+    f32x16 accm[MI][NJ], accc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accc[i][j][e] = 0.f; }
+
+    for (int k = 0; k < nk; ++k) {
+        // stage k has landed when at most the pieces of the min(NST - 2, nk - 1 - k) younger stages are outstanding
+        const int younger = nk - 1 - k < NST - 2 ? nk - 1 - k : NST - 2;
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of stage k are visible; the slot of stage k - 1 is free
+        // the refill of the freed slot, then all 4 (MI + NJ) fragment reads of the stage before the first matrix instruction (the
+        // waits then count down in step with the MFMAs instead of draining before every group)
+        if (k + NST - 1 < nk) issue(k + NST - 1);
+        const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem + (unsigned)(k % NST) * STAGE_B + lane * 16;
+        const unsigned aA = sbase + (unsigned)(wm * MI) * 4096, aW = sbase + (unsigned)(RBA + wn * NJ) * 4096;
+        u32x4 af[2][MI][NPL], wf[2][NJ][NPL];
+        // read order per step: A hi, W hi (-> hi.hi group), W lo' (-> hi.lo'), A lo' (-> lo'.hi)
+#define FRM_READ_STEP(S2)                                                                                                  \
+        do {                                                                                                               \
+            if constexpr (MI >= 1) fr_lds_rd<0 * 4096 + 0 * 2048 + S2 * 1024>(af[S2][0][0], aA);                           \
+            if constexpr (MI >= 2) fr_lds_rd<1 * 4096 + 0 * 2048 + S2 * 1024>(af[S2][MI >= 2 ? 1 : 0][0], aA);             \
+            if constexpr (NJ >= 1) fr_lds_rd<0 * 4096 + 0 * 2048 + S2 * 1024>(wf[S2][0][0], aW);                           \
+            if constexpr (NJ >= 2) fr_lds_rd<1 * 4096 + 0 * 2048 + S2 * 1024>(wf[S2][NJ >= 2 ? 1 : 0][0], aW);             \
+            if constexpr (NJ >= 1) fr_lds_rd<0 * 4096 + 1 * 2048 + S2 * 1024>(wf[S2][0][1], aW);                           \
+            if constexpr (NJ >= 2) fr_lds_rd<1 * 4096 + 1 * 2048 + S2 * 1024>(wf[S2][NJ >= 2 ? 1 : 0][1], aW);             \
+            if constexpr (MI >= 1) fr_lds_rd<0 * 4096 + 1 * 2048 + S2 * 1024>(af[S2][0][1], aA);                           \
+            if constexpr (MI >= 2) fr_lds_rd<1 * 4096 + 1 * 2048 + S2 * 1024>(af[S2][MI >= 2 ? 1 : 0][1], aA);             \
+        } while (0)
+        static_assert(MI <= 2 && NJ <= 2, "fragment read macro covers up to 2 x 2 tiles per wave");
+        FRM_READ_STEP(0);
+        FRM_READ_STEP(1);
+#undef FRM_READ_STEP
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int R = 2 * (MI + NJ);   // reads per step
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            // hi.hi needs the step's first MI + NJ reads
+            if (s2 == 0) fr_lds_wait<2 * R - (MI + NJ)>(wf[0][NJ - 1][0]); else fr_lds_wait<R - (MI + NJ)>(wf[1][NJ - 1][0]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accm[i][j] = mma16(af[s2][i][0], wf[s2][j][0], accm[i][j]);
+            __builtin_amdgcn_sched_barrier(0);   // (the matrix instructions stay between their waits)
+            if (s2 == 0) fr_lds_wait<2 * R - (MI + 2 * NJ)>(wf[0][NJ - 1][1]); else fr_lds_wait<R - (MI + 2 * NJ)>(wf[1][NJ - 1][1]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accc[i][j] = mma16(af[s2][i][0], wf[s2][j][1], accc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s2 == 0) fr_lds_wait<R>(af[0][MI - 1][1]); else fr_lds_wait<0>(af[1][MI - 1][1]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accc[i][j] = mma16(af[s2][i][1], wf[s2][j][0], accc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();   // the ring is free: it becomes the waves' epilogue tiles
+
+    // ---- epilogue, wave-local: accumulators -> [32 MI][PITCH] tile (element e of lane (r, h): row 8 (e >> 2) + 4 h + (e & 3), column r)
+    float* tile = reinterpret_cast<float*>(smem) + (size_t)wid * 32 * MI * PITCH;
+    {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    tile[(32 * i + 8 * (e >> 2) + 4 * h + (e & 3)) * PITCH + 32 * j + r] = accm[i][j][e] + accc[i][j][e] * (1.0f / 2048.0f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int rb0 = rbA0 + wm * MI;                    // first row block of the wave
+    const int m0 = rb0 * 32, n0 = (rbW0 + wn * NJ) * 32;
+    // row-major phase: lane -> (row of a group of 64 / C4 rows, 4 columns): bias, GELU / residual, f32 rows out, values back to the tile
+    constexpr int C4 = TNW / 4, RPI = 64 / C4;
+    {
+        const int c4 = (lane % C4) * 4, rl0 = lane / C4;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + c4);
+#pragma unroll 4
+        for (int it = 0; it < 32 * MI / RPI; ++it) {
+            const int rl = it * RPI + rl0;
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile + rl * PITCH + c4) * a.alpha + bv;
+            if constexpr (EPI == FR_EPI_GELU) {
+                const genie_f2 g0 = gelu_erf_fast2(genie_f2{v[0], v[1]}), g1 = gelu_erf_fast2(genie_f2{v[2], v[3]});
+                v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+            }
+            if constexpr (EPI == FR_EPI_F32 || EPI == FR_EPI_RES) {
+                const long row = m0 + rl;
+                float* dst = a.Cf + (size_t)(row / a.rows_per_batch) * a.strideC + (size_t)(row % a.rows_per_batch) * a.ldc + n0 + c4;
+                if constexpr (EPI == FR_EPI_RES) v += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+            if constexpr (EPI != FR_EPI_F32) *reinterpret_cast<f32x4*>(tile + rl * PITCH + c4) = v;
+        }
+    }
+    if constexpr (EPI == FR_EPI_F32) return;
+    if (EPI == FR_EPI_RES && !a.C16) return;
+    __builtin_amdgcn_wave_barrier();
+    const int fl = lane, r = fl & 31, h = fl >> 5;
+    if constexpr (EPI == FR_EPI_RES || EPI == FR_EPI_GELU) {
+        const int KBo = a.N / 64;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int sl = 0; sl < TNW / 16; ++sl) {
+                const float* src = tile + (32 * i + r) * PITCH + 16 * sl + 8 * h;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
                 const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 u32x4 hi, lo;
                 split8(v, hi, lo);
-                uint16_t* dst = base + ((size_t)blk * NPL * 4 + sl) * FR + fl * 8;
+                const int col = n0 + 16 * sl;
+                uint16_t* dst = a.C16 + fr_frag(rb0 + i, col >> 6, KBo, 0, (col & 63) >> 4) + fl * 8;
                 *reinterpret_cast<u32x4*>(dst) = hi;
                 *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
             }
-        } else {
-            for (int idx = tid; idx < 256; idx += NT) {
-                const int dm = idx >> 6, fl = idx & 63, r = fl & 31, h = fl >> 5;   // dm = 2 dt + m
-                const int dt = dm >> 1, m = dm & 1;
-                float v[8];
+    } else if constexpr (EPI == FR_EPI_QKVS) {
+        // (a wave's 32 columns are half a head slice: steps 2 c .. 2 c + 1 of Q / K, feature tile dt = c of V^T, c = (n0 % 64) / 32)
+        static_assert(EPI != FR_EPI_QKVS || NJ == 1, "attention operand planes: 32 columns per wave");
+        const int dH = a.H * 64;
+        const int which = n0 / dH, head = (n0 % dH) / 64, half = (n0 & 63) >> 5;
+        const int blocks = a.S / 32;
+        const size_t unit = (size_t)blocks * NPL * 4 * FR;
+        const float sc = which == 0 ? a.qscale : 1.0f;
 #pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) v[s8] = red[(16 * m + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + 32 * dt + r];
+        for (int i = 0; i < MI; ++i) {
+            const int rb = rb0 + i;
+            const long seq = rb / blocks;
+            const int blk = rb % blocks;
+            uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
+            const float* tl = tile + (size_t)32 * i * PITCH;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                float v[8];
+                uint16_t* dst;
+                int lo_off;
+                if (which < 2) {       // step 2 half + sub
+                    const float* src = tl + r * PITCH + 16 * sub + 8 * h;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                    dst = base + ((size_t)blk * NPL * 4 + 2 * half + sub) * FR + fl * 8;
+                    lo_off = 4 * FR;
+                } else {               // dt = half, m = sub
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) v[s8] = tl[(16 * sub + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + r];
+                    dst = base + ((size_t)(blk * 2 + half) * 2 + sub) * NPL * FR + fl * 8;
+                    lo_off = FR;
+                }
                 u32x4 hi, lo;
                 split8(v, hi, lo);
-                uint16_t* dst = base + ((size_t)(blk * 2 + dt) * 2 + m) * NPL * FR + fl * 8;
                 *reinterpret_cast<u32x4*>(dst) = hi;
-                *reinterpret_cast<u32x4*>(dst + FR) = lo;
+                *reinterpret_cast<u32x4*>(dst + lo_off) = lo;
             }
         }
     }
+}
+
+// LayerNorm of f32 rows -> fragment-ordered split operand (the mid-size passes; below 1024 rows the Linear does it in its prologue):
+// workgroup = one 32-row block, NW = K / 64 waves, wave w normalises rows 4 w' .. and, after the barrier, writes k-block w.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ln_fr_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, float eps, uint16_t* __restrict__ out16) {
+    constexpr int NT = NW * 64, K = 64 * NW, RW = 32 / NW, G = RW / 4 > 0 ? RW / 4 : 1;
+    static_assert(RW % 4 == 0, "4 rows per instruction");
+    constexpr int HS = 528, SS = 2 * HS, KBS = NPL * 4 * SS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* gb = reinterpret_cast<float*>(smem + (size_t)NW * KBS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long rb = blockIdx.x;
+    f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < K / 4) gbv = reinterpret_cast<const f32x4*>(ln_g)[tid];
+    else if (tid < K / 2) gbv = reinterpret_cast<const f32x4*>(ln_b)[tid - K / 4];
+    f32x4 xv[G][NW];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float* xr = X + (size_t)(rb * 32 + RW * wid + 4 * g + (lane >> 4)) * ldx + 4 * (lane & 15);
+#pragma unroll
+        for (int kb = 0; kb < NW; ++kb) xv[g][kb] = *reinterpret_cast<const f32x4*>(xr + 64 * kb);
+    }
+    FR_PIN_LOADS();
+    if (tid < K / 2) reinterpret_cast<f32x4*>(gb)[tid] = gbv;
+    __syncthreads();
+    const float invK = 1.0f / (float)K;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float sx = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NW; ++kb) sx += (xv[g][kb][0] + xv[g][kb][1]) + (xv[g][kb][2] + xv[g][kb][3]);
+        sx = row16_sum(sx);
+        const float mean = sx * invK;
+        float q = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[g][kb][e] -= mean; q = fmaf(xv[g][kb][e], xv[g][kb][e], q); }
+        q = row16_sum(q);
+        const float rstd = 1.0f / sqrtf(q * invK + eps);
+        const int r = RW * wid + 4 * g + (lane >> 4);
+        const int c = lane & 15;
+        unsigned char* dst = smem + (c >> 2) * SS + ((c >> 1) & 1) * HS + r * 16 + (c & 1) * 8;
+#pragma unroll
+        for (int kb = 0; kb < NW; ++kb) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gb + 64 * kb + 4 * c);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(gb + K + 64 * kb + 4 * c);
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = xv[g][kb][e] * rstd * gm[e] + bt[e];
+            uint32_t h01, h23, l01, l23;
+            split_f16_x4(y[0], y[1], y[2], y[3], h01, h23, l01, l23);
+            *reinterpret_cast<u32x2*>(dst + (size_t)kb * KBS) = u32x2{h01, h23};
+            *reinterpret_cast<u32x2*>(dst + (size_t)kb * KBS + 4 * SS) = u32x2{l01, l23};
+        }
+    }
+    __syncthreads();
+    const unsigned char* src = smem + (size_t)wid * KBS + (lane >> 5) * HS + (lane & 31) * 16;
+    uint16_t* o = out16 + fr_frag(rb, wid, NW, 0, 0) + lane * 8;
+#pragma unroll
+    for (int ps = 0; ps < NPL * 4; ++ps) *reinterpret_cast<u32x4*>(o + ps * FR) = *reinterpret_cast<const u32x4*>(src + ps * SS);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -564,29 +873,44 @@ int launch_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, hipStre
 
 // ---- launchers --------------------------------------------------------------------------------------------------------------
 namespace {
-template <int NW, int NJ, int NKB, int EPI, bool LNF>
+template <int NW, int MI, int NJ, int NKB, int EPI, bool LNF>
 int launch_fr(const FrGemmArgs& a, hipStream_t st) {
-    constexpr int TN = 32 * NJ;
-    size_t lds = (size_t)NW * 32 * (TN + 4) * 4;
-    if (LNF) lds += (size_t)NW * NPL * 4 * 1056 + (size_t)2 * a.K * 4;
+    constexpr int TM = 32 * MI, TN = 32 * NJ;
+    size_t lds = (size_t)NW * TM * (TN + 4) * 4;
+    if (LNF) {   // the LayerNorm staging area shares the LDS of the partial tiles
+        const size_t stage = (size_t)MI * NW * NPL * 4 * 1056 + (size_t)2 * a.K * 4;
+        lds = lds > stage ? lds : stage;
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm16_fr_kernel<NW, NJ, NKB, EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm16_fr_kernel<NW, MI, NJ, NKB, EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((a.M / 32) * (a.N / TN));
-    gemm16_fr_kernel<NW, NJ, NKB, EPI, LNF><<<grid, NW * 64, lds, st>>>(a);
+    const unsigned grid = (unsigned)((a.M / TM) * (a.N / TN));
+    gemm16_fr_kernel<NW, MI, NJ, NKB, EPI, LNF><<<grid, NW * 64, lds, st>>>(a);
     GENIE_LAUNCH_CHECK("gemm16_fr");
     return GENIE_OK;
 }
 
-// dispatch on the width: K = 64 NW (NKB = 1) for the Linears fed by d_model, K = 256 NW (NKB = 4) for fc2
+// dispatch on the width: K = 64 NW (NKB = 1) for the Linears fed by d_model, K = 256 NW (NKB = 4) for fc2; wide2: 64-row
+// workgroups for the 64-column tiles of a pass of >= 512 rows (two frames, or two clips)
 template <int NJ, int NKB, int EPI, bool LNF>
 int launch_fr_w(int nw, const FrGemmArgs& a, hipStream_t st) {
+    const bool wide2 = NJ == 2 && NKB == 1 && a.M >= 512 && a.M % 64 == 0;
+    if constexpr (NJ == 2 && NKB == 1) {
+        if (wide2) {
+            switch (nw) {
+                case 8: return launch_fr<8, 2, NJ, NKB, EPI, LNF>(a, st);
+                case 4: return launch_fr<4, 2, NJ, NKB, EPI, LNF>(a, st);
+                case 2: return launch_fr<2, 2, NJ, NKB, EPI, LNF>(a, st);
+                default: break;
+            }
+        }
+    }
     switch (nw) {
-        case 8: return launch_fr<8, NJ, NKB, EPI, LNF>(a, st);
-        case 4: return launch_fr<4, NJ, NKB, EPI, LNF>(a, st);
-        case 2: return launch_fr<2, NJ, NKB, EPI, LNF>(a, st);
+        case 8: return launch_fr<8, 1, NJ, NKB, EPI, LNF>(a, st);
+        case 4: return launch_fr<4, 1, NJ, NKB, EPI, LNF>(a, st);
+        case 2: return launch_fr<2, 1, NJ, NKB, EPI, LNF>(a, st);
         default: break;
     }
     set_error("gemm16_fr: width %d not covered", 64 * nw);
@@ -594,20 +918,72 @@ int launch_fr_w(int nw, const FrGemmArgs& a, hipStream_t st) {
 }
 }  // namespace
 
+namespace {
+template <int WM, int WN, int MI, int NJ, int NST, int EPI>
+int launch_frm(const FrGemmArgs& a, hipStream_t st) {
+    constexpr int BM = 32 * WM * MI, BN = 32 * WN * NJ;
+    constexpr size_t lds = (size_t)NST * (WM * MI + WN * NJ) * 4096;
+    if (a.M % BM || a.N % BN || a.K % 64) return GENIE_E_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm16_frm_kernel<WM, WN, MI, NJ, NST, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    gemm16_frm_kernel<WM, WN, MI, NJ, NST, EPI><<<(unsigned)((a.M / BM) * (a.N / BN)), 64 * WM * WN, lds, st>>>(a);
+    GENIE_LAUNCH_CHECK("gemm16_frm");
+    return GENIE_OK;
+}
+// 128 x 128 tiles where they fill the chip, 128 x 64 for the narrow outputs (N = d_model)
+template <int EPI>
+int launch_frm_any(const FrGemmArgs& a, hipStream_t st) {
+    const long t128 = (long)(a.M / 128) * (a.N / 128);
+    if (a.N % 128 == 0 && (EPI == FR_EPI_QKVS || t128 >= 160 || a.N >= 1024)) return launch_frm<2, 4, 2, 1, 4, EPI>(a, st);
+    if constexpr (EPI != FR_EPI_QKVS) return launch_frm<4, 2, 1, 1, 5, EPI>(a, st);
+    return GENIE_E_UNSUPPORTED;
+}
+int launch_ln_fr(const float* x, long ldx, const float* g, const float* b, float eps, uint16_t* out16, int M, int K, hipStream_t st) {
+    const size_t lds = (size_t)(K / 64) * NPL * 4 * 1056 + (size_t)2 * K * 4;
+#define LN_FR(NW_)                                                                                                           \
+    case NW_: {                                                                                                              \
+        static bool attr_set = false;                                                                                        \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)ln_fr_kernel<NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        ln_fr_kernel<NW_><<<(unsigned)(M / 32), NW_ * 64, lds, st>>>(x, ldx, g, b, eps, out16);                              \
+        break;                                                                                                               \
+    }
+    switch (K / 64) {
+        LN_FR(8) LN_FR(4) LN_FR(2)
+        default: set_error("ln_fr: width %d not covered", K); return GENIE_E_UNSUPPORTED;
+    }
+#undef LN_FR
+    GENIE_LAUNCH_CHECK("ln_fr");
+    return GENIE_OK;
+}
+}  // namespace
+
 bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows) {
     static const int on = study_env("GENIE_FRAME_KERNELS", 1);
     return on && c.precision == GENIE_PREC_F16X3 && !c.qk_norm && c.S == 256 && c.head_dim == 64 && c.d_model == c.num_heads * 64 &&
-           (c.d_model == 512 || c.d_model == 256 || c.d_model == 128) && c.hidden == 4 * c.d_model && rows % 32 == 0 && rows <= 1024 &&
+           (c.d_model == 512 || c.d_model == 256 || c.d_model == 128) && c.hidden == 4 * c.d_model && rows % 256 == 0 && rows <= 16384 &&
            lw.spatial.frame_w16 && lw.temporal.frame_w16 && lw.mlp_frame_w16 && lw.norm1_w && lw.norm2_w;
 }
 
 // One STBlock (st_transformer.py:70-83) of a frame pass: B clips x nf frames (slots t0 .. t0 + nf - 1 of the cache) x S rows.
 //   x   f32 rows (the residual stream)            xs  = w.xn : operand copy of x (fragment order)
 //   as  = w.aux: attention outputs                 big = w.big: spatial attention operand planes, then the MLP hidden
+// rows from which a pass runs the LDS-tiled kernels (gemm16_frm, separate LayerNorm) instead of the register-direct ones
+static long frm_min_rows() {
+    static const long v = study_env("GENIE_FRM_MIN_ROWS", 2048);
+    return v;
+}
+
 int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, int nf, bool want_xs,
                          hipStream_t st) {
     const int d = c.d_model, S = c.S, H = c.num_heads, hid = c.hidden;
     const int M = B * nf * S, nw = d / 64;
+    const bool mid = M >= frm_min_rows() && M % 128 == 0 && d % 128 == 0;
+    // (the out-projections, N = d: the register-direct kernel is ahead up to twice that many rows -- 7.5 against 10.4 us at 2,048
+    // rows, 17.7 against 14.4 at 4,096: profiles/r05e_frame_gemm.txt)
+    const bool mid_proj = mid && M >= 2 * frm_min_rows();
     uint16_t* xs = (uint16_t*)w.xn;
     uint16_t* as = (uint16_t*)w.aux;
     uint16_t* big = (uint16_t*)w.big;
@@ -626,12 +1002,23 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     // ---- spatial: LayerNorm + qkv -> attention operand planes; attention; out-projection + residual (+ operand copy of x)
     {
         FrGemmArgs g = a;
-        g.X = x; g.ldx = d; g.ln_g = lw.norm1_w; g.ln_b = lw.norm1_b; g.ln_eps = 1e-5f;
         g.W = wq_s; g.bias = c.qkv_bias ? lw.spatial.qkv_b : nullptr; g.N = 3 * d; g.K = d;
         g.qkvs = big; g.qscale = c.attn_scale * 1.4426950408889634f; g.H = H; g.S = S;
-        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
-                       "gemm16_fr_kernel (LayerNorm + qkv -> attention operand planes)");
-        GENIE_TRY((launch_fr_w<2, 1, FR_EPI_QKVS, true>(nw, g, st)));
+        if (mid) {
+            {
+                ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * M * d, 8.0 * M * d, st, "ln_fr_kernel");
+                GENIE_TRY(launch_ln_fr(x, d, lw.norm1_w, lw.norm1_b, 1e-5f, as, M, d, st));
+            }
+            g.A = as;
+            ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
+                           "gemm16_frm_kernel (qkv -> attention operand planes)");
+            GENIE_TRY(launch_frm_any<FR_EPI_QKVS>(g, st));
+        } else {
+            g.X = x; g.ldx = d; g.ln_g = lw.norm1_w; g.ln_b = lw.norm1_b; g.ln_eps = 1e-5f;
+            ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
+                           "gemm16_fr_kernel (LayerNorm + qkv -> attention operand planes)");
+            GENIE_TRY((launch_fr_w<2, 1, FR_EPI_QKVS, true>(nw, g, st)));
+        }
     }
     {
         ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * 64 * H * (double)(B * nf), (double)B * nf * S * d * 16.0, st,
@@ -649,8 +1036,10 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         FrGemmArgs g = a;
         g.A = as; g.W = wp_s; g.bias = c.proj_bias ? lw.spatial.proj_b : nullptr; g.N = d; g.K = d;
         g.Cf = x; g.ldc = d; g.C16 = xs;
-        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)d * d, 4.0 * M * d * 4 + 4.0 * d * d, st, "gemm16_fr_kernel (proj + residual)");
-        GENIE_TRY((launch_fr_w<1, 1, FR_EPI_RES, false>(nw, g, st)));
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)d * d, 4.0 * M * d * 4 + 4.0 * d * d, st,
+                       mid_proj ? "gemm16_frm_kernel (proj + residual)" : "gemm16_fr_kernel (proj + residual)");
+        if (mid_proj) GENIE_TRY(launch_frm_any<FR_EPI_RES>(g, st));
+        else GENIE_TRY((launch_fr_w<1, 1, FR_EPI_RES, false>(nw, g, st)));
     }
     // ---- temporal: qkv -> cache slots t0 .. ; decode attention over the cache; out-projection + residual
     {
@@ -659,8 +1048,9 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         g.Cf = w.fcache + (size_t)w.frame_t * S * 3 * d; g.ldc = 3 * d; g.rows_per_batch = (long)nf * S;
         g.strideC = (long)w.frame_T * S * 3 * d;
         ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
-                       "gemm16_fr_kernel (temporal qkv -> cache)");
-        GENIE_TRY((launch_fr_w<2, 1, FR_EPI_F32, false>(nw, g, st)));
+                       mid ? "gemm16_frm_kernel (temporal qkv -> cache)" : "gemm16_fr_kernel (temporal qkv -> cache)");
+        if (mid) GENIE_TRY(launch_frm_any<FR_EPI_F32>(g, st));
+        else GENIE_TRY((launch_fr_w<2, 1, FR_EPI_F32, false>(nw, g, st)));
     }
     {
         const long n = (long)M * H;
@@ -673,27 +1063,58 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         FrGemmArgs g = a;
         g.A = as; g.W = wp_t; g.bias = c.proj_bias ? lw.temporal.proj_b : nullptr; g.N = d; g.K = d;
         g.Cf = x; g.ldc = d; g.C16 = nullptr;
-        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)d * d, 4.0 * M * d * 3 + 4.0 * d * d, st, "gemm16_fr_kernel (proj + residual)");
-        GENIE_TRY((launch_fr_w<1, 1, FR_EPI_RES, false>(nw, g, st)));
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)d * d, 4.0 * M * d * 3 + 4.0 * d * d, st,
+                       mid_proj ? "gemm16_frm_kernel (proj + residual)" : "gemm16_fr_kernel (proj + residual)");
+        if (mid_proj) GENIE_TRY(launch_frm_any<FR_EPI_RES>(g, st));
+        else GENIE_TRY((launch_fr_w<1, 1, FR_EPI_RES, false>(nw, g, st)));
     }
     // ---- MLP: LayerNorm + fc1 + GELU -> hidden operand; fc2 + residual (+ operand copy for the readout)
     {
         FrGemmArgs g = a;
-        g.X = x; g.ldx = d; g.ln_g = lw.norm2_w; g.ln_b = lw.norm2_b; g.ln_eps = 1e-5f;
         g.W = w1; g.bias = c.mlp_bias ? lw.fc1_b : nullptr; g.N = hid; g.K = d; g.C16 = big;
-        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
-                       "gemm16_fr_kernel (LayerNorm + fc1 + GELU)");
-        GENIE_TRY((launch_fr_w<2, 1, FR_EPI_GELU, true>(nw, g, st)));
+        if (mid) {
+            {
+                ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * M * d, 8.0 * M * d, st, "ln_fr_kernel");
+                GENIE_TRY(launch_ln_fr(x, d, lw.norm2_w, lw.norm2_b, 1e-5f, as, M, d, st));
+            }
+            g.A = as;
+            ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
+                           "gemm16_frm_kernel (fc1 + GELU)");
+            GENIE_TRY(launch_frm_any<FR_EPI_GELU>(g, st));
+        } else {
+            g.X = x; g.ldx = d; g.ln_g = lw.norm2_w; g.ln_b = lw.norm2_b; g.ln_eps = 1e-5f;
+            ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
+                           "gemm16_fr_kernel (LayerNorm + fc1 + GELU)");
+            GENIE_TRY((launch_fr_w<2, 1, FR_EPI_GELU, true>(nw, g, st)));
+        }
     }
     {
         FrGemmArgs g = a;
         g.A = big; g.W = w2; g.bias = c.mlp_bias ? lw.fc2_b : nullptr; g.N = d; g.K = hid;
         g.Cf = x; g.ldc = d; g.C16 = want_xs ? xs : nullptr;
         ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * hid + 4.0 * hid * d + 4.0 * M * d * 2, st,
-                       "gemm16_fr_kernel (fc2 + residual)");
-        GENIE_TRY((launch_fr_w<1, 4, FR_EPI_RES, false>(nw, g, st)));
+                       mid ? "gemm16_frm_kernel (fc2 + residual)" : "gemm16_fr_kernel (fc2 + residual)");
+        if (mid) GENIE_TRY(launch_frm_any<FR_EPI_RES>(g, st));
+        else GENIE_TRY((launch_fr_w<1, 4, FR_EPI_RES, false>(nw, g, st)));
     }
     return GENIE_OK;
+}
+
+// y (M, N) f32 = A . W^T + bias from fragment-ordered split operands (C ABI genie_frame_linear: the kernel-level test and
+// micro-benchmark entry).  mode 0: the block driver's own choice, 1: register-direct kernel, 2: LDS-tiled kernel.
+int launch_frame_linear(const uint16_t* A, const uint16_t* W, const float* bias, float* y, int M, int N, int K, int mode, hipStream_t st) {
+    GENIE_CHECK_SHAPE(M % 32 == 0 && N % 64 == 0 && K % 64 == 0, "frame_linear: (M, N, K) = (%d, %d, %d) must be multiples of (32, 64, 64)", M, N, K);
+    FrGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.a_group = 1; g.a_mul = 1; g.a_off = 0;
+    g.W = W; g.bias = bias; g.alpha = 1.0f; g.M = M; g.N = N; g.K = K;
+    g.Cf = y; g.ldc = N; g.rows_per_batch = M; g.strideC = 0;
+    const bool mid = mode == 2 || (mode == 0 && M >= frm_min_rows() && M % 128 == 0);
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)N * K, 4.0 * M * K + 4.0 * N * K + 4.0 * M * N, st, "gemm16_fr(m)_kernel (frame_linear)");
+    if (mid) return launch_frm_any<FR_EPI_F32>(g, st);
+    if (K <= 512) return launch_fr_w<2, 1, FR_EPI_F32, false>(K / 64, g, st);
+    set_error("frame_linear: K = %d has no register-direct f32-output kernel", K);
+    return GENIE_E_UNSUPPORTED;
 }
 
 // out_x_proj on frame f_out of a frame pass from the fragment-ordered operand copy of x: logits (B, S, V) f32 token-major
@@ -705,7 +1126,8 @@ int readout_frame_f16x3(const genie_cfg& c, const genie_weights& wt, Workspace& 
     g.W = wt.out_frame_w16; g.bias = wt.out_b; g.alpha = c.readout_mult;
     g.M = B * c.S; g.N = V; g.K = d;
     g.Cf = logits; g.ldc = V; g.rows_per_batch = g.M; g.strideC = 0;
-    ProfScope prof(GENIE_KC_GEMM, 2.0 * g.M * (double)V * d, 4.0 * g.M * d + 4.0 * V * d + 4.0 * g.M * V, st, "gemm16_fr_kernel (readout)");
+    ProfScope prof(GENIE_KC_GEMM, 2.0 * g.M * (double)V * d, 4.0 * g.M * d + 4.0 * V * d + 4.0 * g.M * V, st, "gemm16_fr(m)_kernel (readout)");
+    if (g.M >= frm_min_rows() && g.M % 128 == 0 && V % 128 == 0) return launch_frm_any<FR_EPI_F32>(g, st);
     return launch_fr_w<2, 1, FR_EPI_F32, false>(d / 64, g, st);
 }
 

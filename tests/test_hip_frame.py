@@ -46,7 +46,7 @@ def test_pack_frame_w16_is_the_row_major_split_in_fragment_order():
 def test_frame_passes_equal_full_forward_frames(d, heads):
     """genie_frame_pass / genie_frames_pass on the fragment-order kernels against the full 16-frame forward of the same model
     (256x256-tile GEMMs, LDS-DMA attention kernels: validated against the oracle and the reference goldens elsewhere): logits of
-    every decoded frame within f32 accumulation-order noise; one frame per pass, two frames per pass, two clips."""
+    every decoded frame within f32 accumulation-order noise; one frame per pass, two frames per pass, 1 / 2 / 5 clips."""
     cfg, m = _model(d, heads)
     _lib = pkg("_lib")
     lib = _lib.load()
@@ -54,7 +54,7 @@ def test_frame_passes_equal_full_forward_frames(d, heads):
     assert w.out_frame_w16 and w.layers_host[0].spatial.frame_w16 and w.layers_host[0].mlp_frame_w16   # the new path is the one that runs
     T, S = cfg.T, cfg.S
     V = cfg.factored_vocab_size * cfg.num_factored_vocabs
-    for B in (1, 2):
+    for B in (1, 2, 5):    # 256 .. 2,560 rows per pass: the register-direct kernels below 2,048 rows, the LDS-tiled ones from there
         ids = dev(pkg("synthetic").make_clips(B, cfg, seed=70 + B)).view(B, T, S)
         ids[:, 3, ::3] = cfg.image_vocab_size       # some mask tokens
         full = m.compute_logits(ids.view(B, T, 16, 16))          # (B, V, T, 16, 16)
@@ -85,7 +85,10 @@ def test_frame_passes_equal_full_forward_frames(d, heads):
         L = cfg.num_layers
         a = cache.view(L, B, T, S, 3 * d)[:, :, :4]
         b = cache2.view(L, B, T, S, 3 * d)[:, :, :4]
-        assert torch.equal(a, b)   # per-row arithmetic does not depend on how many frames share a pass
+        if (B * S >= 2048) == (2 * B * S >= 2048):
+            assert torch.equal(a, b)   # same kernels: per-row arithmetic does not depend on how many frames share a pass
+        else:                          # one frame on the register-direct kernels, two on the LDS-tiled ones: f32 summation order
+            assert (a - b).abs().max().item() < 3e-5 * max(1.0, a.abs().max().item())
         assert (cache2.view(L, B, T, S, 3 * d)[:, :, 4:] == 0).all()
 
 
