@@ -121,6 +121,96 @@ def pass_flops(cfg, frames=None):
     return T * S * (L * (32 * d * d + 4 * S * d + 4 * T * d) + 2 * d * V)
 
 
+def config_legs(dev, cfgmod, synth, STMaskGIT, evalmod, dist_mod, model138, maskgit_steps):
+    """One cheap measurement per BASELINE config beside the headline (N = 1 only), for the compact `legs` object the line ends with:
+    config 2 (GENIE_35M bf16 forward + CE, 64 clips, fused sub-blocks and GENIE_NO_FUSED), config 3 (generate.py semantics on the
+    GENIE_138M shape: prompt 8 -> 8 frames, temperature 0, batch 1 at 2 and 8 MaskGIT steps, 16 clips at 2), config 5 (MAGVIT2
+    encode -> sample -> MAGVIT2 decode, 8 clips), and the shipped config through the headline's own evaluate schedule in f16x3.
+    Every leg is wrapped: a failure is reported in place, the headline is not touched."""
+    legs = {}
+    G = importlib.import_module("1xgpt_amd.generate")
+
+    def timed(fn, reps=2, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # ---- config 3: generate on the GENIE_138M shape (f16x3: ids bit-exact against the reference, tests/test_hip_configs.py)
+    try:
+        c138 = cfgmod.c138()
+        m = model138 if model138 is not None else STMaskGIT(c138, precision="f16x3").load_numpy_state_dict(
+            synth.make_state_dict(c138, seed=0, law="conditioned")).to(dev)
+        g3 = {}
+        for B, steps in ((1, 2), (1, 8), (16, 2)):
+            ex = torch.from_numpy(synth.make_clips(B, c138, seed=7)).to(dev).view(B, 16, 16, 16)
+            noise = torch.rand(8, max(steps - 1, 1), B, c138.S, device=dev)
+            dt = timed(lambda: G.generate_frames_cached(m, ex, 8, steps, 0.0, False, noise=noise), reps=2, warm=2)
+            g3[f"b{B}s{steps}"] = dt
+        legs["c3_ms_frame_b1"] = {"s2": round(g3["b1s2"] / 8 * 1e3, 2), "s8": round(g3["b1s8"] / 8 * 1e3, 2)}
+        legs["c3_fps_b16s2"] = round(16 * 8 / g3["b16s2"], 1)
+        # executed FLOPs per generated frame: (steps + 1) one-frame passes (the prompt pass amortised over 8 frames)
+        f1 = pass_flops(c138, 1)
+        legs["c3_frac_b1s2"] = round((3 + 1) * f1 / (g3["b1s2"] / 8) / 1e12 / PEAK_TFLOPS["f16x3"], 4)
+        legs["c3_frac_b16s2"] = round((3 + 1) * f1 * 16 / (g3["b16s2"] / 8) / 1e12 / PEAK_TFLOPS["f16x3"], 4)
+        # ---- config 5: encode -> sample -> decode, 8 clips
+        try:
+            e2e = importlib.import_module("tools.bench_e2e").run_e2e(m, 8, 2, reps=2)
+            legs["c5_fps_8clips"] = round(e2e["end_to_end_generated_frames_per_sec"], 1)
+            legs["c5_s"] = [round(e2e["seconds"][k], 4) for k in ("encode_hip", "generate", "decode_hip")]
+        except Exception as e:
+            legs["c5_err"] = f"{type(e).__name__}: {e}"[:80]
+        if model138 is None:
+            del m
+        torch.cuda.empty_cache()
+    except Exception as e:
+        legs["c3_err"] = f"{type(e).__name__}: {e}"[:80]
+    # ---- config 2: the shipped config, bf16, forward + CE on 64 clips
+    try:
+        c35 = cfgmod.c35()
+        sd35 = synth.make_state_dict(c35, seed=0)
+        ids = torch.from_numpy(synth.make_clips(64, c35, seed=1)).to(dev)
+        x = ids.clone().view(64, c35.T, -1)
+        x[:, 8:] = c35.image_vocab_size
+        x = x.view(64, -1)
+        c2 = {}
+        for tag, env in (("fused", None), ("unfused", "1")):
+            old_env = os.environ.get("GENIE_NO_FUSED")
+            if env is not None:
+                os.environ["GENIE_NO_FUSED"] = env
+            try:
+                m2 = STMaskGIT(c35, precision="bf16").load_numpy_state_dict(sd35).to(dev)
+                c2[tag] = round(timed(lambda: m2(x, ids), reps=5, warm=2) * 1e3, 2)
+                del m2
+            finally:
+                if env is not None:
+                    if old_env is None:
+                        os.environ.pop("GENIE_NO_FUSED", None)
+                    else:
+                        os.environ["GENIE_NO_FUSED"] = old_env
+            torch.cuda.empty_cache()
+        legs["c2_ms"] = c2
+        legs["c2_frac"] = round(64 * pass_flops(c35) / (c2["fused"] / 1e3) / 1e12 / PEAK_TFLOPS["bf16"], 3)
+        # ---- the shipped config through the headline's schedule, parity mode
+        m3 = STMaskGIT(c35, precision="f16x3").load_numpy_state_dict(synth.make_state_dict(c35, seed=0, law="conditioned")).to(dev)
+        ev_args = argparse.Namespace(maskgit_steps=maskgit_steps, temperature=0.0, latent_h=m3.h, latent_w=m3.w)
+        ev3 = evalmod.GenieEvaluator(ev_args, None, dev, model=m3)
+        clips = torch.from_numpy(synth.make_clips(128, c35, seed=1234)).to(dev)
+        noise = torch.from_numpy(synth.make_noise((c35.T - 1, max(maskgit_steps - 1, 1), 128, c35.S), seed=42)).to(dev)
+        dt = timed(lambda: ev3.evaluate_metric_sums_reuse(clips, noise=noise), reps=1, warm=1)
+        legs["c35_f16x3_fps"] = round(15 * 128 / dt, 1)
+        legs["c35_f16x3_frac"] = round((1 + maskgit_steps) * 128 * pass_flops(c35, c35.T - 1) / dt / 1e12 / PEAK_TFLOPS["f16x3"], 4)
+        del ev3, m3
+        torch.cuda.empty_cache()
+    except Exception as e:
+        legs["c2_err"] = f"{type(e).__name__}: {e}"[:80]
+    return legs
+
+
 def host_cpu_info():
     """CPU model string, physical cores (distinct (socket, core) pairs), logical CPUs and the CPUs this process may run on."""
     model, cores, logical = "unknown", set(), 0
@@ -158,7 +248,7 @@ def cpu_baseline(cfg, sd, clips, maskgit_steps, cands=None):
     Bounded sample of the same workload: ALL 15 timesteps of clip 0 (each = `maskgit_steps` full 16-frame forwards), every
     timestep timed on its own so that the line can carry min / median / mean (a shared host is noisy: the run-to-run spread
     of a single mean was 1.8x).  The intra-op thread count is fixed first from a probe that goes up to ALL physical cores the
-    process may use (8, 16, 32, 64, ..., physical cores: one cold forward each, then the minimum of two warm ones); the fastest
+    process may use, capped at 64 threads (8, 16, 32, 64: one cold forward each, then the minimum of two warm ones); the fastest
     candidate is used for the whole sample.  `value` = 1 / median seconds per timestep (= frames/s, one frame is sampled per
     timestep); a full clip costs 15 timesteps.  The line names the CPU model, its physical core count and the threads used."""
     O = importlib.import_module("oracle.genie_oracle")
@@ -171,7 +261,8 @@ def cpu_baseline(cfg, sd, clips, maskgit_steps, cands=None):
     top = max(1, min(host["physical_cores"], host["usable_cpus"]))
     prev_threads = torch.get_num_threads()
     if cands is None:
-        cands = [c for c in (8, 16, 32, 64, 128) if c < top] + [top]
+        cands = [c for c in (8, 16, 32, 64) if c <= top] or [top]   # (never above 64 threads: no host seen was faster there, and
+                                                                      # one 128-thread forward alone cost 12 s of the run)
     cands = sorted({c for c in cands if 1 <= c <= host["usable_cpus"]}) or [top]
     probe = {}
     for c in cands:
@@ -536,8 +627,10 @@ def main():
                                                           gemm_bytes + fused_bytes)
     gemm_kernels.sort(key=lambda k: -k["ms"])
     other_classes = {}
+    # (the fused sub-block kernels are in `gemm_kernels_launched` and in the all-GEMM totals, marked `fused_subblock`: listing them
+    # here as well would count their share of the step twice)
     for name, kc in (("attention_spatial", _lib.KC_ATTN_SPATIAL), ("attention_temporal", _lib.KC_ATTN_TEMPORAL),
-                     ("layernorm", _lib.KC_LAYERNORM), ("fused_subblocks", _lib.KC_FUSED)):
+                     ("layernorm", _lib.KC_LAYERNORM)):
         _lib.check(lib.genie_profile_read(kc, prof), "profile_read")
         n, ms, fl, by = list(prof)
         if n:
@@ -667,6 +760,11 @@ def main():
         except Exception as e:
             exact_leg = {"error": f"{type(e).__name__}: {e}"}
 
+    legs = None
+    if world == 1 and not args.no_secondary and os.environ.get("GENIE_BENCH_LEGS", "1") != "0":
+        legs = config_legs(dev, cfgmod, synth, STMaskGIT, evalmod, dist_mod,
+                           model if (args.precision == "f16x3" and args.model == "c138") else None, args.maskgit_steps)
+
     breakdown = None
     if args.breakdown and rank == 0:
         lib.genie_profile_enable(0x1F)
@@ -740,7 +838,8 @@ def main():
     dom = gemm_kernels[0] if gemm_kernels else None
     achieved = dom["tflops"] if dom else achieved_all
     out = {
-        "metric": "sampled frames/sec (whole node) + teacher-forced CE, GENIE_138M 16x256 tokens",
+        "metric": "sampled frames/sec (whole node) + teacher-forced CE, " +
+                  ("GENIE_138M" if args.model == "c138" else "GENIE_35M magvit_n32_h8_d256 (NOT the BASELINE metric's model)") + " 16x256 tokens",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": value / PUBLISHED_FRAMES_PER_SEC[args.model],
@@ -788,7 +887,7 @@ def main():
     }
     # Counter-derived figures cannot be collected inside this run (rocprofv3 --pmc serialises kernels and needs its own
     # passes): they come from the committed PMC summary of this same command and say so.
-    pmc = os.path.join(REPO, "profiles", "pmc_bench.json")
+    pmc = os.path.join(REPO, "profiles", "pmc_bench.json" if args.model == "c138" else f"pmc_bench_{args.model}.json")
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
@@ -859,6 +958,20 @@ def main():
         out["breakdown"] = breakdown
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, all_clips, args.maskgit_steps)
+    # LAST key of the line (a harness that keeps only the tail of stdout still sees it): one compact number per BASELINE config
+    # and per secondary precision, details in the objects above / DESIGN.md section 5
+    if legs is not None:
+        if other_precision and "value" in other_precision:
+            legs["bf16_eval_fps"] = round(other_precision["value"], 1)
+        if exact_leg and "value" in exact_leg:
+            legs["exact_eval_fps"] = round(exact_leg["value"], 1)
+            legs["exact_gemm_frac"] = round(exact_leg["roofline"]["frac"], 3)
+        if full_forward:
+            legs["full_fwd_sched_fps"] = round(full_forward["value"], 1)
+        legs["headline"] = {"fps": round(value, 1), "frac": round(achieved / peak, 4), "ce": round(m["loss"], 6)}
+        legs["key"] = ("c2: GENIE_35M bf16 forward+CE 64 clips ms; c3: GENIE_138M f16x3 generate 8->8 frames (ms per frame at batch 1, "
+                       "frames/s at 16 clips, frac = executed model FLOPs / 2.5 PF); c5: encode->sample->decode frames/s; eval legs frames/s")
+        out["legs"] = legs
     print(json.dumps(out), flush=True)
     if selfcheck and not selfcheck["ok"]:
         print("bench.py: parity_selfcheck FAILED -- the timed schedule does not reproduce the reference schedule / the reference's "

@@ -24,6 +24,44 @@ def timed(fn, reps=2):
     return out, (time.perf_counter() - t0) / reps
 
 
+def run_e2e(m, clips=8, steps=2, reps=2):
+    """encode -> sample -> decode on the model `m` (an STMaskGIT on cuda); returns the result dict of this tool."""
+    mv = importlib.import_module("1xgpt_amd.magvit2")
+    G = importlib.import_module("1xgpt_amd.generate")
+    cfg = m.config
+    vq = mv.VQModel(mv.VQConfig())
+    vq.load_state_dict({k: torch.from_numpy(v) for k, v in mv.make_vq_state_dict(vq, seed=1).items()})
+    vq = vq.to(device="cuda").eval()
+    B = clips
+    g = torch.Generator(device="cuda").manual_seed(0)
+    frames = torch.randint(0, 256, (B * 16, 3, 256, 256), dtype=torch.uint8, device="cuda", generator=g)
+
+    he = vq.hip_encoder()
+
+    def encode_hip():
+        return torch.cat([he.encode_tokens(frames[i:i + 16]) for i in range(0, B * 16, 16)])
+
+    tokens, t_enc = timed(encode_hip, reps)
+    ids = tokens.view(B, 16, 16, 16)
+    noise = torch.rand(8, max(steps - 1, 1), B, cfg.S, device="cuda")
+    out, t_gen = timed(lambda: G.generate_frames_cached(m, ids, 8, steps, 0.0, False, noise=noise), reps)
+    gen = out[:, 8:16].reshape(B * 8, 16, 16)
+
+    hd = vq.hip_decoder()
+
+    def decode_hip():
+        return torch.cat([hd.decode_tokens(gen[i:i + 16]) for i in range(0, B * 8, 16)])
+
+    rgb, t_dec = timed(decode_hip, reps)
+    assert rgb.shape == (B * 8, 3, 256, 256) and rgb.dtype == torch.uint8 and rgb.is_cuda
+    total = t_enc + t_gen + t_dec
+    return {"clips": B, "encode_frames_per_sec": B * 16 / t_enc, "encode_tflops": 135.8e-3 * B * 16 / t_enc,
+            "generate_frames_per_sec": B * 8 / t_gen,
+            "decode_frames_per_sec": B * 8 / t_dec, "decode_tflops": 186.7e-3 * B * 8 / t_dec,
+            "end_to_end_generated_frames_per_sec": B * 8 / total,
+            "seconds": {"encode_hip": t_enc, "generate": t_gen, "decode_hip": t_dec}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=8)
@@ -33,44 +71,12 @@ def main():
     a = ap.parse_args()
     cfgmod = importlib.import_module("1xgpt_amd.config")
     synth = importlib.import_module("1xgpt_amd.synthetic")
-    mv = importlib.import_module("1xgpt_amd.magvit2")
-    G = importlib.import_module("1xgpt_amd.generate")
     STMaskGIT = importlib.import_module("1xgpt_amd.st_mask_git").STMaskGIT
     cfg = cfgmod.c138() if a.model == "c138" else cfgmod.c35()
     m = STMaskGIT(cfg, precision=a.precision).load_numpy_state_dict(synth.make_state_dict(cfg, seed=0)).to("cuda")
-    vq = mv.VQModel(mv.VQConfig())
-    vq.load_state_dict({k: torch.from_numpy(v) for k, v in mv.make_vq_state_dict(vq, seed=1).items()})
-    vq = vq.to(device="cuda").eval()
-    B = a.clips
-    g = torch.Generator(device="cuda").manual_seed(0)
-    frames = torch.randint(0, 256, (B * 16, 3, 256, 256), dtype=torch.uint8, device="cuda", generator=g)
-
-    he = vq.hip_encoder()
-
-    def encode_hip():
-        return torch.cat([he.encode_tokens(frames[i:i + 16]) for i in range(0, B * 16, 16)])
-
-    tokens, t_enc = timed(encode_hip)
-    clips = tokens.view(B, 16, 16, 16)
-    noise = torch.rand(8, max(a.steps - 1, 1), B, cfg.S, device="cuda")
-    out, t_gen = timed(lambda: G.generate_frames_cached(m, clips, 8, a.steps, 0.0, False, noise=noise))
-    gen = out[:, 8:16].reshape(B * 8, 16, 16)
-
-    hd = vq.hip_decoder()
-
-    def decode_hip():
-        return torch.cat([hd.decode_tokens(gen[i:i + 16]) for i in range(0, B * 8, 16)])
-
-    rgb, t_dec = timed(decode_hip)
-    assert rgb.shape == (B * 8, 3, 256, 256) and rgb.dtype == torch.uint8 and rgb.is_cuda
-    total = t_enc + t_gen + t_dec
-    res = {"workload": f"encode {B}x16 frames -> sample 8 frames/clip ({a.steps} MaskGIT steps, KV cache, {a.precision}) -> "
-                       f"decode {B}x8 frames; {a.model}; MAGVIT2 encode and decode on hand-written implicit-GEMM convs",
-           "clips": B, "encode_frames_per_sec": B * 16 / t_enc, "encode_tflops": 135.8e-3 * B * 16 / t_enc,
-           "generate_frames_per_sec": B * 8 / t_gen,
-           "decode_frames_per_sec": B * 8 / t_dec, "decode_tflops": 186.7e-3 * B * 8 / t_dec,
-           "end_to_end_generated_frames_per_sec": B * 8 / total,
-           "seconds": {"encode_hip": t_enc, "generate": t_gen, "decode_hip": t_dec}}
+    res = run_e2e(m, a.clips, a.steps)
+    res = {"workload": f"encode {a.clips}x16 frames -> sample 8 frames/clip ({a.steps} MaskGIT steps, KV cache, {a.precision}) -> "
+                       f"decode {a.clips}x8 frames; {a.model}; MAGVIT2 encode and decode on hand-written implicit-GEMM convs", **res}
     print(json.dumps(res))
 
 
