@@ -124,6 +124,17 @@ __device__ __forceinline__ genie_f2 gelu_erf_poly2(genie_f2 z) {
     return z * __builtin_elementwise_fma(zc, p, splat(0.5f));
 }
 
+// GELU of a 16-bit GEMM epilogue.  LOWP = the value leaves ONLY as bf16 (the MLP hidden of GENIE_PREC_BF16): the polynomial form in
+// EVERY bf16 kernel (fused MLP, gemm16_pp / v2 / nt / sm), so that a clip's hidden does not depend on which kernel its batch
+// size selects; otherwise (split-f16 operands, f32 outputs) the 1.5e-7 form.
+template <bool LOWP>
+__device__ __forceinline__ genie_f2 gelu16_2(genie_f2 z) {
+    if constexpr (LOWP) return gelu_erf_poly2(z);
+    else return gelu_erf_fast2(z);
+}
+template <bool LOWP>
+__device__ __forceinline__ float gelu16_1(float z) { return gelu16_2<LOWP>(genie_f2{z, z})[0]; }
+
 // round-to-nearest-even f32 -> bf16 bits: v_cvt_pk_bf16_f32 (gfx950), one instruction instead of the five of the integer
 // emulation  u += 0x7FFF + ((u >> 16) & 1); u >>= 16  -- the same rounding for every finite value
 typedef __bf16 genie_bf2 __attribute__((ext_vector_type(2)));

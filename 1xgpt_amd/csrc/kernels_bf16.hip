@@ -210,7 +210,15 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
     auto value_of = [&](int it) {
         const ef4 cv = *reinterpret_cast<const ef4*>(ct + (it * 4 + (lane >> 4)) * 64 + c4);
         float4 v = make_float4(cv.x * alpha + bv4.x, cv.y * alpha + bv4.y, cv.z * alpha + bv4.z, cv.w * alpha + bv4.w);
-        if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+        if (do_gelu) {
+            // (bf16 operands and no f32 output: the value leaves only as bf16 -> the polynomial form, as in every bf16 kernel)
+            if (NPL == 1 && !outf) {
+                const genie_f2 g0 = gelu16_2<true>(genie_f2{v.x, v.y}), g1 = gelu16_2<true>(genie_f2{v.z, v.w});
+                v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+            } else {
+                v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w);
+            }
+        }
         return v;
     };
     auto store_row = [&](int row, float4 v) {
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_nt_kernel(const uint16_t* __res
             for (int c = 0; c < 4; ++c) {
                 if (col + c >= N) break;
                 float v = vv[c] * alpha + (bias ? bias[col + c] : 0.f);
-                if (do_gelu) v = gelu_erf_fast(v);
+                if (do_gelu) v = (NPL == 1 && !outf) ? gelu16_1<true>(v) : gelu_erf_fast(v);
                 const size_t idx = (size_t)row * ldc + col + c;
                 if (do_acc) v += Rsrc[idx];
                 if (outf) Cf[idx] = v;
@@ -534,7 +542,15 @@ __global__ __launch_bounds__(256 * NWN, 1) void gemm16_v2_kernel(const uint16_t*
     auto value_of = [&](int it) {   // alpha * tile + bias (+ GELU) of wave-instruction `it`
         const ef4 cv = *reinterpret_cast<const ef4*>(ct + (it * RPI + lane / LPR) * WN_COLS + c4);
         float4 v = make_float4(cv.x * alpha + bv.x, cv.y * alpha + bv.y, cv.z * alpha + bv.z, cv.w * alpha + bv.w);
-        if (do_gelu) { v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w); }
+        if (do_gelu) {
+            // (bf16 operands and no f32 output: the value leaves only as bf16 -> the polynomial form, as in every bf16 kernel)
+            if (NPL == 1 && !outf) {
+                const genie_f2 g0 = gelu16_2<true>(genie_f2{v.x, v.y}), g1 = gelu16_2<true>(genie_f2{v.z, v.w});
+                v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
+            } else {
+                v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w);
+            }
+        }
         return v;
     };
     auto store_row = [&](int row, float4 v) {
@@ -855,7 +871,7 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     const float* nbt = c.qk_norm ? lw.temporal.norm_b : nullptr;
     // Will the temporal sub-block run as the fused kernel?  Then it rounds its operands from the f32 rows itself and the spatial kernel in
     // front need not write the bf16 shadow of x (134 MB per layer at 64 clips it would write and the temporal kernel read).
-    static const int no_shadow_env = [] { const char* e = getenv("GENIE_T_FROM_F32"); return e ? atoi(e) : 1; }();
+    static const int no_shadow_env = study_env("GENIE_T_FROM_F32", 1);   // (a study-build knob: the shipping library reads no environment)
     const bool fused_t = w.frame_t < 0 && !w.tqkv && !w.tcache && !w.stop_after_tqkv && temporal_qkv16(c, w.model_T) &&
                          temporal_fused_takes(c, lw.temporal, B);
     const bool shadow16 = !(fused_t && no_shadow_env);

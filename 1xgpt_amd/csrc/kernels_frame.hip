@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm16_frm_kernel(const FrGem
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void ln_fr_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, float eps, uint16_t* __restrict__ out16) {
-    constexpr int NT = NW * 64, K = 64 * NW, RW = 32 / NW, G = RW / 4 > 0 ? RW / 4 : 1;
+    constexpr int K = 64 * NW, RW = 32 / NW, G = RW / 4 > 0 ? RW / 4 : 1;
     static_assert(RW % 4 == 0, "4 rows per instruction");
     constexpr int HS = 528, SS = 2 * HS, KBS = NPL * 4 * SS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -1020,9 +1020,30 @@ int launch_pack_spatial_qkv(const float* qkv_w, uint16_t* out, hipStream_t st) {
 
 // x += Mlp(LayerNorm(x)) on (rows, 256); x16_out (optional): bf16 shadow of the result, or -- when nx_g / nx_b are given --
 // LayerNorm(result; nx_g, nx_b) as bf16.  GENIE_E_UNSUPPORTED outside the geometry.
+#ifndef GENIE_VAR_S_MIN_SEQ
+#define GENIE_VAR_S_MIN_SEQ 128   // fewest sequences the fused spatial kernel takes (one workgroup each; measured: 64 sequences lose 15 %, 128 gain 5 %, 192 gain 9 % over attention + proj GEMM)
+#endif
+// (mode 2 of the fused MLP kernel writes planes for any consumer of the format: the stand-alone attention kernel takes them below
+// the fused spatial kernel's threshold, so no lower bound is needed on the producer side)
+#define GENIE_VAR_S_MIN_SEQ_DECL 0
 #ifndef GENIE_VAR_M_MIN_CLIPS
 #define GENIE_VAR_M_MIN_CLIPS 2   // fewest clips' worth of rows (4,096 each; same measurement)
 #endif
+// The spatial operand planes of n_seq sequences are addressed with 32-bit scalar offsets: one plane (n_seq * 256 * 256 bf16 values)
+// plus a tile of slack must stay below 2^31 bytes.  ONE predicate for the producer (fused MLP kernel, mode 2) and the consumer
+// (spatial_attn_proj): planes that are written can always be read (n_seq < ~15,200).
+static bool spatial_planes_addressable(long n_seq) { return (double)n_seq * 256 * 256 * 2 + 4096.0 * 256 < 2.0e9; }
+// multiprocessor count of the current device, read once (the fused launches size their persistent grids with it)
+static int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    return cus;
+}
+
 int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,
                           const float* nx_g, const float* nx_b, const uint16_t* nx_qkv_stream, uint16_t* planes) {
     if (!lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < GENIE_VAR_M_MIN_CLIPS * 4096 || !lw.norm2_w ||
@@ -1032,12 +1053,10 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
     // planes: the next block's spatial operand planes instead of its norm1 output (needs its qkv fragment stream, no qkv bias,
     // sequences of 256 tokens -- a wave's 32 rows never straddle one -- and the scalar offsets of the planes inside 2^31)
     const bool qkv = planes && nx_qkv_stream && nx_g && !c.qkv_bias && c.S == 256 && c.num_heads == 8 && c.head_dim == 32 && rows % 256 == 0 &&
-                     (double)rows * 256 * 2 * 3 < 2.0e9 * 4;
+                     spatial_planes_addressable(rows / 256) && rows / 256 >= GENIE_VAR_S_MIN_SEQ_DECL;
     if (planes && !qkv) return GENIE_E_UNSUPPORTED;
     const int n_blocks = (int)(rows / 128);
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     const int grid = n_blocks < 2 * cus ? n_blocks : 2 * cus;
     ProfScope prof(GENIE_KC_FUSED, (double)rows * (4.0 * 256 * 1024 + (qkv ? 2.0 * 256 * 768 : 0.0)),
                    (double)rows * (2048.0 + (qkv ? 1536.0 : x16_out ? 512.0 : 0.0)), st,
@@ -1048,15 +1067,15 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
     const int abl = study_env("GENIE_FUSED_ABL", 0);
     fs_stamps_prepare();
     if (qkv) {
-        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        { static const hipError_t once = hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); (void)once; }
         mlp_fused_bf16_kernel<2><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, planes, nx_g, nx_b, n_blocks,
                                                             1e-5f, abl, nx_qkv_stream, rows * 256, c.attn_scale * 1.4426950408889634f);
     } else if (nx_g) {
-        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        { static const hipError_t once = hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); (void)once; }
         mlp_fused_bf16_kernel<1><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nx_g, nx_b,
                                                             n_blocks, 1e-5f, abl, nullptr, 0, 0.f);
     } else {
-        (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+        { static const hipError_t once = hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); (void)once; }
         mlp_fused_bf16_kernel<0><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nullptr,
                                                             nullptr, n_blocks, 1e-5f, abl, nullptr, 0, 0.f);
     }
@@ -1223,7 +1242,14 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
             // this head's 64 KB have landed for every wave; the other buffer is free.  Head 0 of every sequence but the first: the
             // 64 stores of the previous sequence's epilogue are YOUNGER than this head's 8 LDS-DMA pieces (requested at that
             // sequence's last barrier) and may stay in flight -- vmcnt retires in order, so 63 outstanding means the pieces are in.
-            if (hd == 0 && seq != seq0) fs_wait_vm<63>(); else fs_wait_vm<0>();
+            // The count must not exceed the number of epilogue operations that are ALWAYS issued: 32 f32 stores, plus -- in the shipped
+            // form, GENIE_VAR_S_RESEND -- the 32 residual loads of the row-major epilogue (the 32 bf16 stores only exist with x16).
+#ifdef GENIE_VAR_S_RESEND
+            constexpr int YOUNGER_MIN = 64;
+#else
+            constexpr int YOUNGER_MIN = 32;   // (GENIE_VAR_S_RES_AT_START: the residual loads sit in front of the head loop)
+#endif
+            if (hd == 0 && seq != seq0) fs_wait_vm<YOUNGER_MIN - 1>(); else fs_wait_vm<0>();
             fs_barrier();
             {
                 const bool last_h = hd == NH - 1;
@@ -1349,23 +1375,18 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
 }
 
 // x += proj_s(attention_S(planes)) and x16 = bf16(x) for n_seq sequences of 256 tokens; GENIE_E_UNSUPPORTED outside d 256 / 8 x 32
-#ifndef GENIE_VAR_S_MIN_SEQ
-#define GENIE_VAR_S_MIN_SEQ 128   // fewest sequences the fused spatial kernel takes (one workgroup each; measured: 64 sequences lose 15 %, 128 gain 5 %, 192 gain 9 % over attention + proj GEMM)
-#endif
 int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* qkv16, float* x, uint16_t* x16,
                                   long n_seq, hipStream_t st) {
     if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.S != 256 || c.qk_norm || n_seq < GENIE_VAR_S_MIN_SEQ)
         return GENIE_E_UNSUPPORTED;
     const long P = n_seq * 256 * 256;
-    if ((double)P * 2 + 4096.0 * 256 >= 2.0e9) return GENIE_E_UNSUPPORTED;   // 32-bit scalar offsets inside the plane descriptors
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (!spatial_planes_addressable(n_seq)) return GENIE_E_UNSUPPORTED;   // 32-bit scalar offsets inside the plane descriptors
+    const int cus = device_cus();
     const unsigned grid = (unsigned)(n_seq < cus ? n_seq : cus);
     const double M = (double)n_seq * 256;
     ProfScope prof(GENIE_KC_FUSED, M * (4.0 * 256 * 256 + 2.0 * 256 * 256), M * (3 * 512.0 + 2048.0 + 512.0), st,
                    "spatial_attn_proj_bf16_kernel (attention over S, all heads + proj + residual)");
-    (void)hipFuncSetAttribute((const void*)spatial_attn_proj_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS);
+    { static const hipError_t once = hipFuncSetAttribute((const void*)spatial_attn_proj_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS); (void)once; }
 #ifndef GENIE_VAR_S_STAGGER
 #define GENIE_VAR_S_STAGGER 0     // (measured: 3-15 us per class only adds the delay -- profiles/r04_fused_experiments.txt)
 #endif
@@ -1389,9 +1410,7 @@ int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw,
                                hipStream_t st) {
     if (!temporal_fused_takes(c, aw, B)) return GENIE_E_UNSUPPORTED;
     const int n_blocks = B * c.S / 8;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     const int grid = n_blocks < 2 * cus ? n_blocks : 2 * cus;
     const double M = (double)B * c.T * c.S;
     ProfScope prof(GENIE_KC_FUSED, M * (2.0 * 256 * 1024 + 4.0 * 16 * 256), M * (512.0 + 2048.0), st,

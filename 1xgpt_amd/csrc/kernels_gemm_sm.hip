@@ -258,7 +258,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm16_sm_kernel(const uint16_t* _
         if constexpr (!PRE) { if (bias) bv = *reinterpret_cast<const float4*>(bias + col); }
         v.x = v.x * alpha + bv.x; v.y = v.y * alpha + bv.y; v.z = v.z * alpha + bv.z; v.w = v.w * alpha + bv.w;
         if (do_gelu) {
-            const genie_f2 g0 = gelu_erf_fast2(genie_f2{v.x, v.y}), g1 = gelu_erf_fast2(genie_f2{v.z, v.w});
+            // (bf16 operands and no f32 output: the polynomial form of every bf16 kernel, common.hpp gelu16_2)
+            const bool lowp = NPL == 1 && !outf;
+            const genie_f2 g0 = lowp ? gelu16_2<true>(genie_f2{v.x, v.y}) : gelu_erf_fast2(genie_f2{v.x, v.y});
+            const genie_f2 g1 = lowp ? gelu16_2<true>(genie_f2{v.z, v.w}) : gelu_erf_fast2(genie_f2{v.z, v.w});
             v.x = g0[0]; v.y = g0[1]; v.z = g1[0]; v.w = g1[1];
         }
         const size_t idx = (size_t)row * ldc + col;

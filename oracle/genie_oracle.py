@@ -34,10 +34,31 @@ def round_bf16(a: np.ndarray) -> np.ndarray:
     return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
 
 
-class Numerics:
-    """dtype + optional operand rounding applied at every GEMM/attention-matmul input."""
+# The GELU of the HIP bf16 contract (csrc/common.hpp gelu_erf_poly2, used by EVERY bf16 kernel whose hidden leaves only as bf16):
+# gelu(z) = z * (1/2 + zc * P(zc^2)), zc = clamp(z, -4.25, 4.25), P of degree 8 -- |Phi error| <= 1.3e-5 against the reference's erf form
+# (st_transformer.py:18); coefficients = tools/fit_gelu_poly.py COEF (tests/test_gelu_poly.py holds all three copies together).
+GELU_POLY_Z = 4.25
+GELU_POLY_COEF = (3.989023268e-01, -6.634449214e-02, 9.815969504e-03, -1.108560245e-03, 9.341857367e-05, -5.626413895e-06,
+                  2.255418963e-07, -5.327728037e-09, 5.564818051e-11)
 
-    def __init__(self, dtype=np.float32, gemm_in=None, attn_in=False, temporal_qkv=None):
+
+def gelu_poly(z):
+    """What the bf16 kernels compute, in f32 like the kernel's Horner chain (numpy's mul + add where the kernel has one fused
+    multiply-add: the same to ~1 ulp per step, which only matters where the bf16 rounding of the result sits on a boundary)."""
+    z = np.asarray(z, dtype=np.float32)
+    zc = np.clip(z, np.float32(-GELU_POLY_Z), np.float32(GELU_POLY_Z))
+    s = zc * zc
+    p = np.full_like(s, np.float32(GELU_POLY_COEF[-1]))
+    for c in GELU_POLY_COEF[-2::-1]:
+        p = p * s + np.float32(c)
+    return z * (zc * p + np.float32(0.5))
+
+
+class Numerics:
+    """dtype + optional operand rounding applied at every GEMM/attention-matmul input (+ the GELU form of the contract)."""
+
+    def __init__(self, dtype=np.float32, gemm_in=None, attn_in=False, temporal_qkv=None, gelu=None):
+        self.gelu = gelu            # None: the reference's erf form (gelu_erf); the HIP bf16 contract: gelu_poly
         self.dtype = np.dtype(dtype)
         self.gemm_in = gemm_in  # rounding of every nn.Linear operand (e.g. round_bf16)
         self.attn_in = attn_in  # True: the attention matmuls also take rounded operands (bf16 contract);
@@ -54,8 +75,9 @@ class Numerics:
 F32 = Numerics(np.float32)
 F64 = Numerics(np.float64)
 # HIP bf16 contract: Linear operands bf16, the temporal qkv buffer / KV cache stored in bf16, attention arithmetic f32
-BF16_MFMA = Numerics(np.float32, round_bf16, temporal_qkv=round_bf16)
-BF16_ALL = Numerics(np.float32, round_bf16, attn_in=True, temporal_qkv=round_bf16)  # attention matmuls on bf16 operands as well
+# (+ the polynomial GELU in front of the bf16 rounding of the MLP hidden)
+BF16_MFMA = Numerics(np.float32, round_bf16, temporal_qkv=round_bf16, gelu=gelu_poly)
+BF16_ALL = Numerics(np.float32, round_bf16, attn_in=True, temporal_qkv=round_bf16, gelu=gelu_poly)  # attention matmuls on bf16 operands as well
 
 
 # ----------------------------------------------------------------------------------------------
@@ -167,7 +189,7 @@ def mlp(x, sd, prefix, cfg, nm=F32):
     h = nm.r(x) @ nm.r(sd[prefix + "fc1.weight"].astype(dt)).T
     if cfg.mlp_bias:
         h = h + sd[prefix + "fc1.bias"].astype(dt)
-    h = gelu_erf(h)
+    h = nm.gelu(h) if nm.gelu is not None else gelu_erf(h)
     o = nm.r(h) @ nm.r(sd[prefix + "fc2.weight"].astype(dt)).T
     if cfg.mlp_bias:
         o = o + sd[prefix + "fc2.bias"].astype(dt)

@@ -19,6 +19,11 @@ def test_kernel_literals_are_the_fitted_ones():
     lits = [float(m) for m in re.findall(r"splat\((-?[0-9.]+e[-+][0-9]+)f\)", body)]
     assert lits == list(F.COEF[::-1])             # Horner order: highest power first
     assert "-4.25f, 4.25f" in body and F.Z == 4.25
+    # ... and the oracle's bf16 contract evaluates the same polynomial
+    from oracle import genie_oracle as O
+    assert tuple(O.GELU_POLY_COEF) == tuple(F.COEF) and O.GELU_POLY_Z == F.Z
+    z = np.linspace(-9, 9, 20001).astype(np.float32)
+    assert np.array_equal(O.gelu_poly(z), F.gelu_poly_f32(z)[0])
 
 
 def test_error_bounds():

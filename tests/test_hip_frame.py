@@ -122,3 +122,38 @@ def test_merged_commit_schedule_equals_plain_kv_cache_schedule(steps):
             plain = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=False)
             merged = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=True)
             assert torch.equal(plain, merged)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(256, 1536, 512, 1), (512, 512, 512, 1), (96, 192, 128, 1), (1024, 2048, 512, 1), (2048, 1536, 512, 2),
+                                        (1280, 512, 2048, 2), (4096, 512, 512, 2), (384, 128, 256, 2)])
+def test_frame_linear_vs_f64(M, N, K, mode):
+    """genie_frame_linear (nn.Linear on fragment-ordered split operands; st_transformer.py:16-25, attention.py:27-29) against the
+    f64 product of the SAME split operands (hi + lo / 2048 of genie_pack_split_f16): the kernels' only error is the dropped lo.lo term
+    and f32 accumulation order.  mode 1 = register-direct kernel, 2 = LDS-tiled kernel; ragged chip fills, K = 128 .. 2048."""
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g) * 2.0
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+
+    def packs(t):
+        rm = torch.empty((2,) + tuple(t.shape), dtype=torch.float16, device="cuda")
+        fr = torch.empty(2 * t.numel(), dtype=torch.float16, device="cuda")
+        _lib.check(lib.genie_pack_split_f16(t.data_ptr(), rm.data_ptr(), t.numel(), st), "pack_split")
+        _lib.check(lib.genie_pack_frame_w16(t.data_ptr(), fr.data_ptr(), t.shape[0], t.shape[1], st), "pack_frame")
+        return rm[0].double() + rm[1].double() / 2048.0, fr
+
+    x64, x_fr = packs(x)
+    w64, w_fr = packs(W)
+    y = torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(lib.genie_frame_linear(x_fr.data_ptr(), w_fr.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, mode, st), "frame_linear")
+    ref = x64 @ w64.T + b.double()
+    err = (y.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"frame_linear M={M} N={N} K={K} mode={mode}: max err {err:.2e} of {scale:.2f}")
+    assert err < 5e-6 * scale * max(1.0, (K / 512) ** 0.5)
+    # without a bias
+    _lib.check(lib.genie_frame_linear(x_fr.data_ptr(), w_fr.data_ptr(), 0, y.data_ptr(), M, N, K, mode, st), "frame_linear")
+    assert (y.double() - (ref - b.double())).abs().max().item() < 5e-6 * scale * max(1.0, (K / 512) ** 0.5)

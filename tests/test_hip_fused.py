@@ -46,7 +46,23 @@ def test_fused_blocks_match_unfused_and_oracle(monkeypatch, qkv_bias):
     x[:, 8:] = cfg.image_vocab_size
     mf = _model(cfg, sd, True, monkeypatch)
     assert _uses_fused(mf)
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    _lib.check(lib.genie_profile_enable(1 << _lib.KC_FUSED), "profile_enable")
+    lib.genie_profile_reset()
     hf = mf.hidden_states(dev(x)).cpu().numpy().copy()
+    import ctypes
+    kbuf = ctypes.create_string_buffer(4096)
+    _lib.check(lib.genie_profile_kernels(_lib.KC_FUSED, kbuf, len(kbuf)), "profile_kernels")
+    lib.genie_profile_enable(0)
+    launched = {ln.split("\t")[0].split(" ")[0]: int(float(ln.split("\t")[1])) for ln in kbuf.value.decode().splitlines()}
+    print("fused launches:", launched)
+    # proof of launch: every block ran its three sub-blocks as the fused kernels (19 clips = 304 sequences: above every size
+    # threshold) -- nothing fell back to the unfused launches silently
+    L = cfg.num_layers
+    assert launched.get("spatial_attn_proj_bf16_kernel", 0) == L, launched
+    assert launched.get("temporal_fused_bf16_kernel", 0) == L, launched
+    assert sum(v for k, v in launched.items() if k.startswith("mlp_fused_bf16_kernel")) == L, launched
     mu = _model(cfg, sd, False, monkeypatch)
     assert not _uses_fused(mu)
     hu = mu.hidden_states(dev(x)).cpu().numpy().copy()
@@ -62,9 +78,14 @@ def test_fused_blocks_match_unfused_and_oracle(monkeypatch, qkv_bias):
         print("clip", b, "fused vs oracle max/median", ef.max(), np.median(ef), " unfused vs oracle", eu.max(), np.median(eu))
         assert np.median(ef) < 2e-3 * scale and ef.max() < 5e-2 * scale
         assert np.median(ef) < 2.0 * np.median(eu) + 1e-6     # no worse than the launches it replaces (same contract)
-    # batch independence: a clip alone takes the unfused launches (too few blocks), in a batch the fused kernel
-    h1 = mf.hidden_states(dev(x[4:5])).cpu().numpy()
-    assert np.abs(h1[0] - hf[4]).max() < 5e-2 * scale
+    # batch independence: the kernel a sub-block runs on depends on the batch (1 clip: unfused launches; 2-7: fused temporal / MLP, unfused
+    # spatial; >= 8: all fused) -- the SAME rounding points and the same GELU everywhere (common.hpp gelu16_2), so a clip's hidden state
+    # moves by summation order and one-ulp bf16 flips only: measured 2.5e-3 of the scale at the maximum, 2.5e-4 at the median
+    for nb in (1, 2, 8):
+        hb = mf.hidden_states(dev(x[4:4 + nb])).cpu().numpy()
+        db = np.abs(hb - hf[4:4 + nb])
+        print(f"clip 4 in a batch of {nb} vs in the batch of {B}: max {db.max():.3e} median {np.median(db):.3e} (scale {scale:.2f})")
+        assert db.max() < 1e-2 * scale and np.median(db) < 6e-4 * scale
     # the readout takes the bf16 shadow of x that the last layer's fused MLP writes: logits of the last frames, fused vs unfused
     lf = mf.compute_logits_frames(dev(x), 14, 16, "token").cpu().numpy()
     lu = mu.compute_logits_frames(dev(x), 14, 16, "token").cpu().numpy()
@@ -239,3 +260,58 @@ def test_mlp_fused_qkv_entry_point_planes_vs_oracle():
     cb = _lib.make_cfg(pkg("config").GenieConfig(num_layers=32, num_heads=8, d_model=256, T=16, S=256, num_factored_vocabs=2,
                                                  qk_norm=False, use_mup=False, qkv_bias=True), _lib.PREC_BF16)
     assert lib.genie_mlp_fused_qkv_bf16(cb, lw, nx, xd.data_ptr(), planes.data_ptr(), rows, st) != 0
+
+
+@pytest.mark.parametrize("n_seq", [128, 304, 1920])
+@pytest.mark.parametrize("with_x16", [False, True])
+def test_spatial_attn_proj_fused_entry_point_vs_reference_math(n_seq, with_x16):
+    """genie_spatial_attn_proj_fused_bf16 on operand planes built HERE from random q, k, v in the formats of include/genie_hip.h
+    (Q scale log2e, K head-major; V^T with its key order): x += proj(softmax(q k^T scale) v) over the 256 positions of each sequence,
+    8 heads of 32 (attention.py:48-60 + the out-projection and residual of st_transformer.py:73-74), against the same math in f64
+    on the bf16-rounded operands (the BF16_MFMA contract: bf16 q / k / v and out-projection operands, f32 softmax).  128 = the
+    kernel's smallest problem (one workgroup per sequence, half the CUs idle), 304 = a ragged second round, 1,920 = the benchmark's
+    128-clip pass."""
+    _lib, lib, c, cfg, st = _unit_setup()
+    g = torch.Generator(device="cuda").manual_seed(100 + n_seq)
+    rows = n_seq * 256
+    q = torch.randn(n_seq, 8, 256, 32, device="cuda", generator=g) * 1.2
+    k = torch.randn(n_seq, 8, 256, 32, device="cuda", generator=g) * 1.2
+    v = torch.randn(n_seq, 8, 256, 32, device="cuda", generator=g)
+    wp = torch.randn(256, 256, device="cuda", generator=g) * 0.06
+    pb = torch.randn(256, device="cuda", generator=g) * 0.05
+    x = torch.randn(rows, 256, device="cuda", generator=g) * 1.5
+    scale = float(c.attn_scale)
+    q16 = (q * (scale * 1.4426950408889634)).to(torch.bfloat16)     # what the qkv GEMM's epilogue stores
+    k16, v16 = k.to(torch.bfloat16), v.to(torch.bfloat16)
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device="cuda")
+    vt = v16.transpose(2, 3).reshape(n_seq, 8, 32, 16, 16)[..., perm].reshape(n_seq, 8, 32, 256)   # stored position p' holds key perm[p']
+    planes = torch.cat([q16.reshape(-1), k16.reshape(-1), vt.reshape(-1)]).contiguous()
+    assert planes.numel() == 3 * rows * 256
+    sf = torch.zeros(_lib.SPATIAL_PROJ_FUSED_ELEMS + _lib.SPATIAL_QKV_FUSED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_pack_spatial_proj_fused_bf16(wp.data_ptr(), sf.data_ptr(), st), "pack proj")
+    aw = _lib.AttnWeights()
+    aw.fused_w16, aw.proj_b = sf.data_ptr(), pb.data_ptr()
+    xd = x.clone()
+    x16 = torch.zeros(rows, 256, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_spatial_attn_proj_fused_bf16(cfg, aw, planes.data_ptr(), xd.data_ptr(), x16.data_ptr() if with_x16 else 0, n_seq,
+                                                      st), "spatial fused")
+    # reference math in f64 on the same bf16 operands, chunked over sequences
+    upd = torch.empty_like(x)
+    wp64 = wp.to(torch.bfloat16).double()
+    for s0 in range(0, n_seq, 64):
+        sl = slice(s0, min(s0 + 64, n_seq))
+        sc = (q16[sl].double() / 1.4426950408889634) @ k16[sl].double().transpose(2, 3)       # = q k^T scale
+        o = torch.softmax(sc, dim=-1) @ v16[sl].double()                                       # (n, 8, 256, 32)
+        o16 = o.transpose(1, 2).reshape(-1, 256).float().to(torch.bfloat16).double()          # attention output as proj operand
+        upd[sl.start * 256:sl.stop * 256] = (o16 @ wp64.T + pb.double()).float()
+    ref = x + upd
+    u = upd.abs().max().item()
+    d = (xd - ref).abs()
+    print("spatial fused unit: n_seq", n_seq, "update", u, "max err", d.max().item(), "median", d.median().item())
+    assert torch.isfinite(xd).all() and d.max().item() < 2e-2 * u and d.median().item() < 1e-3 * u
+    if with_x16:
+        assert torch.equal(x16, xd.to(torch.bfloat16))       # the 16-bit copy is the bf16 rounding of the kernel's own f32 result
+    else:
+        assert (x16 == 0).all()
+    # below the kernel's size threshold the entry point must refuse, not compute garbage
+    assert lib.genie_spatial_attn_proj_fused_bf16(cfg, aw, planes.data_ptr(), xd.data_ptr(), 0, 64, st) == _lib.E_UNSUPPORTED
