@@ -1327,8 +1327,13 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
             uint16_t* xw16 = x16 + soff;
             int w16 = x16 != nullptr;
             asm volatile("" : "+v"(w16));   // per-lane predicate: the store is masked, the loop not duplicated
-            int rr = lane >> 3, cc = (lane & 7) * 4;              // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
-            asm volatile("" : "+v"(rr), "+v"(cc));            // (everything derived from them is formed here, not hoisted and spilled)
+            // (an opaque copy of the lane id: what the epilogue derives from it -- rr, cc, the tile row offset r * 36 -- is formed HERE;
+            // derived from `lane` itself the compiler computed (lane & 7) * 4 and (lane & 31) * 144 in front of the head loop, spilled
+            // them at 256 registers and reloaded them here behind an s_waitcnt vmcnt(0) that also drained the next head's LDS-DMA)
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int rr = le >> 3, cc = (le & 7) * 4;        // row-major side: row rr + 8 i, columns cc .. cc + 3 of the tile
+            const int re = le & 31, he = le >> 5;             // accumulator side: (r, h) of this lane
 #ifdef GENIE_VAR_S_RESEND
 #ifndef GENIE_VAR_S_EPF
 #define GENIE_VAR_S_EPF 1      // residual column tiles requested ahead of their use
@@ -1349,9 +1354,9 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
 #endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f32x4*>(tile + r * 36 + 8 * j + 4 * h) =
+                    *reinterpret_cast<f32x4*>(tile + re * 36 + 8 * j + 4 * he) =
                         f32x4{out[ct][4 * j], out[ct][4 * j + 1], out[ct][4 * j + 2], out[ct][4 * j + 3]} +
-                        *reinterpret_cast<const f32x4*>(sbias + 32 * ct + 8 * j + 4 * h);
+                        *reinterpret_cast<const f32x4*>(sbias + 32 * ct + 8 * j + 4 * he);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
