@@ -528,7 +528,7 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* wt, const int64_
 }
 
 int genie_frame_linear(const uint16_t* a_fr, const uint16_t* w_fr, const float* bias, float* y, int M, int N, int K, int mode, void* stream) {
-    GENIE_CHECK_ARG(a_fr && w_fr && y && mode >= 0 && mode <= 3, "frame_linear: bad argument");
+    GENIE_CHECK_ARG(a_fr && w_fr && y && mode >= 0 && mode <= 2, "frame_linear: bad argument");
     return launch_frame_linear(a_fr, w_fr, bias, y, M, N, K, mode, as_stream(stream));
 }
 

@@ -450,42 +450,46 @@ __device__ __forceinline__ void frm_epilogue(const FrGemmArgs& a, const f32x16 (
                 *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
             }
     } else if constexpr (EPI == FR_EPI_QKVS) {
-        // (a wave's 32 columns are half a head slice: steps 2 c .. 2 c + 1 of Q / K, feature tile dt = c of V^T, c = (n0 % 64) / 32)
-        static_assert(EPI != FR_EPI_QKVS || NJ == 1, "attention operand planes: 32 columns per wave");
+        // (every 32-column tile j of the wave is half a head slice: steps 2 c .. 2 c + 1 of Q / K, feature tile dt = c of V^T,
+        // c = (column % 64) / 32)
         const int dH = a.H * 64;
-        const int which = n0 / dH, head = (n0 % dH) / 64, half = (n0 & 63) >> 5;
         const int blocks = a.S / 32;
         const size_t unit = (size_t)blocks * NPL * 4 * FR;
-        const float sc = which == 0 ? a.qscale : 1.0f;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int rb = rb0 + i;
-            const long seq = rb / blocks;
-            const int blk = rb % blocks;
-            uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
-            const float* tl = tile + (size_t)32 * i * PITCH;
+        for (int j = 0; j < NJ; ++j) {
+            const int nj = n0 + 32 * j;
+            const int which = nj / dH, head = (nj % dH) / 64, half = (nj & 63) >> 5;
+            const float sc = which == 0 ? a.qscale : 1.0f;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                float v[8];
-                uint16_t* dst;
-                int lo_off;
-                if (which < 2) {       // step 2 half + sub
-                    const float* src = tl + r * PITCH + 16 * sub + 8 * h;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
+            for (int i = 0; i < MI; ++i) {
+                const int rb = rb0 + i;
+                const long seq = rb / blocks;
+                const int blk = rb % blocks;
+                uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
+                const float* tl = tile + (size_t)32 * i * PITCH + 32 * j;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                    dst = base + ((size_t)blk * NPL * 4 + 2 * half + sub) * FR + fl * 8;
-                    lo_off = 4 * FR;
-                } else {               // dt = half, m = sub
+                for (int sub = 0; sub < 2; ++sub) {
+                    float v[8];
+                    uint16_t* dst;
+                    int lo_off;
+                    if (which < 2) {       // step 2 half + sub
+                        const float* src = tl + r * PITCH + 16 * sub + 8 * h;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
 #pragma unroll
-                    for (int s8 = 0; s8 < 8; ++s8) v[s8] = tl[(16 * sub + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + r];
-                    dst = base + ((size_t)(blk * 2 + half) * 2 + sub) * NPL * FR + fl * 8;
-                    lo_off = FR;
+                        for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                        dst = base + ((size_t)blk * NPL * 4 + 2 * half + sub) * FR + fl * 8;
+                        lo_off = 4 * FR;
+                    } else {               // dt = half, m = sub
+#pragma unroll
+                        for (int s8 = 0; s8 < 8; ++s8) v[s8] = tl[(16 * sub + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + r];
+                        dst = base + ((size_t)(blk * 2 + half) * 2 + sub) * NPL * FR + fl * 8;
+                        lo_off = FR;
+                    }
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    *reinterpret_cast<u32x4*>(dst) = hi;
+                    *reinterpret_cast<u32x4*>(dst + lo_off) = lo;
                 }
-                u32x4 hi, lo;
-                split8(v, hi, lo);
-                *reinterpret_cast<u32x4*>(dst) = hi;
-                *reinterpret_cast<u32x4*>(dst + lo_off) = lo;
             }
         }
     }
@@ -610,86 +614,6 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm16_frm_kernel(const FrGem
     // ---- epilogue, wave-local
     frm_epilogue<MI, NJ, EPI>(a, accm, accc, reinterpret_cast<float*>(smem) + (size_t)wid * 32 * MI * PITCH, rbA0 + wm * MI,
                               (rbW0 + wn * NJ) * 32, lane);
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// The wide Linears (N >= 1024: qkv, fc1, readout; K <= 512) of passes from 1,024 rows: what bounds a pipelined tile at this size is the
-// memory round trip (~2 us for a cold weight line), not the matrix pipe -- gemm16_frm's three 32 KB stages in flight cover about
-// 1 us of it (13.9 us for ONE 128 x 128 tile on an idle chip, 16 stages: profiles/r05e_frame_gemm.txt).  Here nothing is staged
-// through a ring: workgroup = (32 MI) rows x 256 columns, wave w = the 32 columns w of the tile;
-//   * A: the tile's rows over ALL of K sit in LDS (MI x K / 64 blocks of 8 KB, fragment order, LDS-DMA, requested at once);
-//   * W: every wave streams ITS column block's fragments straight into registers, DW k-blocks (32 registers each) ahead --
-//     no wave reads another wave's weights, so there is nothing to share and no barrier in the K loop;
-// one barrier (A landed) per tile; 128 KB + 256 KB of requests in flight per CU from the first cycle.  Same two-accumulator split
-// arithmetic and wave-local epilogues as gemm16_frm (a row's sum runs over k in order).
-// ------------------------------------------------------------------------------------------------------------------------------
-template <int MI, int KB, int EPI>
-__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm16_frs_kernel(const FrGemmArgs a) {
-    constexpr int DW = KB < 4 ? KB : 4;                 // k-blocks of W in flight per wave
-    constexpr int PITCH = 36;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = a.N / 256;
-    const int rb0 = (blockIdx.x / nt) * MI;
-    const int cb = (blockIdx.x % nt) * 8 + wid;         // this wave's 32-column block of W
-    asm volatile("" :: "s"(a.A), "s"(a.W), "s"(a.bias), "s"(a.Cf), "s"(a.ldc), "s"(a.N), "s"(a.a_group), "s"(a.a_mul), "s"(a.a_off));
-    // ---- A: wave w moves fragment w (plane w / 4, step w % 4) of every (row block, k-block): the k-blocks land in order on every wave
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int rb = rb0 + i;
-        const long arb = ((long)(rb / a.a_group) * a.a_mul + a.a_off) * a.a_group + rb % a.a_group;
-        const uint16_t* src = a.A + fr_frag(arb, 0, KB, 0, 0) + (size_t)wid * FR + lane * 8;
-        unsigned char* dst = smem + (size_t)i * KB * 8192 + (size_t)wid * 1024;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)kb * 8 * FR),
-                                             (__attribute__((address_space(3))) void*)(dst + kb * 8192), 16, 0, 0);
-    }
-    // ---- W: this wave's column block, DW k-blocks ahead in registers
-    u32x4 wf[DW][NPL][4];
-    const uint16_t* wsrc = a.W + fr_frag(cb, 0, KB, 0, 0) + lane * 8;
-    auto load_w = [&](int slot, int kb) {
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) wf[slot][p][s] = *reinterpret_cast<const u32x4*>(wsrc + ((size_t)kb * 8 + p * 4 + s) * FR);
-    };
-#pragma unroll
-    for (int kb = 0; kb < DW; ++kb) load_w(kb, kb);
-    FR_PIN_LOADS();
-    f32x16 accm[MI][1], accc[MI][1];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { accm[i][0][e] = 0.f; accc[i][0][e] = 0.f; }
-    // A has landed when only the DW x 8 weight loads (younger) are outstanding
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DW * 8) : "memory");
-    __builtin_amdgcn_s_barrier();   // (not __syncthreads: its vmcnt(0) would wait for the weight loads as well)
-    const unsigned char* abase = smem + lane * 16;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const int slot = kb % DW;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            u32x4 af[MI][NPL];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    af[i][p] = *reinterpret_cast<const u32x4*>(abase + ((size_t)(i * KB + kb) * 8 + p * 4 + s) * 1024);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) accm[i][0] = mma16(af[i][0], wf[slot][0][s], accm[i][0]);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) accc[i][0] = mma16(af[i][0], wf[slot][1][s], accc[i][0]);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) accc[i][0] = mma16(af[i][1], wf[slot][0][s], accc[i][0]);
-        }
-        if (kb + DW < KB) load_w(slot, kb + DW);   // the freed slot is refilled at once: its round trip hides behind DW - 1 k-blocks
-        FR_PIN_LOADS();
-    }
-    __syncthreads();   // every wave is done with A: its area becomes the epilogue tiles
-    frm_epilogue<MI, 1, EPI>(a, accm, accc, reinterpret_cast<float*>(smem) + (size_t)wid * 32 * MI * PITCH, rb0, cb * 32, lane);
 }
 
 // LayerNorm of f32 rows -> fragment-ordered split operand (the mid-size passes; below 1024 rows the Linear does it in its prologue):
@@ -1027,31 +951,16 @@ int launch_frm(const FrGemmArgs& a, hipStream_t st) {
 template <int EPI>
 int launch_frm_any(const FrGemmArgs& a, hipStream_t st) {
     const long t128 = (long)(a.M / 128) * (a.N / 128);
+    // the wide Linears (N >= 1024) from 4,096 rows: 256 x 128 tiles, 64 x 64 per wave -- a 32 k stage is 24 matrix instructions per
+    // wave (0.64 us per CU), so the two stages in flight cover twice the round trip that 128 x 128 tiles (12 per stage) cover:
+    // qkv 32.6 -> 29.4 us, fc1 38.6 -> 33.2 at 4,096 rows, fc1 73.4 -> 64.9 at 8,192; at 2,048 rows (96 tiles) they lose
+    // (17.7 -> 26.6): profiles/r05j_frame_gemm.txt against r05i
+    static const int big = study_env("GENIE_FRM_256", 1);
+    if (big && a.N >= 1024 && a.N % 128 == 0 && a.M % 256 == 0 && a.M >= 4096) return launch_frm<4, 2, 2, 2, 3, EPI>(a, st);
     if (a.N % 128 == 0 && (EPI == FR_EPI_QKVS || t128 >= 160 || a.N >= 1024)) return launch_frm<2, 4, 2, 1, 4, EPI>(a, st);
     if constexpr (EPI != FR_EPI_QKVS) return launch_frm<4, 2, 1, 1, 5, EPI>(a, st);
     return GENIE_E_UNSUPPORTED;
 }
-// A-resident kernel: 64-row tiles x 256 columns (N % 256 == 0, K in {512, 256, 128}, M % 64 == 0)
-template <int EPI>
-int launch_frs(const FrGemmArgs& a, hipStream_t st) {
-    if (a.M % 64 || a.N % 256 || (a.K != 512 && a.K != 256 && a.K != 128)) return GENIE_E_UNSUPPORTED;
-#define FRS_LAUNCH(KB_)                                                                                                      \
-    case KB_: {                                                                                                              \
-        static bool attr_set = false;                                                                                        \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm16_frs_kernel<2, KB_, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        const size_t lds = (size_t)2 * KB_ * 8192 > 73728 ? (size_t)2 * KB_ * 8192 : 73728;                                  \
-        gemm16_frs_kernel<2, KB_, EPI><<<(unsigned)((a.M / 64) * (a.N / 256)), 512, lds, st>>>(a);                           \
-        break;                                                                                                               \
-    }
-    switch (a.K / 64) {
-        FRS_LAUNCH(8) FRS_LAUNCH(4) FRS_LAUNCH(2)
-        default: return GENIE_E_UNSUPPORTED;
-    }
-#undef FRS_LAUNCH
-    GENIE_LAUNCH_CHECK("gemm16_frs");
-    return GENIE_OK;
-}
-
 int launch_ln_fr(const float* x, long ldx, const float* g, const float* b, float eps, uint16_t* out16, int M, int K, hipStream_t st) {
     const size_t lds = (size_t)(K / 64) * NPL * 4 * 1056 + (size_t)2 * K * 4;
 #define LN_FR(NW_)                                                                                                           \
@@ -1086,11 +995,6 @@ static long frm_min_rows() {
     static const long v = study_env("GENIE_FRM_MIN_ROWS", 2048);
     return v;
 }
-// rows from which the wide Linears (qkv, fc1, readout) run the A-resident kernel (gemm16_frs, separate LayerNorm)
-static long frs_min_rows() {
-    static const long v = study_env("GENIE_FRS_MIN_ROWS", 1024);
-    return v;
-}
 
 int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, int nf, bool want_xs,
                          hipStream_t st) {
@@ -1100,8 +1004,6 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     // (the out-projections, N = d: the register-direct kernel is ahead up to twice that many rows -- 7.5 against 10.4 us at 2,048
     // rows, 17.7 against 14.4 at 4,096: profiles/r05e_frame_gemm.txt)
     const bool mid_proj = mid && M >= 2 * frm_min_rows();
-    // the wide Linears (3 d and 4 d columns over K = d) on the A-resident kernel
-    const bool wide = M >= frs_min_rows() && M % 64 == 0 && (3 * d) % 256 == 0 && hid % 256 == 0 && (d == 512 || d == 256 || d == 128);
     uint16_t* xs = (uint16_t*)w.xn;
     uint16_t* as = (uint16_t*)w.aux;
     uint16_t* big = (uint16_t*)w.big;
@@ -1122,15 +1024,15 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         FrGemmArgs g = a;
         g.W = wq_s; g.bias = c.qkv_bias ? lw.spatial.qkv_b : nullptr; g.N = 3 * d; g.K = d;
         g.qkvs = big; g.qscale = c.attn_scale * 1.4426950408889634f; g.H = H; g.S = S;
-        if (wide || mid) {
+        if (mid) {
             {
                 ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * M * d, 8.0 * M * d, st, "ln_fr_kernel");
                 GENIE_TRY(launch_ln_fr(x, d, lw.norm1_w, lw.norm1_b, 1e-5f, as, M, d, st));
             }
             g.A = as;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
-                           wide ? "gemm16_frs_kernel (qkv -> attention operand planes)" : "gemm16_frm_kernel (qkv -> attention operand planes)");
-            GENIE_TRY(wide ? launch_frs<FR_EPI_QKVS>(g, st) : launch_frm_any<FR_EPI_QKVS>(g, st));
+                           "gemm16_frm_kernel (qkv -> attention operand planes)");
+            GENIE_TRY(launch_frm_any<FR_EPI_QKVS>(g, st));
         } else {
             g.X = x; g.ldx = d; g.ln_g = lw.norm1_w; g.ln_b = lw.norm1_b; g.ln_eps = 1e-5f;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
@@ -1166,9 +1068,8 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         g.Cf = w.fcache + (size_t)w.frame_t * S * 3 * d; g.ldc = 3 * d; g.rows_per_batch = (long)nf * S;
         g.strideC = (long)w.frame_T * S * 3 * d;
         ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
-                       wide ? "gemm16_frs_kernel (temporal qkv -> cache)" : mid ? "gemm16_frm_kernel (temporal qkv -> cache)" : "gemm16_fr_kernel (temporal qkv -> cache)");
-        if (wide) GENIE_TRY(launch_frs<FR_EPI_F32>(g, st));
-        else if (mid) GENIE_TRY(launch_frm_any<FR_EPI_F32>(g, st));
+                       mid ? "gemm16_frm_kernel (temporal qkv -> cache)" : "gemm16_fr_kernel (temporal qkv -> cache)");
+        if (mid) GENIE_TRY(launch_frm_any<FR_EPI_F32>(g, st));
         else GENIE_TRY((launch_fr_w<2, 1, FR_EPI_F32, false>(nw, g, st)));
     }
     {
@@ -1191,15 +1092,15 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     {
         FrGemmArgs g = a;
         g.W = w1; g.bias = c.mlp_bias ? lw.fc1_b : nullptr; g.N = hid; g.K = d; g.C16 = big;
-        if (wide || mid) {
+        if (mid) {
             {
                 ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * M * d, 8.0 * M * d, st, "ln_fr_kernel");
                 GENIE_TRY(launch_ln_fr(x, d, lw.norm2_w, lw.norm2_b, 1e-5f, as, M, d, st));
             }
             g.A = as;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
-                           wide ? "gemm16_frs_kernel (fc1 + GELU)" : "gemm16_frm_kernel (fc1 + GELU)");
-            GENIE_TRY(wide ? launch_frs<FR_EPI_GELU>(g, st) : launch_frm_any<FR_EPI_GELU>(g, st));
+                           "gemm16_frm_kernel (fc1 + GELU)");
+            GENIE_TRY(launch_frm_any<FR_EPI_GELU>(g, st));
         } else {
             g.X = x; g.ldx = d; g.ln_g = lw.norm2_w; g.ln_b = lw.norm2_b; g.ln_eps = 1e-5f;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
@@ -1220,7 +1121,7 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
 }
 
 // y (M, N) f32 = A . W^T + bias from fragment-ordered split operands (C ABI genie_frame_linear: the kernel-level test and
-// micro-benchmark entry).  mode 0: the block driver's own choice, 1: register-direct kernel, 2: LDS-tiled kernel, 3: A-resident kernel.
+// micro-benchmark entry).  mode 0: the block driver's own choice, 1: register-direct kernel, 2: LDS-tiled kernel.
 int launch_frame_linear(const uint16_t* A, const uint16_t* W, const float* bias, float* y, int M, int N, int K, int mode, hipStream_t st) {
     GENIE_CHECK_SHAPE(M % 32 == 0 && N % 64 == 0 && K % 64 == 0, "frame_linear: (M, N, K) = (%d, %d, %d) must be multiples of (32, 64, 64)", M, N, K);
     FrGemmArgs g;
@@ -1228,8 +1129,6 @@ int launch_frame_linear(const uint16_t* A, const uint16_t* W, const float* bias,
     g.A = A; g.a_group = 1; g.a_mul = 1; g.a_off = 0;
     g.W = W; g.bias = bias; g.alpha = 1.0f; g.M = M; g.N = N; g.K = K;
     g.Cf = y; g.ldc = N; g.rows_per_batch = M; g.strideC = 0;
-    if (mode == 3 || (mode == 0 && M >= frs_min_rows() && M % 64 == 0 && N % 256 == 0 && (K == 512 || K == 256 || K == 128)))
-        return launch_frs<FR_EPI_F32>(g, st);
     const bool mid = mode == 2 || (mode == 0 && M >= frm_min_rows() && M % 128 == 0);
     ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)N * K, 4.0 * M * K + 4.0 * N * K + 4.0 * M * N, st, "gemm16_fr(m)_kernel (frame_linear)");
     if (mid) return launch_frm_any<FR_EPI_F32>(g, st);
@@ -1248,7 +1147,6 @@ int readout_frame_f16x3(const genie_cfg& c, const genie_weights& wt, Workspace& 
     g.M = B * c.S; g.N = V; g.K = d;
     g.Cf = logits; g.ldc = V; g.rows_per_batch = g.M; g.strideC = 0;
     ProfScope prof(GENIE_KC_GEMM, 2.0 * g.M * (double)V * d, 4.0 * g.M * d + 4.0 * V * d + 4.0 * g.M * V, st, "gemm16_fr(m)_kernel (readout)");
-    if (g.M >= frs_min_rows() && g.M % 64 == 0 && V % 256 == 0 && (d == 512 || d == 256 || d == 128)) return launch_frs<FR_EPI_F32>(g, st);
     if (g.M >= frm_min_rows() && g.M % 128 == 0 && V % 128 == 0) return launch_frm_any<FR_EPI_F32>(g, st);
     return launch_fr_w<2, 1, FR_EPI_F32, false>(d / 64, g, st);
 }

@@ -295,8 +295,7 @@ int genie_frames_pass(const genie_cfg* cfg, const genie_weights* w, const int64_
 int genie_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, void* stream);
 /* y (M, N) f32 = a . w^T + bias on the one-frame kernels, both operands split f16 in fragment order (genie_pack_frame_w16 packs
  * an (M, K) activation the same way as an (N, K) weight): the unit the parity tests and the micro-benchmark call.  mode 0 = the kernel
- * a frame pass of M rows would take, 1 = register-direct kernel (K <= 512), 2 = LDS-tiled kernel (M % 128 == 0, N % 64 == 0),
- * 3 = A-resident kernel (M % 64 == 0, N % 256 == 0, K in {128, 256, 512}).
+ * a frame pass of M rows would take, 1 = register-direct kernel (K <= 512), 2 = LDS-tiled kernel (M % 128 == 0, N % 64 == 0).
  * Reference counterpart: nn.Linear.forward (st_transformer.py:16-25, attention.py:27-29). */
 int genie_frame_linear(const uint16_t* a_fr, const uint16_t* w_fr, const float* bias, float* y, int M, int N, int K, int mode,
                        void* stream);

@@ -125,12 +125,12 @@ def test_merged_commit_schedule_equals_plain_kv_cache_schedule(steps):
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(256, 1536, 512, 1), (512, 512, 512, 1), (96, 192, 128, 1), (1024, 2048, 512, 1), (2048, 1536, 512, 2),
-                                        (1280, 512, 2048, 2), (4096, 512, 512, 2), (384, 128, 256, 2), (1024, 1536, 512, 3), (2112, 2048, 512, 3),
-                                        (4096, 1024, 512, 3), (192, 768, 256, 3), (64, 256, 128, 3)])
+                                        (1280, 512, 2048, 2), (4096, 512, 512, 2), (384, 128, 256, 2), (4096, 1536, 512, 2),
+                                        (4352, 1024, 256, 2)])
 def test_frame_linear_vs_f64(M, N, K, mode):
     """genie_frame_linear (nn.Linear on fragment-ordered split operands; st_transformer.py:16-25, attention.py:27-29) against the
     f64 product of the SAME split operands (hi + lo / 2048 of genie_pack_split_f16): the kernels' only error is the dropped lo.lo term
-    and f32 accumulation order.  mode 1 = register-direct kernel, 2 = LDS-tiled kernel, 3 = A-resident kernel; ragged chip fills, K = 128 .. 2048."""
+    and f32 accumulation order.  mode 1 = register-direct kernel, 2 = LDS-tiled kernel; ragged chip fills, K = 128 .. 2048."""
     _lib = pkg("_lib")
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream

@@ -36,8 +36,8 @@ for M in a.rows:
         res = {}
         res["row-major"] = timed(lambda i: _lib.check(lib.genie_linear_lowp(_lib.PREC_F16X3, x_rm.data_ptr(), W_rm[i].data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, 0, 0, st), "lin"))
         ref = y.clone()
-        for mode, tag in ((1, "fr"), (2, "frm"), (3, "frs")):
-            if (mode == 1 and K > 512) or (mode == 2 and M % 128) or (mode == 3 and (K > 512 or N % 256 or M % 64)):
+        for mode, tag in ((1, "fr"), (2, "frm")):
+            if (mode == 1 and K > 512) or (mode == 2 and M % 128):
                 continue
             rc = lib.genie_frame_linear(x_fr.data_ptr(), W_fr[0].data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, mode, st)
             if rc != 0:
