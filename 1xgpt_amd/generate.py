@@ -84,15 +84,21 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
         _lib.check(rc, "genie_frames_pass")
         return True
 
-    # the prompt fills slots 0..P-1 of the cache in ONE P-frame pass (genie_clean_pass with the cache's T-frame layout);
-    # geometries that pass does not cover fill them frame by frame
-    rc = lib.genie_clean_pass(cfg, w, ids[:, :P].contiguous().data_ptr(), B, P, T, cache.data_ptr(), nbytes, ws.data_ptr(),
-                              ws.numel(), st) if P > 1 else _lib.E_UNSUPPORTED
+    # the prompt fills slots 0..P-1 of the cache in ONE P-frame pass: on the fragment-order kernels where they cover the model
+    # (genie_frames_pass with nf = P), else genie_clean_pass with the cache's T-frame layout; geometries neither covers fill the
+    # slots frame by frame
+    rc = _lib.E_UNSUPPORTED
+    if P > 1:
+        rc = lib.genie_frames_pass(cfg, w, ids[:, :P].contiguous().data_ptr(), B, 0, P, cache.data_ptr(), nbytes, 0, ws.data_ptr(),
+                                   ws.numel(), st)
+        if rc == _lib.E_UNSUPPORTED:
+            rc = lib.genie_clean_pass(cfg, w, ids[:, :P].contiguous().data_ptr(), B, P, T, cache.data_ptr(), nbytes, ws.data_ptr(),
+                                      ws.numel(), st)
     if rc == _lib.E_UNSUPPORTED:
         for t in range(P):
             frame_pass(ids[:, t].contiguous(), t)
     else:
-        _lib.check(rc, "genie_clean_pass")
+        _lib.check(rc, "genie_frames_pass / genie_clean_pass (prompt)")
     logits = torch.empty(B, S, V, dtype=torch.float32, device=dev)
     samples = torch.empty(B, S, dtype=torch.int64, device=dev)
     conf = torch.empty(B, S, dtype=torch.float32, device=dev)

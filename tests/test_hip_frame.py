@@ -92,6 +92,32 @@ def test_frame_passes_equal_full_forward_frames(d, heads):
         assert (cache2.view(L, B, T, S, 3 * d)[:, :, 4:] == 0).all()
 
 
+def test_prompt_in_one_frames_pass_fills_the_cache_like_single_frame_passes():
+    """generate()'s prompt as ONE 8-frame genie_frames_pass (2,048 rows: the LDS-tiled kernels) leaves every layer's cache slots as 8
+    one-frame passes (register-direct kernels) do, up to f32 summation order; later slots stay untouched."""
+    cfg, m = _model(512, 8, layers=3)
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    c, w = m._weights()[:2]
+    B, P, T, S, d, L = 1, 8, cfg.T, cfg.S, cfg.d_model, cfg.num_layers
+    ids = dev(pkg("synthetic").make_clips(B, cfg, seed=55)).view(B, T, S)
+    ws = m._workspace(B)
+    nbytes = lib.genie_prefix_cache_bytes(c, B)
+    st = torch.cuda.current_stream().cuda_stream
+    ca = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    cb = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    _lib.check(lib.genie_frames_pass(c, w, ids[:, :P].contiguous().data_ptr(), B, 0, P, ca.data_ptr(), nbytes, 0, ws.data_ptr(), ws.numel(), st),
+               "genie_frames_pass")
+    for t in range(P):
+        _lib.check(lib.genie_frame_pass(c, w, ids[:, t].contiguous().data_ptr(), B, t, cb.data_ptr(), nbytes, 0, ws.data_ptr(), ws.numel(), st),
+                   "genie_frame_pass")
+    a = ca.view(L, B, T, S, 3 * d)
+    b = cb.view(L, B, T, S, 3 * d)
+    assert torch.isfinite(a).all()
+    assert (a[:, :, :P] - b[:, :, :P]).abs().max().item() < 3e-5 * max(1.0, b.abs().max().item())
+    assert (a[:, :, P:] == 0).all()
+
+
 def test_frames_pass_refuses_what_it_does_not_cover():
     _lib = pkg("_lib")
     lib = _lib.load()
