@@ -489,7 +489,7 @@ int genie_frames_pass(const genie_cfg* cfg, const genie_weights* wt, const int64
     c1.T = nf;  // every buffer of this pass is a dense (B, nf, S, *) tensor
     // the fragment-order kernels (kernels_frame.hip) take the pass when they cover every layer; several frames per pass exist
     // only there
-    bool fr = cfg->precision == GENIE_PREC_F16X3 && wt->out_frame_w16;
+    bool fr = cfg->precision == GENIE_PREC_F16X3 && wt->out_frame_w16 && cfg->T <= 16;   // (the decode attention kernel holds 16 cache slots)
     for (int i = 0; fr && i < c1.num_layers; ++i) fr = frame_path_takes(c1, wt->layers_host[i], (long)B * nf * cfg->S);
     if (nf > 1 && !fr) {
         set_error("frames_pass: %d frames per pass need the fragment-order kernels (f16x3, head_dim 64, LayerNorm blocks, frame_w16 "

@@ -108,8 +108,47 @@ struct FrGemmArgs {
     uint16_t* C16;               // EPI_RES (optional) / EPI_GELU: fragment-ordered operand copy of the output, N / 64 k-blocks
     uint16_t* qkvs;              // EPI_QKVS: attention operand planes
     float qscale;                // EPI_QKVS: softmax scale * log2(e), folded into Q
-    int H, S;                    // EPI_QKVS: heads (64 columns each), rows per sequence (256)
+    int H, S, Dh;                // EPI_QKVS: heads, rows per sequence (256), head_dim (64 or 32 columns per head)
 };
+
+// The spatial attention's operand planes (FR_EPI_QKVS), written from a finished 32 x 32 sub-tile of the qkv output that sits in LDS
+// (`tl`: its first element, row pitch `pitch` floats): rows = the 32 tokens of row block rb, columns col0 .. col0 + 31 of the 3 d wide
+// output = 32 features of ONE (q | k | v, head) slice (head_dim 64: half a head, head_dim 32: a whole one).  Per (sequence, head):
+//   Q, K: [block of 32 tokens][plane][step 0 .. Dh / 16) fragments, lane (r, h): token r, features 16 step + 8 h .. + 7  (Q scaled)
+//   V^T:  [key tile kt][feature tile dt < Dh / 32][step m][plane] fragments, lane (r, h): feature 32 dt + r of keys
+//         32 kt + 16 m + 4 h + {0..3, 8..11} -- the key order in which the S^T accumulators hold the probabilities
+// `sub` = 0, 1: the two fragments the sub-tile fills (Q / K: steps (col0 % Dh) / 16 + sub; V^T: m = sub); fl = lane of the fragment.
+__device__ __forceinline__ void qkvs_store(const FrGemmArgs& a, const float* tl, int pitch, int rb, int col0, int sub, int fl) {
+    const int r = fl & 31, h = fl >> 5;
+    const int d = a.H * a.Dh, KS = a.Dh >> 4;
+    const int which = col0 / d, head = (col0 % d) / a.Dh, o = col0 % a.Dh;
+    const int blocks = a.S / 32;
+    const long seq = rb / blocks;
+    const int blk = rb % blocks;
+    const size_t unit = (size_t)blocks * NPL * KS * FR;     // one of Q | K | V^T of a (sequence, head)
+    uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
+    float v[8];
+    uint16_t* dst;
+    int lo_off;
+    if (which < 2) {
+        const float sc = which == 0 ? a.qscale : 1.0f;
+        const float* src = tl + r * pitch + 16 * sub + 8 * h;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+        dst = base + ((size_t)blk * NPL * KS + (o >> 4) + sub) * FR + fl * 8;
+        lo_off = KS * FR;
+    } else {
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) v[s8] = tl[(16 * sub + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * pitch + r];
+        dst = base + ((size_t)(blk * (a.Dh >> 5) + (o >> 5)) * 2 + sub) * NPL * FR + fl * 8;
+        lo_off = FR;
+    }
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + lo_off) = lo;
+}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // C = epilogue(alpha * A . W^T + bias): workgroup = (32 MI) rows x (32 NJ) columns, NW waves split K (wave w: 64-k blocks w, w + NW, ..),
@@ -344,44 +383,11 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
             *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
         }
     } else if constexpr (EPI == FR_EPI_QKVS) {
-        // ---- the spatial attention's operand planes.  A 64-column tile is one (q | k | v, head) slice; per (sequence, head):
-        //   Q, K: [block of 32 tokens][plane][step] fragments, lane (r, h): token r, features 16 step + 8 h .. + 7  (Q scaled)
-        //   V^T:  [key tile kt][feature tile dt][step m][plane] fragments, lane (r, h): feature 32 dt + r of keys
-        //         32 kt + 16 m + 4 h + {0..3, 8..11} -- the key order in which the S^T accumulators hold the probabilities
-        static_assert(EPI != FR_EPI_QKVS || TN == 64, "attention operand planes: one head slice (64 columns) per tile");
-        const int dH = a.H * 64;
-        const int which = n0 / dH, head = (n0 % dH) / 64;
-        const int blocks = a.S / 32;                           // 32-token blocks per sequence
-        const size_t unit = (size_t)blocks * NPL * 4 * FR;     // one of Q | K | V^T of a (sequence, head)
-        const float sc = which == 0 ? a.qscale : 1.0f;
+        // ---- the spatial attention's operand planes (qkvs_store): item = (row block, 32-column half of the tile, fragment, lane)
+        static_assert(EPI != FR_EPI_QKVS || TN == 64, "attention operand planes: 64-column tiles");
         for (int idx = tid; idx < MI * 256; idx += NT) {
-            const int i = idx >> 8, sub = (idx >> 6) & 3, fl = idx & 63, r = fl & 31, h = fl >> 5;
-            const int rb = rb0 + i;
-            const long seq = rb / blocks;
-            const int blk = rb % blocks;
-            uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
-            const float* tile = red + (size_t)32 * i * PITCH;
-            float v[8];
-            uint16_t* dst;
-            int lo_off;
-            if (which < 2) {       // sub = step
-                const float* src = tile + r * PITCH + 16 * sub + 8 * h;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                dst = base + ((size_t)blk * NPL * 4 + sub) * FR + fl * 8;
-                lo_off = 4 * FR;
-            } else {               // sub = 2 dt + m
-                const int dt = sub >> 1, m = sub & 1;
-#pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) v[s8] = tile[(16 * m + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + 32 * dt + r];
-                dst = base + ((size_t)(blk * 2 + dt) * 2 + m) * NPL * FR + fl * 8;
-                lo_off = FR;
-            }
-            u32x4 hi, lo;
-            split8(v, hi, lo);
-            *reinterpret_cast<u32x4*>(dst) = hi;
-            *reinterpret_cast<u32x4*>(dst + lo_off) = lo;
+            const int i = idx >> 8, j = (idx >> 7) & 1, sub = (idx >> 6) & 1, fl = idx & 63;
+            qkvs_store(a, red + (size_t)32 * i * PITCH + 32 * j, PITCH, rb0 + i, n0 + 32 * j, sub, fl);
         }
     }
 }
@@ -450,48 +456,14 @@ __device__ __forceinline__ void frm_epilogue(const FrGemmArgs& a, const f32x16 (
                 *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
             }
     } else if constexpr (EPI == FR_EPI_QKVS) {
-        // (every 32-column tile j of the wave is half a head slice: steps 2 c .. 2 c + 1 of Q / K, feature tile dt = c of V^T,
-        // c = (column % 64) / 32)
-        const int dH = a.H * 64;
-        const int blocks = a.S / 32;
-        const size_t unit = (size_t)blocks * NPL * 4 * FR;
+        // (qkvs_store: every 32 x 32 sub-tile of the wave's tile fills two fragments of its (q | k | v, head) slice)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int nj = n0 + 32 * j;
-            const int which = nj / dH, head = (nj % dH) / 64, half = (nj & 63) >> 5;
-            const float sc = which == 0 ? a.qscale : 1.0f;
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int rb = rb0 + i;
-                const long seq = rb / blocks;
-                const int blk = rb % blocks;
-                uint16_t* base = a.qkvs + ((size_t)(seq * a.H + head) * 3 + which) * unit;
-                const float* tl = tile + (size_t)32 * i * PITCH + 32 * j;
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    float v[8];
-                    uint16_t* dst;
-                    int lo_off;
-                    if (which < 2) {       // step 2 half + sub
-                        const float* src = tl + r * PITCH + 16 * sub + 8 * h;
-                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc, v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                        dst = base + ((size_t)blk * NPL * 4 + 2 * half + sub) * FR + fl * 8;
-                        lo_off = 4 * FR;
-                    } else {               // dt = half, m = sub
-#pragma unroll
-                        for (int s8 = 0; s8 < 8; ++s8) v[s8] = tl[(16 * sub + 4 * h + (s8 & 3) + 8 * (s8 >> 2)) * PITCH + r];
-                        dst = base + ((size_t)(blk * 2 + half) * 2 + sub) * NPL * FR + fl * 8;
-                        lo_off = FR;
-                    }
-                    u32x4 hi, lo;
-                    split8(v, hi, lo);
-                    *reinterpret_cast<u32x4*>(dst) = hi;
-                    *reinterpret_cast<u32x4*>(dst + lo_off) = lo;
-                }
-            }
-        }
+                for (int sub = 0; sub < 2; ++sub)
+                    qkvs_store(a, tile + (size_t)32 * i * PITCH + 32 * j, PITCH, rb0 + i, n0 + 32 * j, sub, fl);
     }
 }
 
@@ -681,15 +653,16 @@ __global__ __launch_bounds__(NW * 64) void ln_fr_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Spatial attention of a frame pass (attention.py:36-61 over the S = 256 positions of one frame, head_dim 64): workgroup =
-// (sequence, head, block of 32 queries), wave kt = the 32-key tile kt.  All 24 operand fragments of a wave (Q block, K tile,
-// V^T tile; hi and lo' planes) are requested at once, nothing is converted or transposed here (the qkv Linear's epilogue did
-// that, FR_EPI_QKVS).  S^T = K Q^T so a lane holds 16 scores of ITS query; exp2 softmax per tile; the eight partial
+// Spatial attention of a frame pass (attention.py:36-61 over the S = 256 positions of one frame, head_dim DH = 64 or 32): workgroup =
+// (sequence, head, block of 32 queries), wave kt = the 32-key tile kt.  All operand fragments of a wave (Q block, K tile, V^T tile;
+// hi and lo' planes: 24 at DH 64) are requested at once, nothing is converted or transposed here (the qkv Linear's epilogue did
+// that, qkvs_store).  S^T = K Q^T so a lane holds 16 scores of ITS query; exp2 softmax per tile; the eight partial
 // (max, sum, O) triples merge through LDS in wave order; O leaves in the fragment order of the out-projection's A operand.
 // ------------------------------------------------------------------------------------------------------------------------------
+template <int DH>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_spatial_fr_kernel(const uint16_t* __restrict__ qkvs, uint16_t* __restrict__ out16,
                                                                   int H) {
-    constexpr int DH = 64, PITCH = DH + 4, BLK = 8;
+    constexpr int KS = DH / 16, DT = DH / 32, PITCH = DH + 4, BLK = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* part = reinterpret_cast<float*>(smem);                               // [8 waves][32 queries][PITCH]
     float* stat = part + 8 * 32 * PITCH;                                        // [8 waves][32 queries][2]
@@ -698,22 +671,22 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int r = lane & 31, h = lane >> 5;
     const long seq = blockIdx.x;
     const int head = blockIdx.y, qb = blockIdx.z;
-    const size_t unit = (size_t)BLK * NPL * 4 * FR;
+    const size_t unit = (size_t)BLK * NPL * KS * FR;
     const uint16_t* base = qkvs + (size_t)(seq * H + head) * 3 * unit + lane * 8;
-    u32x4 qf[NPL][4], kf[NPL][4], vf[2][2][NPL];
+    u32x4 qf[NPL][KS], kf[NPL][KS], vf[DT][2][NPL];
     {
-        const uint16_t* qp = base + (size_t)qb * NPL * 4 * FR;
-        const uint16_t* kp = base + unit + (size_t)kt * NPL * 4 * FR;
-        const uint16_t* vp = base + 2 * unit + (size_t)kt * 8 * FR;
+        const uint16_t* qp = base + (size_t)qb * NPL * KS * FR;
+        const uint16_t* kp = base + unit + (size_t)kt * NPL * KS * FR;
+        const uint16_t* vp = base + 2 * unit + (size_t)kt * DT * 2 * NPL * FR;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                kf[p][s] = *reinterpret_cast<const u32x4*>(kp + (p * 4 + s) * FR);
-                qf[p][s] = *reinterpret_cast<const u32x4*>(qp + (p * 4 + s) * FR);
+            for (int s = 0; s < KS; ++s) {
+                kf[p][s] = *reinterpret_cast<const u32x4*>(kp + (p * KS + s) * FR);
+                qf[p][s] = *reinterpret_cast<const u32x4*>(qp + (p * KS + s) * FR);
             }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -724,7 +697,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int e = 0; e < 16; ++e) { a0[e] = 0.f; c0[e] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
         a0 = mma16(kf[0][s], qf[0][s], a0);
         c0 = mma16(kf[0][s], qf[1][s], c0);
         c0 = mma16(kf[1][s], qf[0][s], c0);
@@ -739,9 +712,9 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(p[e] - mw); lw += p[e]; }
     lw += __shfl_xor(lw, 32);
     if (h == 0) { stat[(kt * 32 + r) * 2] = mw; stat[(kt * 32 + r) * 2 + 1] = lw; }
-    f32x16 oa[2], oc[2];
+    f32x16 oa[DT], oc[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { oa[dt][e] = 0.f; oc[dt][e] = 0.f; }
 #pragma unroll
@@ -749,7 +722,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         u32x4 ph, pl;
         split8(p + 8 * m, ph, pl);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             oa[dt] = mma16(ph, vf[dt][m][0], oa[dt]);
             oc[dt] = mma16(ph, vf[dt][m][1], oc[dt]);
             oc[dt] = mma16(pl, vf[dt][m][0], oc[dt]);
@@ -757,13 +730,13 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     float* op = part + (size_t)kt * 32 * PITCH;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             op[((e & 3) + 8 * (e >> 2) + 4 * h) * PITCH + dt * 32 + r] = oa[dt][e] + oc[dt][e] * (1.0f / 2048.0f);
     __syncthreads();
     // ---- merge like an online softmax, waves in order; thread -> (step, lane of the output fragment): 8 features of one query
-    if (tid < 256) {
+    if (tid < KS * 64) {
         const int sl = tid >> 6, fl = tid & 63, q = fl & 31, hh = fl >> 5;
         float mg = -INFINITY;
 #pragma unroll
@@ -786,7 +759,9 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int e = 0; e < 8; ++e) o[e] *= invl;
         u32x4 hi, lo;
         split8(o, hi, lo);
-        uint16_t* dst = out16 + fr_frag(seq * BLK + qb, head, H, 0, sl) + fl * 8;
+        // the head's features are columns head * DH .. of the out-projection's A operand (K = H * DH, 64-k blocks)
+        const int col = head * DH + 16 * sl;
+        uint16_t* dst = out16 + fr_frag(seq * BLK + qb, col >> 6, (H * DH) >> 6, 0, (col & 63) >> 4) + fl * 8;
         *reinterpret_cast<u32x4*>(dst) = hi;
         *reinterpret_cast<u32x4*>(dst + 4 * FR) = lo;
     }
@@ -795,13 +770,15 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Temporal decode attention of a frame pass (attention.py:36-61 with the causal mask, one query frame per row): one wave per
 // (clip, frame of the pass, position, head).  The query frame t = t0 + f attends cache slots 0..t of its position; the cache
-// is the (B, T, S, 3 d) f32 qkv of the earlier passes, slot t written by this pass's qkv Linear.  Whole 256-byte head slices per
-// request: instruction i fetches frames 4 i .. 4 i + 3 (lane = (frame 4 i + lane / 16, features 4 (lane % 16) .. + 3)), so K and
-// V are four loads each; scores are 4-feature partial dot products reduced over 16 lanes, the softmax runs over the four
-// register copies and the four lane groups, P.V reduces over the groups.  head_dim 64, T <= 16, no qk-norm.
+// is the (B, T, S, 3 d) f32 qkv of the earlier passes, slot t written by this pass's qkv Linear.  Whole head slices per request
+// (DH floats = LPF = DH / 4 lanes x 16 bytes): an instruction fetches FPI = 64 / LPF frames (lane = (frame, 4 features)), so K and
+// V are 16 / FPI loads each; scores are 4-feature partial dot products reduced over the LPF lanes of a frame, the softmax runs over
+// the register copies and the lane groups, P.V reduces over the groups.  head_dim 64 / 32, T <= 16, no qk-norm.
 // ------------------------------------------------------------------------------------------------------------------------------
+template <int DH>
 __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __restrict__ cache, uint16_t* __restrict__ out16,
                                                                long n_items, int T, int S, int t0, int nf, int d, int H, float scale) {
+    constexpr int LPF = DH / 4, FPI = 64 / LPF, NI = 16 / FPI;     // lanes per frame, frames per instruction, instructions
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_items) return;
@@ -811,48 +788,55 @@ __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __re
     const int s = (int)(row - bf * S);
     const long b = bf / nf;
     const int f = (int)(bf - b * nf), t = t0 + f;
-    const int g = lane >> 4, c = lane & 15;
+    const int g = lane / LPF, c = lane % LPF;
     const size_t tok = (size_t)S * 3 * d;
-    const float* hb = cache + ((size_t)(b * T) * S + s) * 3 * d + head * 64 + 4 * c;
+    const float* hb = cache + ((size_t)(b * T) * S + s) * 3 * d + head * DH + 4 * c;
     const f32x4 qv = *reinterpret_cast<const f32x4*>(hb + (size_t)t * tok);
-    f32x4 kv[4], vv[4];
+    f32x4 kv[NI], vv[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = 4 * i + g;
+    for (int i = 0; i < NI; ++i) {
+        const int j = FPI * i + g;
         const float* src = hb + (size_t)(j <= t ? j : t) * tok;    // (frames past t re-read frame t: their probability is 0)
         kv[i] = *reinterpret_cast<const f32x4*>(src + d);
         vv[i] = *reinterpret_cast<const f32x4*>(src + 2 * d);
     }
     FR_PIN_LOADS();
-    float sc[4];
+    float sc[NI];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float part = row16_sum(fmaf(qv[3], kv[i][3], fmaf(qv[2], kv[i][2], fmaf(qv[1], kv[i][1], qv[0] * kv[i][0]))));
-        sc[i] = (4 * i + g <= t) ? part * scale : -INFINITY;
+    for (int i = 0; i < NI; ++i) {
+        float part = fmaf(qv[3], kv[i][3], fmaf(qv[2], kv[i][2], fmaf(qv[1], kv[i][1], qv[0] * kv[i][0])));
+        if constexpr (LPF == 16) part = row16_sum(part);
+        else {
+#pragma unroll
+            for (int o = 1; o < LPF; o <<= 1) part += __shfl_xor(part, o);
+        }
+        sc[i] = (FPI * i + g <= t) ? part * scale : -INFINITY;
         mx = fmaxf(mx, sc[i]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+    for (int o = LPF; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sc[i] = (4 * i + g <= t) ? expf(sc[i] - mx) : 0.f; sum += sc[i]; }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    for (int i = 0; i < NI; ++i) { sc[i] = (FPI * i + g <= t) ? expf(sc[i] - mx) : 0.f; sum += sc[i]; }
+#pragma unroll
+    for (int o = LPF; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
     const float inv = 1.0f / sum;
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o += vv[i] * (sc[i] * inv);
+    for (int i = 0; i < NI; ++i) o += vv[i] * (sc[i] * inv);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        o[e] += __shfl_xor(o[e], 16);
-        o[e] += __shfl_xor(o[e], 32);
+#pragma unroll
+        for (int x = LPF; x < 64; x <<= 1) o[e] += __shfl_xor(o[e], x);
     }
     if (g != 0) return;
-    // lane c: features 4 c .. 4 c + 3 -> half (c >> 1) & 1 of step c >> 2, elements 4 (c & 1) .. + 3 of the lane's 16-byte piece
+    // lane c: features 4 c .. 4 c + 3 of the head = columns col .. col + 3 of the out-projection's A operand: 64-k block col / 64,
+    // step (col % 64) / 16, half (col % 16) / 8, elements col % 8 .. + 3 of the lane's 16-byte piece
     uint32_t h01, h23, l01, l23;
     split_f16_x4(o[0], o[1], o[2], o[3], h01, h23, l01, l23);
-    uint16_t* dst = out16 + fr_frag(row >> 5, head, H, 0, c >> 2) + (32 * ((c >> 1) & 1) + (int)(row & 31)) * 8 + 4 * (c & 1);
+    const int col = head * DH + 4 * c;
+    uint16_t* dst = out16 + fr_frag(row >> 5, col >> 6, (H * DH) >> 6, 0, (col & 63) >> 4) + (32 * ((col >> 3) & 1) + (int)(row & 31)) * 8 + (col & 7);
     *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
     *reinterpret_cast<u32x2*>(dst + 4 * FR) = u32x2{l01, l23};
 }
@@ -982,7 +966,8 @@ int launch_ln_fr(const float* x, long ldx, const float* g, const float* b, float
 
 bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows) {
     static const int on = study_env("GENIE_FRAME_KERNELS", 1);
-    return on && c.precision == GENIE_PREC_F16X3 && !c.qk_norm && c.S == 256 && c.head_dim == 64 && c.d_model == c.num_heads * 64 &&
+    return on && c.precision == GENIE_PREC_F16X3 && !c.qk_norm && c.S == 256 && (c.head_dim == 64 || c.head_dim == 32) &&
+           c.d_model == c.num_heads * c.head_dim &&
            (c.d_model == 512 || c.d_model == 256 || c.d_model == 128) && c.hidden == 4 * c.d_model && rows % 256 == 0 && rows <= 16384 &&
            lw.spatial.frame_w16 && lw.temporal.frame_w16 && lw.mlp_frame_w16 && lw.norm1_w && lw.norm2_w;
 }
@@ -1023,7 +1008,7 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     {
         FrGemmArgs g = a;
         g.W = wq_s; g.bias = c.qkv_bias ? lw.spatial.qkv_b : nullptr; g.N = 3 * d; g.K = d;
-        g.qkvs = big; g.qscale = c.attn_scale * 1.4426950408889634f; g.H = H; g.S = S;
+        g.qkvs = big; g.qscale = c.attn_scale * 1.4426950408889634f; g.H = H; g.S = S; g.Dh = c.head_dim;
         if (mid) {
             {
                 ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * M * d, 8.0 * M * d, st, "ln_fr_kernel");
@@ -1041,15 +1026,18 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         }
     }
     {
-        ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * 64 * H * (double)(B * nf), (double)B * nf * S * d * 16.0, st,
+        ProfScope prof(GENIE_KC_ATTN_SPATIAL, 4.0 * S * S * c.head_dim * H * (double)(B * nf), (double)B * nf * S * d * 16.0, st,
                        "attn_spatial_fr_kernel");
-        const size_t lds = (size_t)8 * 32 * 68 * 4 + 8 * 32 * 2 * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_spatial_fr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
+        const dim3 grid((unsigned)(B * nf), H, 8);
+        if (c.head_dim == 64) {
+            const size_t lds = (size_t)8 * 32 * 68 * 4 + 8 * 32 * 2 * 4;
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_spatial_fr_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            attn_spatial_fr_kernel<64><<<grid, 512, lds, st>>>(big, as, H);
+        } else {
+            const size_t lds = (size_t)8 * 32 * 36 * 4 + 8 * 32 * 2 * 4;
+            attn_spatial_fr_kernel<32><<<grid, 512, lds, st>>>(big, as, H);
         }
-        attn_spatial_fr_kernel<<<dim3((unsigned)(B * nf), H, 8), 512, lds, st>>>(big, as, H);
         GENIE_LAUNCH_CHECK("attn_spatial_fr");
     }
     {
@@ -1074,9 +1062,12 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     }
     {
         const long n = (long)M * H;
-        ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * (w.frame_t + nf) * 64 * (double)n, (double)n * 64 * 4.0 * (2 * (w.frame_t + nf) + 2), st,
+        ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * (w.frame_t + nf) * c.head_dim * (double)n, (double)n * c.head_dim * 4.0 * (2 * (w.frame_t + nf) + 2), st,
                        "attn_temporal_fr_kernel");
-        attn_temporal_fr_kernel<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale);
+        if (c.head_dim == 64)
+            attn_temporal_fr_kernel<64><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale);
+        else
+            attn_temporal_fr_kernel<32><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale);
         GENIE_LAUNCH_CHECK("attn_temporal_fr");
     }
     {

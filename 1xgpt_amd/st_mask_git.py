@@ -108,10 +108,10 @@ class _Packer:
         return t.data_ptr()
 
     def _frame_geometry(self):
-        # the fragment-order kernels of the one-frame passes (csrc/kernels_frame.hip): f16x3, LayerNorm blocks, heads of 64
+        # the fragment-order kernels of the one-frame passes (csrc/kernels_frame.hip): f16x3, LayerNorm blocks, heads of 64 or 32
         c = self.config
         return (self.prec == _lib.PREC_F16X3 and not c.qk_norm and c.S == 256 and c.d_model in (128, 256, 512)
-                and c.d_model == 64 * c.num_heads and os.environ.get("GENIE_NO_FRAME_KERNELS", "0") != "1")
+                and c.d_model in (64 * c.num_heads, 32 * c.num_heads) and os.environ.get("GENIE_NO_FRAME_KERNELS", "0") != "1")
 
     def frame_stream(self, *weights):
         """The given Linear weights back to back as split f16 in fragment order (genie_pack_frame_w16), or 0."""

@@ -80,7 +80,7 @@ typedef struct genie_attn_weights {
     /* GENIE_PREC_F16X3 range flags of the packed tensors (bit 0: qkv_w16, bit 1: proj_w16): set when the tensor's hi plane
      * reaches |w| >= 32, see "range contract" below.  0 in the other precisions. */
     int32_t w16_wide;
-    /* GENIE_PREC_F16X3, head_dim 64 (ABI 3), or NULL (the one-frame passes then run the row-major kernels): [qkv | proj] as split
+    /* GENIE_PREC_F16X3, head_dim 64 or 32 (ABI 3), or NULL (the one-frame passes then run the row-major kernels): [qkv | proj] as split
      * f16 in FRAGMENT ORDER for the one-frame passes of generate (genie_pack_frame_w16, genie_frames_pass). */
     const uint16_t* frame_w16;
 } genie_attn_weights;
@@ -283,7 +283,7 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t
  * of the LAST frame of the pass (NULL = not wanted).  generate()'s use: the pass that commits the final tokens of frame t also
  * carries the first MaskGIT step of frame t + 1 (all-mask tokens), so a new frame costs `steps` passes instead of `steps + 1`
  * (generate.py:81-95: the reference recomputes everything per step).  nf == 1 is genie_frame_pass; nf > 1 returns
- * GENIE_E_UNSUPPORTED (nothing enqueued) unless the fragment-order kernels cover the model (GENIE_PREC_F16X3, head_dim 64,
+ * GENIE_E_UNSUPPORTED (nothing enqueued) unless the fragment-order kernels cover the model (GENIE_PREC_F16X3, head_dim 64 or 32,
  * LayerNorm blocks, S 256, frame_w16 streams present, B * nf <= 4): the caller then runs the frames one by one. */
 int genie_frames_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* frame_ids, int B, int t0, int nf, float* cache,
                       size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream);

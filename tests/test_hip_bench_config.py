@@ -144,3 +144,36 @@ def test_bench_config_bf16_schedules_agree(golden, name, B):
     assert abs(ce0 - float(z["ev_loss"])) < 5e-2, (ce0, float(z["ev_loss"]))
     # clip 0 and clip B-1 are the same clip with the same draws: identical results whatever sits between them
     assert abs(eu.compute_loss(d_ids[-1:], fl_reuse[-1:].contiguous()) - ce0) < 2e-3
+
+
+def test_fused_subblocks_effect_on_sampled_ids_at_depth(golden, monkeypatch):
+    """The fused sub-block kernels of the shipped config (csrc/kernels_fused.hip) against the launches they replace, THROUGH ALL 32
+    LAYERS and the MaskGIT sampling (st_transformer.py:70-83 x 32, st_mask_git.py:154-229): 12 clips of the reference's full-forward
+    schedule (the schedule in which all three sub-blocks run fused), same clips and draws, fused vs GENIE_NO_FUSED.  bf16 is not a parity
+    mode: what is held is that fusing changes the sampled ids no more than bf16's own noise does -- the two runs agree with each other at
+    least as well as either agrees with the f32 reference run of clip 0 -- and that CE moves by less than 1e-3."""
+    z, cfg, sd = golden("ev_c35")
+    B = 12
+    ids, noise = batch_with_golden(z, cfg, B, seed=9400)
+    eu = pkg("eval_utils")
+    d_ids, d_noise = dev(ids), dev(noise)
+    out = {}
+    for tag, env in (("fused", "0"), ("unfused", "1")):
+        monkeypatch.setenv("GENIE_NO_FUSED", env)
+        ev = make_ev(cfg, sd, "bf16")
+        ev.model._weights()
+        uses = any(l.temporal.fused_w16 or l.mlp_fused_w16 for l in ev.model._weights()[2])
+        assert uses == (tag == "fused")
+        s, fl = ev.predict_zframe_logits(d_ids, noise=d_noise)
+        out[tag] = (s.cpu().numpy(), eu.compute_loss(d_ids, fl.contiguous()), eu.compute_loss(d_ids[:1], fl[:1].contiguous()))
+        del ev
+        torch.cuda.empty_cache()
+    (sf, cef, cef0), (su, ceu, ceu0) = out["fused"], out["unfused"]
+    agree = float((sf == su).mean())
+    ref = z["ev_samples"][0].astype(np.int64)
+    agree_f_ref, agree_u_ref = float((sf[0] == ref).mean()), float((su[0] == ref).mean())
+    print(f"ids: fused vs unfused {agree:.4f}; clip 0 vs the f32 reference: fused {agree_f_ref:.4f}, unfused {agree_u_ref:.4f}; "
+          f"CE fused {cef:.6f} unfused {ceu:.6f} (clip 0: {cef0:.6f} / {ceu0:.6f} / reference {float(z['ev_loss']):.6f})")
+    assert agree > 0.95 and agree >= min(agree_f_ref, agree_u_ref) - 0.01
+    assert abs(agree_f_ref - agree_u_ref) < 0.02          # fusing neither helps nor hurts the agreement with the reference
+    assert abs(cef - ceu) < 1e-3 and abs(cef0 - float(z["ev_loss"])) < 5e-2

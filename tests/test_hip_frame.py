@@ -15,10 +15,14 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
 
 
-def _model(d, heads, layers=2, precision="f16x3", seed=11):
+def _model(d, heads, layers=2, precision="f16x3", seed=11, **kw):
     cfg = pkg("config").GenieConfig(num_layers=layers, num_heads=heads, d_model=d, T=16, S=256, num_factored_vocabs=2,
-                                    qk_norm=False, use_mup=False)
+                                    qk_norm=False, use_mup=False, **kw)
     sd = pkg("synthetic").make_state_dict(cfg, seed=seed, law="conditioned")
+    g = np.random.default_rng(seed + 1)
+    for k in sd:       # the synthetic law leaves biases at zero: make every bias the kernels add count
+        if k.endswith(".bias") and "norm" not in k:
+            sd[k] = (0.05 * g.standard_normal(sd[k].shape)).astype(np.float32)
     return cfg, pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
 
 
@@ -42,19 +46,23 @@ def test_pack_frame_w16_is_the_row_major_split_in_fragment_order():
     assert lib.genie_pack_frame_w16(W.data_ptr(), fr.data_ptr(), 48, 64, st) == _lib.E_SHAPE
 
 
-@pytest.mark.parametrize("d,heads", [(512, 8), (256, 4), (128, 2)])
-def test_frame_passes_equal_full_forward_frames(d, heads):
+@pytest.mark.parametrize("d,heads,kw", [(512, 8, {}), (256, 4, {}), (128, 2, {}), (256, 4, dict(qkv_bias=True)),
+                                        (128, 2, dict(qkv_bias=True, proj_bias=False, mlp_bias=False)),
+                                        (256, 8, {}),                       # the shipped geometry magvit_n32_h8_d256: heads of 32
+                                        (512, 16, dict(qkv_bias=True)), (128, 4, {})])
+def test_frame_passes_equal_full_forward_frames(d, heads, kw):
     """genie_frame_pass / genie_frames_pass on the fragment-order kernels against the full 16-frame forward of the same model
     (256x256-tile GEMMs, LDS-DMA attention kernels: validated against the oracle and the reference goldens elsewhere): logits of
-    every decoded frame within f32 accumulation-order noise; one frame per pass, two frames per pass, 1 / 2 / 5 clips."""
-    cfg, m = _model(d, heads)
+    every decoded frame within f32 accumulation-order noise; one frame per pass, two frames per pass, 1 / 2 / 3 / 5 clips; with and
+    without the Linear biases."""
+    cfg, m = _model(d, heads, **kw)
     _lib = pkg("_lib")
     lib = _lib.load()
     c, w = m._weights()[:2]
     assert w.out_frame_w16 and w.layers_host[0].spatial.frame_w16 and w.layers_host[0].mlp_frame_w16   # the new path is the one that runs
     T, S = cfg.T, cfg.S
     V = cfg.factored_vocab_size * cfg.num_factored_vocabs
-    for B in (1, 2, 5):    # 256 .. 2,560 rows per pass: the register-direct kernels below 2,048 rows, the LDS-tiled ones from there
+    for B in (1, 2, 3, 5):    # 256 .. 2,560 rows per pass: the register-direct kernels below 2,048 rows, the LDS-tiled ones from there
         ids = dev(pkg("synthetic").make_clips(B, cfg, seed=70 + B)).view(B, T, S)
         ids[:, 3, ::3] = cfg.image_vocab_size       # some mask tokens
         full = m.compute_logits(ids.view(B, T, 16, 16))          # (B, V, T, 16, 16)
@@ -135,11 +143,12 @@ def test_frames_pass_refuses_what_it_does_not_cover():
     assert lib.genie_frames_pass(c, w, ids.data_ptr(), B, 15, 2, cache.data_ptr(), nbytes, 0, ws.data_ptr(), ws.numel(), st) == _lib.E_ARG
 
 
+@pytest.mark.parametrize("heads", [4, 8])
 @pytest.mark.parametrize("steps", [2, 3])
-def test_merged_commit_schedule_equals_plain_kv_cache_schedule(steps):
+def test_merged_commit_schedule_equals_plain_kv_cache_schedule(steps, heads):
     """generate_frames_cached with the commit pass of frame t carrying step 0 of frame t + 1 (genie_frames_pass, 2 frames) produces
     the frames of the schedule that runs them as two passes -- same per-row arithmetic, so exactly the same ids."""
-    cfg, m = _model(256, 4, layers=3)
+    cfg, m = _model(256, heads, layers=3)
     G = pkg("generate")
     for B in (1, 2):
         ex = dev(pkg("synthetic").make_clips(B, cfg, seed=40 + B)).view(B, 16, 16, 16)

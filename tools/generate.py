@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--precision", choices=["exact", "f16x3", "bf16"], default="f16x3")
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--model", choices=["c138", "c35"], default="c35")
+    ap.add_argument("--schedule", choices=["kv_cache", "full_forward"], default="kv_cache",
+                    help="kv_cache: one-frame passes against a temporal KV cache (same frames up to f32 accumulation order); "
+                         "full_forward: the reference's schedule, a full 16-frame forward per MaskGIT step (generate.py:81-95)")
     args = ap.parse_args()
     G = importlib.import_module("1xgpt_amd.generate")
     STMaskGIT = importlib.import_module("1xgpt_amd.st_mask_git").STMaskGIT
@@ -46,8 +49,8 @@ def main():
         meta = ds.metadata
     model = model.to("cuda")
     ex = example.to("cuda").view(1, args.window_size, model.h, model.w)
-    out = G.generate_frames(model, ex, args.num_prompt_frames, args.maskgit_steps, args.temperature,
-                            args.teacher_force_time)
+    fn = G.generate_frames_cached if args.schedule == "kv_cache" else G.generate_frames
+    out = fn(model, ex, args.num_prompt_frames, args.maskgit_steps, args.temperature, args.teacher_force_time)
     print(G.write_outputs(out, args.output_dir, meta, vars(args)))
 
 
