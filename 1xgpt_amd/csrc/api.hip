@@ -492,8 +492,8 @@ int genie_frames_pass(const genie_cfg* cfg, const genie_weights* wt, const int64
     bool fr = cfg->precision == GENIE_PREC_F16X3 && wt->out_frame_w16 && cfg->T <= 16;   // (the decode attention kernel holds 16 cache slots)
     for (int i = 0; fr && i < c1.num_layers; ++i) fr = frame_path_takes(c1, wt->layers_host[i], (long)B * nf * cfg->S);
     if (nf > 1 && !fr) {
-        set_error("frames_pass: %d frames per pass need the fragment-order kernels (f16x3, head_dim 64, LayerNorm blocks, frame_w16 "
-                  "streams, B * nf <= 4)", nf);
+        set_error("frames_pass: %d frames per pass need the fragment-order kernels (f16x3, head_dim 64 or 32, LayerNorm blocks, frame_w16 "
+                  "streams, B * nf * S <= 16,384 rows)", nf);
         return GENIE_E_UNSUPPORTED;
     }
     Workspace w = carve(c1, B, workspace);

@@ -49,7 +49,7 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
     against the cached temporal keys/values of the earlier frames instead of the full 16-frame forward --
     one P-frame pass for the prompt + (T-P)*(steps+1) single-frame passes (= 2 full-pass equivalents at P=8, steps=2) instead of (T-P)*steps full
     forwards (16).  Same outputs (per-row arithmetic is unchanged).
-    merge_commit: where the library covers it (genie_frames_pass: f16x3, heads of 64, <= 2 clips) the pass that commits frame t's
+    merge_commit: where the library covers it (genie_frames_pass: f16x3, heads of 64 or 32, up to 16,384 rows per pass) the pass that commits frame t's
     final tokens also carries MaskGIT step 0 of frame t+1, so a frame costs `steps` passes instead of `steps + 1`."""
     import math
     from . import _lib

@@ -284,7 +284,7 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t
  * carries the first MaskGIT step of frame t + 1 (all-mask tokens), so a new frame costs `steps` passes instead of `steps + 1`
  * (generate.py:81-95: the reference recomputes everything per step).  nf == 1 is genie_frame_pass; nf > 1 returns
  * GENIE_E_UNSUPPORTED (nothing enqueued) unless the fragment-order kernels cover the model (GENIE_PREC_F16X3, head_dim 64 or 32,
- * LayerNorm blocks, S 256, frame_w16 streams present, B * nf <= 4): the caller then runs the frames one by one. */
+ * LayerNorm blocks, S 256, frame_w16 streams present, B * nf * S <= 16,384 rows): the caller then runs the frames one by one. */
 int genie_frames_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* frame_ids, int B, int t0, int nf, float* cache,
                       size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 /* f32 (N, K) row-major weight -> split f16 in FRAGMENT ORDER (2 N K 16-bit values) for the one-frame kernels
