@@ -532,6 +532,107 @@ int genie_frame_linear(const uint16_t* a_fr, const uint16_t* w_fr, const float* 
     return launch_frame_linear(a_fr, w_fr, bias, y, M, N, K, mode, as_stream(stream));
 }
 
+// rows of S token ids: dst[b][0..S) = src[b][0..S) (clip strides in elements) or, src == NULL, the fill value
+__global__ void frame_ids_kernel(const int64_t* __restrict__ src, long src_stride, int64_t* __restrict__ dst, long dst_stride, int S, int B,
+                                 int64_t fill) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * S) return;
+    const long b = i / S, s = i - b * S;
+    dst[b * dst_stride + s] = src ? src[b * src_stride + s] : fill;
+}
+static int put_frame_ids(const int64_t* src, long src_stride, int64_t* dst, long dst_stride, int S, int B, int64_t fill, hipStream_t st) {
+    frame_ids_kernel<<<(unsigned)(((long)B * S + 255) / 256), 256, 0, st>>>(src, src_stride, dst, dst_stride, S, B, fill);
+    GENIE_LAUNCH_CHECK("frame_ids");
+    return GENIE_OK;
+}
+
+int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int P, int steps, float temperature,
+                          int unmask_mode, const float* noise, const float* uniforms, int teacher_force_time, int merge_commit,
+                          int64_t* gen_out, float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    const genie_cfg& c = *cfg;
+    GENIE_CHECK_ARG(wt && wt->layers_host && ids && gen_out && cache, "generate_cached: NULL pointer");
+    GENIE_CHECK_ARG(B >= 1 && P >= 1 && P < c.T && steps >= 1, "generate_cached: B=%d, prompt frames %d of %d, steps %d", B, P, c.T, steps);
+    if (unmask_mode != GENIE_UNMASK_RANDOM && unmask_mode != GENIE_UNMASK_GREEDY) {
+        set_error("Expected `unmask_mode` to be one of ['greedy', 'random']");
+        return GENIE_E_UNSUPPORTED;
+    }
+    GENIE_CHECK_ARG(steps == 1 || unmask_mode == GENIE_UNMASK_GREEDY || noise,
+                    "generate_cached: 'random' unmasking with steps > 1 needs the caller's U[0,1) draws");
+    GENIE_CHECK_ARG(temperature <= 1e-8f || uniforms, "generate_cached: temperature > 0 needs uniforms");
+    GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "generate_cached: cache too small");
+    GENIE_TRY(check_ws(c, B, workspace, workspace_bytes));
+    hipStream_t st = as_stream(stream);
+    const int S = c.S, T = c.T, n_new = T - P;
+    const size_t BS = (size_t)B * S, V = (size_t)c.factored_vocab * c.num_factored;
+    // scratch of the loop behind the workspace of its largest pass (the prompt's P frames; two frames for the merged passes)
+    genie_cfg cm = c;
+    cm.T = P > 2 ? P : 2;
+    char* base = (char*)workspace;
+    size_t off = carve(cm, B, nullptr).total;
+    auto take = [&](size_t bytes) { char* r = base + off; off += align_up(bytes, 256); return r; };
+    int64_t* idsP = (int64_t*)take(BS * P * 8);
+    int64_t* two = (int64_t*)take(BS * 2 * 8);
+    int64_t* cur = (int64_t*)take(BS * 8);
+    int64_t* fin = (int64_t*)take(BS * 8);
+    int64_t* samples = (int64_t*)take(BS * 8);
+    float* conf = (float*)take(BS * 4);
+    uint8_t* unmasked = (uint8_t*)take(BS);
+    float* logits = (float*)take(BS * V * 4);
+    GENIE_CHECK_ARG(off <= workspace_bytes, "generate_cached: workspace too small (%zu < %zu bytes)", workspace_bytes, off);
+
+    // ---- the prompt fills cache slots 0 .. P-1: one P-frame pass where the fragment-order kernels cover it, else the clean pass
+    // with the cache's T-frame layout, else frame by frame
+    for (int t = 0; t < P; ++t) GENIE_TRY(put_frame_ids(ids + (size_t)t * S, (long)T * S, idsP + (size_t)t * S, (long)P * S, S, B, 0, st));
+    int rc = GENIE_E_UNSUPPORTED;
+    if (P > 1) {
+        rc = genie_frames_pass(cfg, wt, idsP, B, 0, P, cache, cache_bytes, nullptr, workspace, workspace_bytes, stream);
+        if (rc == GENIE_E_UNSUPPORTED)
+            rc = genie_clean_pass(cfg, wt, idsP, B, P, T, cache, cache_bytes, workspace, workspace_bytes, stream);
+    }
+    if (rc == GENIE_E_UNSUPPORTED) {
+        for (int t = 0; t < P; ++t) {
+            GENIE_TRY(put_frame_ids(ids + (size_t)t * S, (long)T * S, fin, S, S, B, 0, st));
+            GENIE_TRY(genie_frames_pass(cfg, wt, fin, B, t, 1, cache, cache_bytes, nullptr, workspace, workspace_bytes, stream));
+        }
+    } else {
+        GENIE_TRY(rc);
+    }
+    bool opened = false, merge = merge_commit != 0;
+    for (int k = 0; k < n_new; ++k) {
+        const int t = P + k;
+        GENIE_TRY(put_frame_ids(nullptr, 0, cur, S, S, B, c.image_vocab_size, st));
+        if (hipMemsetAsync(unmasked, 0, BS, st) != hipSuccess) { set_error("memset failed"); return GENIE_E_LAUNCH; }
+        for (int step = 0; step < steps; ++step) {
+            if (!(step == 0 && opened))
+                GENIE_TRY(genie_frames_pass(cfg, wt, cur, B, t, 1, cache, cache_bytes, logits, workspace, workspace_bytes, stream));
+            const float* u = temperature > 1e-8f ? uniforms + ((size_t)k * steps + step) * c.num_factored * BS : nullptr;
+            GENIE_TRY(launch_sample(c, logits, GENIE_LAYOUT_TOKEN_MAJOR, B, temperature, u, samples, conf, st));
+            const bool last = step == steps - 1;
+            const float* keys = last ? nullptr : (unmask_mode == GENIE_UNMASK_GREEDY ? conf : noise + ((size_t)k * (steps - 1) + step) * BS);
+            GENIE_TRY(launch_mask_step(keys, last ? 0 : mask_count(step, steps, S), last, c.image_vocab_size, unmasked, samples, cur, S, B, S, st));
+        }
+        GENIE_TRY(put_frame_ids(cur, S, gen_out + (size_t)k * S, (long)n_new * S, S, B, 0, st));
+        opened = false;
+        if (t + 1 < T) {   // commit frame t: its final tokens, or the ground truth when teacher-forcing in time
+            const int64_t* fsrc = teacher_force_time ? ids + (size_t)t * S : cur;
+            const long fstride = teacher_force_time ? (long)T * S : S;
+            if (merge) {   // ... in the pass that also carries MaskGIT step 0 of frame t + 1 (all-mask tokens)
+                GENIE_TRY(put_frame_ids(fsrc, fstride, two, 2L * S, S, B, 0, st));
+                GENIE_TRY(put_frame_ids(nullptr, 0, two + S, 2L * S, S, B, c.image_vocab_size, st));
+                rc = genie_frames_pass(cfg, wt, two, B, t, 2, cache, cache_bytes, logits, workspace, workspace_bytes, stream);
+                if (rc == GENIE_E_UNSUPPORTED) merge = false;
+                else { GENIE_TRY(rc); opened = true; }
+            }
+            if (!opened) {
+                GENIE_TRY(put_frame_ids(fsrc, fstride, fin, S, S, B, 0, st));
+                GENIE_TRY(genie_frames_pass(cfg, wt, fin, B, t, 1, cache, cache_bytes, nullptr, workspace, workspace_bytes, stream));
+            }
+        }
+    }
+    return GENIE_OK;
+}
+
 int genie_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, void* stream) {
     GENIE_CHECK_ARG(src && dst, "pack_frame_w16: NULL pointer");
     return launch_pack_frame_w16(src, dst, N, K, as_stream(stream));

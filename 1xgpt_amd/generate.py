@@ -44,13 +44,15 @@ def generate_frames(model, example_THW: torch.LongTensor, num_prompt_frames=8, m
 
 @torch.no_grad()
 def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_frames=8, maskgit_steps=2, temperature=0.0,
-                           teacher_force_time=False, noise=None, unmask_mode="random", merge_commit=True):
+                           teacher_force_time=False, noise=None, unmask_mode="random", merge_commit=True, host_loop=False):
     """``generate_frames`` with a temporal KV cache (genie_frame_pass): every pass runs ONE frame through the stack
     against the cached temporal keys/values of the earlier frames instead of the full 16-frame forward --
     one P-frame pass for the prompt + (T-P)*(steps+1) single-frame passes (= 2 full-pass equivalents at P=8, steps=2) instead of (T-P)*steps full
     forwards (16).  Same outputs (per-row arithmetic is unchanged).
     merge_commit: where the library covers it (genie_frames_pass: f16x3, heads of 64 or 32, up to 16,384 rows per pass) the pass that commits frame t's
-    final tokens also carries MaskGIT step 0 of frame t+1, so a frame costs `steps` passes instead of `steps + 1`."""
+    final tokens also carries MaskGIT step 0 of frame t+1, so a frame costs `steps` passes instead of `steps + 1`.
+    host_loop: False = the whole loop is ONE library call (genie_generate_cached: every pass, sampling and mask step enqueued
+    without a host step in between); True = the same loop driven from Python (one C-ABI call per pass / sample / mask step)."""
     import math
     from . import _lib
     lib = _lib.load()
@@ -66,6 +68,24 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
     nbytes = lib.genie_prefix_cache_bytes(cfg, B)
     cache = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+
+    if not host_loop and P < T:
+        steps = int(maskgit_steps)
+        if unmask_mode not in ("random", "greedy"):
+            raise NotImplementedError(f"Expected `unmask_mode` to be one of ['greedy', 'random'], got {unmask_mode}")
+        nz = None
+        if steps > 1 and unmask_mode == "random":   # the draws of torch.rand_like (st_mask_git.py:204-206): the caller's, or fresh ones
+            nz = (torch.rand(T - P, steps - 1, B, S, device=dev) if noise is None
+                  else noise.to(dev)[:, :steps - 1].reshape(T - P, steps - 1, B, S).float().contiguous())
+        uni = torch.rand(T - P, steps, model.config.num_factored_vocabs, B, S, device=dev) if temperature > 1e-8 else None
+        gen = torch.empty(B, T - P, S, dtype=torch.int64, device=dev)
+        _lib.check(lib.genie_generate_cached(cfg, w, ids.data_ptr(), B, P, steps, float(temperature),
+                                             _lib.UNMASK_GREEDY if unmask_mode == "greedy" else _lib.UNMASK_RANDOM,
+                                             0 if nz is None else nz.data_ptr(), 0 if uni is None else uni.data_ptr(),
+                                             int(bool(teacher_force_time)), int(bool(merge_commit)), gen.data_ptr(), cache.data_ptr(), nbytes,
+                                             ws.data_ptr(), ws.numel(), st), "genie_generate_cached")
+        outputs = torch.cat([ex[:, :P], gen.view(B, T - P, model.h, model.w)], dim=1)
+        return torch.cat([outputs, ex[:, P:]], dim=1)
 
     def frame_pass(tokens_BS, t, logits=None):
         _lib.check(lib.genie_frame_pass(cfg, w, tokens_BS.data_ptr(), B, t, cache.data_ptr(), nbytes,

@@ -147,16 +147,29 @@ def test_frames_pass_refuses_what_it_does_not_cover():
 @pytest.mark.parametrize("steps", [2, 3])
 def test_merged_commit_schedule_equals_plain_kv_cache_schedule(steps, heads):
     """generate_frames_cached with the commit pass of frame t carrying step 0 of frame t + 1 (genie_frames_pass, 2 frames) produces
-    the frames of the schedule that runs them as two passes -- same per-row arithmetic, so exactly the same ids."""
+    the frames of the schedule that runs them as two passes -- same per-row arithmetic, so exactly the same ids; and the loop as one
+    library call (genie_generate_cached) produces what the Python-driven loop produces."""
     cfg, m = _model(256, heads, layers=3)
     G = pkg("generate")
     for B in (1, 2):
         ex = dev(pkg("synthetic").make_clips(B, cfg, seed=40 + B)).view(B, 16, 16, 16)
         noise = torch.rand(8, max(steps - 1, 1), B, cfg.S, device="cuda")
         for tf in (False, True):
-            plain = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=False)
-            merged = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=True)
+            plain = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=False, host_loop=True)
+            merged = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=True, host_loop=True)
             assert torch.equal(plain, merged)
+            # ... and the whole loop as ONE library call (genie_generate_cached) gives the same frames again, merged or not
+            for mc in (False, True):
+                one = G.generate_frames_cached(m, ex, 8, steps, 0.0, tf, noise=noise, merge_commit=mc)
+                assert torch.equal(one, plain)
+    # greedy unmasking needs no draws; a temperature > 0 run only has to be well-formed (its draws are its own)
+    ex = dev(pkg("synthetic").make_clips(1, cfg, seed=44)).view(1, 16, 16, 16)
+    a = G.generate_frames_cached(m, ex, 8, steps, 0.0, False, unmask_mode="greedy")
+    b = G.generate_frames_cached(m, ex, 8, steps, 0.0, False, unmask_mode="greedy", host_loop=True)
+    assert torch.equal(a, b)
+    hot = G.generate_frames_cached(m, ex, 8, steps, 0.7, False)
+    assert hot.shape == (1, 24, 16, 16) and torch.equal(hot[:, :8], ex[:, :8]) and torch.equal(hot[:, 16:], ex[:, 8:])
+    assert int(hot[:, 8:16].min()) >= 0 and int(hot[:, 8:16].max()) < cfg.image_vocab_size
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(256, 1536, 512, 1), (512, 512, 512, 1), (96, 192, 128, 1), (1024, 2048, 512, 1), (2048, 1536, 512, 2),
