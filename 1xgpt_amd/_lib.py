@@ -86,8 +86,8 @@ SIGNATURES = {
                                    c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_frames_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_size_t,
                                     c_ptr, c_ptr, C.c_size_t, c_ptr]),
-    "genie_generate_cached": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
-                                        c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr, C.c_size_t, c_ptr]),
+    "genie_generate_cached": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, C.c_size_t, c_ptr, C.c_size_t, c_ptr]),
     "genie_pack_frame_w16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     "genie_frame_linear": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_metric_hits": (C.c_int, [c_ptr, C.c_int64, c_ptr, C.c_int64, C.c_int, C.c_int64, c_ptr, C.c_double, C.c_double,

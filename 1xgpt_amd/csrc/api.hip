@@ -546,13 +546,15 @@ static int put_frame_ids(const int64_t* src, long src_stride, int64_t* dst, long
     return GENIE_OK;
 }
 
-int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int P, int steps, float temperature,
-                          int unmask_mode, const float* noise, const float* uniforms, int teacher_force_time, int merge_commit,
-                          int64_t* gen_out, float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int P, int n_new, int steps,
+                          float temperature, int unmask_mode, const float* noise, const float* uniforms, int teacher_force_time,
+                          int merge_commit, int64_t* gen_out, float* logits0_out, float* cache, size_t cache_bytes, void* workspace,
+                          size_t workspace_bytes, void* stream) {
     GENIE_TRY(check_cfg(cfg));
     const genie_cfg& c = *cfg;
     GENIE_CHECK_ARG(wt && wt->layers_host && ids && gen_out && cache, "generate_cached: NULL pointer");
-    GENIE_CHECK_ARG(B >= 1 && P >= 1 && P < c.T && steps >= 1, "generate_cached: B=%d, prompt frames %d of %d, steps %d", B, P, c.T, steps);
+    GENIE_CHECK_ARG(B >= 1 && P >= 1 && n_new >= 1 && P + n_new <= c.T && steps >= 1,
+                    "generate_cached: B=%d, %d prompt + %d new frames of at most %d, steps %d", B, P, n_new, c.T, steps);
     if (unmask_mode != GENIE_UNMASK_RANDOM && unmask_mode != GENIE_UNMASK_GREEDY) {
         set_error("Expected `unmask_mode` to be one of ['greedy', 'random']");
         return GENIE_E_UNSUPPORTED;
@@ -563,7 +565,7 @@ int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const i
     GENIE_CHECK_ARG(cache_bytes >= genie_prefix_cache_bytes(cfg, B), "generate_cached: cache too small");
     GENIE_TRY(check_ws(c, B, workspace, workspace_bytes));
     hipStream_t st = as_stream(stream);
-    const int S = c.S, T = c.T, n_new = T - P;
+    const int S = c.S, T = P + n_new;   // frames per clip in `ids` (the cache keeps the model's c.T slots per clip)
     const size_t BS = (size_t)B * S, V = (size_t)c.factored_vocab * c.num_factored;
     // scratch of the loop behind the workspace of its largest pass (the prompt's P frames; two frames for the merged passes)
     genie_cfg cm = c;
@@ -588,7 +590,7 @@ int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const i
     if (P > 1) {
         rc = genie_frames_pass(cfg, wt, idsP, B, 0, P, cache, cache_bytes, nullptr, workspace, workspace_bytes, stream);
         if (rc == GENIE_E_UNSUPPORTED)
-            rc = genie_clean_pass(cfg, wt, idsP, B, P, T, cache, cache_bytes, workspace, workspace_bytes, stream);
+            rc = genie_clean_pass(cfg, wt, idsP, B, P, c.T, cache, cache_bytes, workspace, workspace_bytes, stream);
     }
     if (rc == GENIE_E_UNSUPPORTED) {
         for (int t = 0; t < P; ++t) {
@@ -606,6 +608,13 @@ int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const i
         for (int step = 0; step < steps; ++step) {
             if (!(step == 0 && opened))
                 GENIE_TRY(genie_frames_pass(cfg, wt, cur, B, t, 1, cache, cache_bytes, logits, workspace, workspace_bytes, stream));
+            if (step == 0 && logits0_out) {   // orig_logits of the frame (st_mask_git.py:165,226): the step-0 logits, (B, n_new, S, V)
+                if (hipMemcpy2DAsync(logits0_out + (size_t)k * S * V, (size_t)n_new * S * V * 4, logits, (size_t)S * V * 4, (size_t)S * V * 4,
+                                     (size_t)B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                    set_error("memcpy failed");
+                    return GENIE_E_LAUNCH;
+                }
+            }
             const float* u = temperature > 1e-8f ? uniforms + ((size_t)k * steps + step) * c.num_factored * BS : nullptr;
             GENIE_TRY(launch_sample(c, logits, GENIE_LAYOUT_TOKEN_MAJOR, B, temperature, u, samples, conf, st));
             const bool last = step == steps - 1;

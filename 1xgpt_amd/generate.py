@@ -79,11 +79,11 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
                   else noise.to(dev)[:, :steps - 1].reshape(T - P, steps - 1, B, S).float().contiguous())
         uni = torch.rand(T - P, steps, model.config.num_factored_vocabs, B, S, device=dev) if temperature > 1e-8 else None
         gen = torch.empty(B, T - P, S, dtype=torch.int64, device=dev)
-        _lib.check(lib.genie_generate_cached(cfg, w, ids.data_ptr(), B, P, steps, float(temperature),
+        _lib.check(lib.genie_generate_cached(cfg, w, ids.data_ptr(), B, P, T - P, steps, float(temperature),
                                              _lib.UNMASK_GREEDY if unmask_mode == "greedy" else _lib.UNMASK_RANDOM,
                                              0 if nz is None else nz.data_ptr(), 0 if uni is None else uni.data_ptr(),
-                                             int(bool(teacher_force_time)), int(bool(merge_commit)), gen.data_ptr(), cache.data_ptr(), nbytes,
-                                             ws.data_ptr(), ws.numel(), st), "genie_generate_cached")
+                                             int(bool(teacher_force_time)), int(bool(merge_commit)), gen.data_ptr(), 0, cache.data_ptr(),
+                                             nbytes, ws.data_ptr(), ws.numel(), st), "genie_generate_cached")
         outputs = torch.cat([ex[:, :P], gen.view(B, T - P, model.h, model.w)], dim=1)
         return torch.cat([outputs, ex[:, P:]], dim=1)
 

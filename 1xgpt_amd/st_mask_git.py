@@ -394,13 +394,15 @@ class STMaskGIT(nn.Module):
         return samples, logits0.view(B, nv, vf, self.h, self.w).permute(0, 2, 1, 3, 4)
 
     def generate(self, input_ids, attention_mask=None, max_new_tokens=None, min_new_tokens=None, return_logits=False,
-                 maskgit_steps=1, temperature=0.0, noise=None):
+                 maskgit_steps=1, temperature=0.0, noise=None, kv_cache=True):
         """Autoregressive frame generation behind the reference's Llama-style signature (st_mask_git.py:65-113):
         ``input_ids`` (B, n_prompt_frames * S) holds the prompt frames; ``max_new_tokens // S`` further frames are decoded one
         after the other with ``maskgit_generate``, each seeing every frame before it.  Returns the (B, (n_prompt + n_new) * S)
         token ids, plus -- with ``return_logits`` -- the step-0 factored logits of the new frames stacked on dim 3.
         ``attention_mask`` is accepted and ignored, as in the reference.  ``min_new_tokens`` may only repeat ``max_new_tokens``.
-        noise: optional (n_new_frames, maskgit_steps - 1, B, S) unmasking draws to replay (the reference draws them itself)."""
+        noise: optional (n_new_frames, maskgit_steps - 1, B, S) unmasking draws to replay (the reference draws them itself).
+        kv_cache: True (default) = the frames are decoded by one-frame passes against a temporal KV cache; False = the reference's
+        own schedule, a full forward over the canvas per MaskGIT step (same frames up to f32 accumulation order)."""
         S = self.config.S
         if min_new_tokens is not None and min_new_tokens != max_new_tokens:
             raise AssertionError("Expecting `min_new_tokens`, if specified, to match `max_new_tokens`.")
@@ -409,6 +411,37 @@ class STMaskGIT(nn.Module):
         ids = self._ids(input_ids)
         B, n_new = ids.size(0), max_new_tokens // S
         n_prompt = ids.numel() // (B * S)
+        if kv_cache and n_new >= 1 and n_prompt >= 1 and n_prompt + n_new <= self.config.T:
+            # the same frames on the temporal KV cache, the whole loop one library call (genie_generate_cached): every MaskGIT step
+            # runs the rows of the frame being decoded instead of a full forward over the canvas (causal in time: the all-MASK
+            # frames behind it never reach it).  Equal to the loop below up to f32 accumulation order.
+            lib = _lib.load()
+            cfg, w = self._weights()[:2]
+            dev = ids.device
+            steps = int(maskgit_steps)
+            V = self.config.factored_vocab_size * self.config.num_factored_vocabs
+            clip = torch.full((B, n_prompt + n_new, S), self.mask_token_id, dtype=torch.int64, device=dev)
+            clip[:, :n_prompt] = ids.view(B, n_prompt, S)
+            nz = None
+            if steps > 1:   # torch.rand_like of st_mask_git.py:204-206: the caller's draws, or fresh ones
+                nz = (torch.rand(n_new, steps - 1, B, S, device=dev) if noise is None
+                      else noise.to(dev)[:, :steps - 1].reshape(n_new, steps - 1, B, S).float().contiguous())
+            uni = torch.rand(n_new, steps, self.config.num_factored_vocabs, B, S, device=dev) if temperature > 1e-8 else None
+            gen = torch.empty(B, n_new, S, dtype=torch.int64, device=dev)
+            lg0 = torch.empty(B, n_new, S, V, dtype=torch.float32, device=dev) if return_logits else None
+            nbytes = lib.genie_prefix_cache_bytes(cfg, B)
+            cache = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws = self._workspace(B)
+            _lib.check(lib.genie_generate_cached(cfg, w, clip.data_ptr(), B, n_prompt, n_new, steps, float(temperature), _lib.UNMASK_RANDOM,
+                                                 0 if nz is None else nz.data_ptr(), 0 if uni is None else uni.data_ptr(), 0, 1,
+                                                 gen.data_ptr(), 0 if lg0 is None else lg0.data_ptr(), cache.data_ptr(), nbytes,
+                                                 ws.data_ptr(), ws.numel(), self._stream()), "genie_generate_cached")
+            tokens = torch.cat([ids.view(B, n_prompt * S), gen.view(B, n_new * S)], dim=1)
+            if not return_logits:
+                return tokens
+            nv, vf = self.config.num_factored_vocabs, self.config.factored_vocab_size
+            # (B, n, S, [vocab0 | vocab1]) -> "B vocab_size num_vocabs n H W": the per-frame (B, 512, 2, H, W) logits stacked on dim 3
+            return tokens, lg0.view(B, n_new, self.h, self.w, nv, vf).permute(0, 5, 4, 1, 2, 3)
         # one (B, n_prompt + n_new, H, W) canvas: prompt frames up front, the frames to come all-MASK; maskgit_generate fills
         # canvas[:, t] in place, which is exactly what the next frame's context must contain
         canvas = torch.full((B, n_prompt + n_new, self.h, self.w), self.mask_token_id, dtype=torch.long, device=ids.device)

@@ -287,17 +287,20 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t
  * LayerNorm blocks, S 256, frame_w16 streams present, B * nf * S <= 16,384 rows): the caller then runs the frames one by one. */
 int genie_frames_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* frame_ids, int B, int t0, int nf, float* cache,
                       size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream);
-/* generate.py:77-103 on the temporal KV cache, the WHOLE loop enqueued by one call (no host synchronisation, no host work between
- * passes): ids (B, T, S) = the example clip (frames [0, P) are the prompt; frames >= P are read only when teacher_force_time);
- * gen_out (B, T - P, S) receives the generated frames.  Per new frame: `steps` MaskGIT steps of one-frame passes (genie_frames_pass),
- * genie_sample, genie_mask_step; the commit of frame t shares a two-frame pass with step 0 of frame t + 1 where the library covers it
- * and merge_commit != 0.  noise: the unmasking draws (T - P, steps - 1, B, S) f32 ('random' mode with steps > 1; st_mask_git.py:204-206
- * draws them with torch.rand_like); uniforms: (T - P, steps, num_factored, B, S) for temperature > 0; both may be NULL otherwise.
- * cache: genie_prefix_cache_bytes(cfg, B); workspace: genie_workspace_bytes(cfg, B).  Same frames as the full-forward schedule
- * (generate.py:81-95) up to f32 accumulation order. */
-int genie_generate_cached(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int P, int steps, float temperature,
-                          int unmask_mode, const float* noise, const float* uniforms, int teacher_force_time, int merge_commit,
-                          int64_t* gen_out, float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* generate.py:77-103 / STMaskGIT.generate (st_mask_git.py:65-113) on the temporal KV cache, the WHOLE loop enqueued by one call (no
+ * host synchronisation, no host work between passes): ids (B, P + n_new, S) = the clip (frames [0, P) are the prompt; frames >= P are
+ * read only when teacher_force_time); gen_out (B, n_new, S) receives the generated frames; logits0_out (B, n_new, S, V) f32
+ * token-major (or NULL) the step-0 logits of every new frame (what maskgit_generate returns, st_mask_git.py:165,226).  P + n_new <= T.
+ * Per new frame: `steps` MaskGIT steps of one-frame passes (genie_frames_pass), genie_sample, genie_mask_step; the commit of frame t
+ * shares a two-frame pass with step 0 of frame t + 1 where the library covers it and merge_commit != 0.  noise: the unmasking draws
+ * (n_new, steps - 1, B, S) f32 ('random' mode with steps > 1; st_mask_git.py:204-206 draws them with torch.rand_like); uniforms:
+ * (n_new, steps, num_factored, B, S) for temperature > 0; both may be NULL otherwise.  cache: genie_prefix_cache_bytes(cfg, B);
+ * workspace: genie_workspace_bytes(cfg, B).  Same frames as the full-forward schedule (generate.py:81-95) up to f32 accumulation
+ * order. */
+int genie_generate_cached(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int P, int n_new, int steps,
+                          float temperature, int unmask_mode, const float* noise, const float* uniforms, int teacher_force_time,
+                          int merge_commit, int64_t* gen_out, float* logits0_out, float* cache, size_t cache_bytes, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* f32 (N, K) row-major weight -> split f16 in FRAGMENT ORDER (2 N K 16-bit values) for the one-frame kernels
  * (csrc/kernels_frame.hip): blocks of 32 rows x 64 k, per block [plane hi | lo'][MFMA step 0..3] fragments of 1 KB = the 64 lanes'
  * 16-byte operand pieces (lane 32 h + r: row r, k = 16 step + 8 h .. + 7), so that every operand load of those kernels is a

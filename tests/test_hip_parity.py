@@ -193,12 +193,14 @@ def test_maskgit_errors(golden, models):
 def test_generate_golden(golden, models, name):
     z, cfg, sd = golden(name)
     m = models(name)
-    out = m.generate(dev(z["ids"][:, :2 * cfg.S]), None, max_new_tokens=2 * cfg.S, return_logits=True,
-                     maskgit_steps=2, temperature=0.0, noise=dev(z["gen_noise"]))
-    toks, gl = out
-    assert np.array_equal(toks.cpu().numpy(), z["gen_out"])
-    if name == "tiny_ln":
-        assert np.abs(gl.cpu().numpy() - z["gen_logits"]).max() < 1e-4
+    for kv in (True, False):   # one-frame passes against the temporal KV cache (the default) / the reference's full forwards
+        out = m.generate(dev(z["ids"][:, :2 * cfg.S]), None, max_new_tokens=2 * cfg.S, return_logits=True,
+                         maskgit_steps=2, temperature=0.0, noise=dev(z["gen_noise"]), kv_cache=kv)
+        toks, gl = out
+        assert np.array_equal(toks.cpu().numpy(), z["gen_out"]), kv
+        if name == "tiny_ln":
+            assert np.abs(gl.cpu().numpy() - z["gen_logits"]).max() < 1e-4, kv
+    assert m.generate(dev(z["ids"][:, :2 * cfg.S]), None, max_new_tokens=cfg.S, maskgit_steps=1).shape == (z["ids"].shape[0], 3 * cfg.S)
 
 
 @pytest.mark.parametrize("name", TINY)
