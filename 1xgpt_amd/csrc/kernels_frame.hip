@@ -894,7 +894,10 @@ int launch_fr(const FrGemmArgs& a, hipStream_t st) {
 // workgroups for the 64-column tiles of a pass of >= 512 rows (two frames, or two clips)
 template <int NJ, int NKB, int EPI, bool LNF>
 int launch_fr_w(int nw, const FrGemmArgs& a, hipStream_t st) {
-    const bool wide2 = NJ == 2 && NKB == 1 && a.M >= 512 && a.M % 64 == 0;
+    // (the LayerNorm-fused Linears keep 32-row workgroups: two of them fit a CU since the staging area shares the reduce's LDS, and a
+    // 64-row workgroup does twice the LayerNorm work behind one barrier -- same-box A/B: equal at 512 rows, +2-3 % at 1,024,
+    // profiles/r05o_ln_mi1_ab.txt)
+    const bool wide2 = NJ == 2 && NKB == 1 && a.M >= 512 && a.M % 64 == 0 && !LNF;
     if constexpr (NJ == 2 && NKB == 1) {
         if (wide2) {
             switch (nw) {
