@@ -162,6 +162,8 @@ template <int NW, int MI, int NJ, int NKB, int EPI, bool LNF>
 __global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW >= 4 ? NW / 4 : 1, NW >= 4 ? NW / 4 : 1)))
 void gemm16_fr_kernel(const FrGemmArgs a) {
     constexpr int NT = NW * 64, TM = 32 * MI, TN = 32 * NJ, PITCH = TN + 4;
+    // k-blocks of a wave in flight (fc2: 4 per wave).  Three in flight (231 registers) measured +0.3 %: fc2's 10 us are its 512 KB per
+    // workgroup on 128 CUs, not the second round trip (profiles/r05q_fc2_ring3_ab.txt)
     constexpr int RING = NKB > 1 ? 2 : 1;
     static_assert(!LNF || NKB == 1, "LayerNorm-fused A: the waves tile one row of K = 64 NW");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
