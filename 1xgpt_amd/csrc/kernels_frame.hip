@@ -949,7 +949,14 @@ int launch_frm_any(const FrGemmArgs& a, hipStream_t st) {
     static const int big = study_env("GENIE_FRM_256", 1);
     if (big && a.N >= 1024 && a.N % 128 == 0 && a.M % 256 == 0 && a.M >= 4096) return launch_frm<4, 2, 2, 2, 3, EPI>(a, st);
     if (a.N % 128 == 0 && (EPI == FR_EPI_QKVS || t128 >= 160 || a.N >= 1024)) return launch_frm<2, 4, 2, 1, 4, EPI>(a, st);
-    if constexpr (EPI != FR_EPI_QKVS) return launch_frm<4, 2, 1, 1, 5, EPI>(a, st);
+    if constexpr (EPI != FR_EPI_QKVS) {
+        // the narrow outputs (N = d): 128 x 64 tiles, or -- while those leave CUs idle (fc2 at 2,048 rows: 128 tiles) -- 64 x 64 tiles on
+        // 4-wave workgroups, two per CU (64 KB of ring each)
+        static const int small = study_env("GENIE_FRM_64", 1);
+        const long t64w = (long)(a.M / 128) * (a.N / 64);
+        if (small && t64w < 192 && a.M % 64 == 0 && a.N % 64 == 0) return launch_frm<2, 2, 1, 1, 4, EPI>(a, st);
+        return launch_frm<4, 2, 1, 1, 5, EPI>(a, st);
+    }
     return GENIE_E_UNSUPPORTED;
 }
 int launch_ln_fr(const float* x, long ldx, const float* g, const float* b, float eps, uint16_t* out16, int M, int K, hipStream_t st) {
