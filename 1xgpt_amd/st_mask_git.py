@@ -357,6 +357,10 @@ class STMaskGIT(nn.Module):
         in_place = prompt_THW.dtype == torch.int64 and prompt_THW.is_contiguous()
         prompt = prompt_THW if in_place else prompt_THW.to(torch.int64).contiguous()
         B, T = prompt.shape[0], prompt.shape[1]
+        if T != self.config.T or prompt.numel() != B * T * self.config.S:
+            # (the reference fails here too: `x_TSC + self.pos_embed_TSC` does not broadcast, st_mask_git.py:261; the library would
+            # read past the tensor)
+            raise RuntimeError(f"maskgit_generate expects a (B, T={self.config.T}, H, W) prompt, got {tuple(prompt_THW.shape)}")
         S, V = self.config.S, self.config.factored_vocab_size * self.config.num_factored_vocabs
         dev = prompt.device
         ws = self._workspace(B)

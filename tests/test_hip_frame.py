@@ -206,3 +206,28 @@ def test_frame_linear_vs_f64(M, N, K, mode):
     # without a bias
     _lib.check(lib.genie_frame_linear(x_fr.data_ptr(), w_fr.data_ptr(), 0, y.data_ptr(), M, N, K, mode, st), "frame_linear")
     assert (y.double() - (ref - b.double())).abs().max().item() < 5e-6 * scale * max(1.0, (K / 512) ** 0.5)
+
+
+@pytest.mark.parametrize("B,n_prompt,n_new,steps", [(1, 1, 15, 1), (3, 2, 14, 3), (2, 5, 11, 2)])
+def test_module_generate_on_kv_cache_equals_full_forward_schedule(B, n_prompt, n_new, steps):
+    """STMaskGIT.generate (st_mask_git.py:65-113) on the temporal KV cache (genie_generate_cached: one library call) against the same call
+    on the reference's schedule (a full forward over the canvas per MaskGIT step): same frames up to f32 accumulation order, the same
+    step-0 logits; odd batch, one prompt frame, one MaskGIT step.  (The KV-cache form also takes a canvas shorter than T; the reference's
+    own schedule cannot: its positional table does not broadcast, st_mask_git.py:261 -- here a RuntimeError instead of a fault.)"""
+    cfg, m = _model(128, 2, layers=2)
+    S = cfg.S
+    ids = dev(pkg("synthetic").make_clips(B, cfg, seed=60 + B)).view(B, cfg.T, S)[:, :n_prompt].reshape(B, n_prompt * S)
+    noise = torch.rand(n_new, max(steps - 1, 1), B, S, device="cuda")
+    a, la = m.generate(ids, None, max_new_tokens=n_new * S, return_logits=True, maskgit_steps=steps, temperature=0.0, noise=noise, kv_cache=True)
+    b, lb = m.generate(ids, None, max_new_tokens=n_new * S, return_logits=True, maskgit_steps=steps, temperature=0.0, noise=noise, kv_cache=False)
+    assert a.shape == b.shape == (B, (n_prompt + n_new) * S) and la.shape == lb.shape == (B, 512, 2, n_new, 16, 16)
+    assert torch.equal(a[:, :n_prompt * S], ids)
+    first = a[:, n_prompt * S:(n_prompt + 1) * S] == b[:, n_prompt * S:(n_prompt + 1) * S]
+    assert first.float().mean().item() > 0.995          # the first new frame sees identical context in both schedules
+    assert (la[:, :, :, 0] - lb[:, :, :, 0]).abs().max().item() < 3e-5 * max(1.0, lb.abs().max().item())
+    assert (a == b).float().mean().item() > 0.97         # later frames inherit any flipped argmax of the earlier ones
+    short = m.generate(ids, None, max_new_tokens=S, maskgit_steps=steps, noise=noise[:1])      # a canvas shorter than T: KV cache only
+    assert short.shape == (B, (n_prompt + 1) * S) and torch.equal(short, a[:, :(n_prompt + 1) * S])
+    if n_prompt + 1 < cfg.T:
+        with pytest.raises(RuntimeError):
+            m.generate(ids, None, max_new_tokens=S, maskgit_steps=steps, kv_cache=False)
