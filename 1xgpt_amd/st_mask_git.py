@@ -244,9 +244,14 @@ class STMaskGIT(nn.Module):
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
-    def _ids(self, t):
+    def _ids(self, t, whole_clips=False):
         if not t.is_cuda:
             raise RuntimeError("1xgpt_amd runs on the GPU only (no CPU fallback): move inputs to cuda")
+        if whole_clips and (t.dim() < 2 or t.numel() != t.shape[0] * self.config.T * self.config.S):
+            # (the reference fails on such an input too -- the positional table does not broadcast, st_mask_git.py:261 --; the
+            # library takes B from dim 0 and would read past the tensor)
+            raise RuntimeError(f"expected token ids of {self.config.T} frames x {self.config.S} tokens per clip (B, T, H, W) / "
+                               f"(B, T*S), got {tuple(t.shape)}")
         return t.to(torch.int64).contiguous()
 
     # ------------------------------------------------------------------ forward pieces
@@ -254,7 +259,7 @@ class STMaskGIT(nn.Module):
         """Run embed + decoder; the (B,T,S,d) result stays at offset 0 of the workspace (returned as a view)."""
         lib = _lib.load()
         cfg, w = self._weights()[:2]
-        ids = self._ids(x_THW)
+        ids = self._ids(x_THW, whole_clips=True)
         B = ids.shape[0]
         ws = self._workspace(B)
         _lib.check(lib.genie_compute_logits(cfg, w, ids.data_ptr(), B, 0, 0, 0, ws.data_ptr(), ws.data_ptr(),
@@ -266,7 +271,7 @@ class STMaskGIT(nn.Module):
         """Logits of frames [t0,t1): (B, V, t1-t0, H, W) for layout='bcthw', (B, t1-t0, S, V) for 'token'."""
         lib = _lib.load()
         cfg, w = self._weights()[:2]
-        ids = self._ids(x_THW)
+        ids = self._ids(x_THW, whole_clips=True)
         B = ids.shape[0]
         ws = self._workspace(B)
         nt, V = t1 - t0, self.config.factored_vocab_size * self.config.num_factored_vocabs
@@ -289,7 +294,7 @@ class STMaskGIT(nn.Module):
         [sum CE, sum all-factors-correct, n counted] over frames [t0,t1); no logits leave the workspace."""
         lib = _lib.load()
         cfg, w = self._weights()[:2]
-        ids, lab = self._ids(x_THW), self._ids(labels_THW)
+        ids, lab = self._ids(x_THW, whole_clips=True), self._ids(labels_THW, whole_clips=True)
         B = ids.shape[0]
         t1 = self.config.T if t1 is None else t1
         ws = self._workspace(B)
@@ -319,6 +324,8 @@ class STMaskGIT(nn.Module):
         T, H, W = self.config.T, self.h, self.w
         x_THW = self._ids(input_ids).view(-1, T, H, W)
         lab = self._ids(labels).view(-1, T, H, W)
+        if lab.shape != x_THW.shape:
+            raise RuntimeError(f"labels {tuple(labels.shape)} do not match input_ids {tuple(input_ids.shape)}")
         logits = self.compute_logits(x_THW)  # leaves the hidden state in the workspace
         lib = _lib.load()
         cfg, w = self._weights()[:2]

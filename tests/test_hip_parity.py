@@ -183,6 +183,13 @@ def test_maskgit_errors(golden, models):
     prompt[:, 2:] = cfg.image_vocab_size
     with pytest.raises(NotImplementedError):
         m.maskgit_generate(prompt, 2, maskgit_steps=2, unmask_mode="bogus")
+    # inputs that are not whole clips: the reference fails on them (its positional table does not broadcast, st_mask_git.py:261);
+    # the library takes B from dim 0 and must not be handed less memory than B clips
+    short = dev(z["ids"]).view(-1, cfg.T, H, W)[:, :cfg.T - 1]
+    for call in (lambda: m.compute_logits(short), lambda: m.hidden_states(short), lambda: m.maskgit_generate(short.clone(), 1),
+                 lambda: m(dev(z["ids"]), dev(z["ids"])[:1])):
+        with pytest.raises(RuntimeError):
+            call()
     with pytest.raises(RuntimeError):  # no CPU fallback
         m.maskgit_generate(prompt.cpu(), 2)
     with pytest.raises(AssertionError):
