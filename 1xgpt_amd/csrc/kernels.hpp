@@ -65,6 +65,11 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
                           uint16_t* planes = nullptr);
 int launch_pack_spatial_qkv(const float* qkv_w, uint16_t* out, hipStream_t st);
 bool temporal_fused_takes(const genie_cfg& c, const genie_attn_weights& aw, int B);   // will launch_temporal_fused_bf16 run this problem?
+// kernels_fused_prefix.hip: the same sub-block in the prefix-cache passes (mode 1 clean pass: K / V fragment images written to `kv`, the
+// layer's cache slice; mode 2 masked pass: read back).  `takes` is the ONE predicate of producer and consumer.
+bool temporal_prefix_fused_takes(const genie_cfg& c, const genie_attn_weights& aw, int B, int model_T);
+int launch_temporal_prefix_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, float* x, uint16_t* kv, int B, int mode,
+                                      int shift, int model_T, hipStream_t st);
 
 // Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
 // tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.

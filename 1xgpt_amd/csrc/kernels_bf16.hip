@@ -874,7 +874,10 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
     static const int no_shadow_env = study_env("GENIE_T_FROM_F32", 1);   // (a study-build knob: the shipping library reads no environment)
     const bool fused_t = w.frame_t < 0 && !w.tqkv && !w.tcache && !w.stop_after_tqkv && temporal_qkv16(c, w.model_T) &&
                          temporal_fused_takes(c, lw.temporal, B);
-    const bool shadow16 = !(fused_t && no_shadow_env);
+    // ... or, in the prefix-cache passes, as the fused kernel that keeps the K / V fragment images in the cache slice (kernels_fused_prefix.hip)
+    const bool frag_t = w.frame_t < 0 && (w.tqkv || w.tcache) && (!w.tqkv || w.tq_frames <= c.T) && temporal_qkv16(c, w.model_T) &&
+                        temporal_prefix_fused_takes(c, lw.temporal, B, w.model_T);
+    const bool shadow16 = !((fused_t || frag_t) && no_shadow_env);
     // spatial
     const uint16_t* u = x16;
     int rc = GENIE_E_UNSUPPORTED;
@@ -935,6 +938,12 @@ int st_block_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, W
         rc = launch_temporal_fused_bf16(c, lw.temporal, (proj_done && !shadow16) ? nullptr : x16, x, B, st);
         if (rc == GENIE_OK) temporal_done = true;
         else if (rc != GENIE_E_UNSUPPORTED) return rc;
+    }
+    if (frag_t) {   // prefix-cache passes of the shipped geometry: one kernel, the cache slice holds K / V fragment images
+        GENIE_TRY(launch_temporal_prefix_fused_bf16(c, lw.temporal, x, reinterpret_cast<uint16_t*>(w.tqkv ? w.tqkv : const_cast<float*>(w.tcache)),
+                                                    B, w.tqkv ? 1 : 2, w.tshift, w.model_T, st));
+        if (w.stop_after_tqkv) return GENIE_OK;
+        temporal_done = true;
     }
     if (!temporal_done) {
     if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t

@@ -262,7 +262,12 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int
  * genie_prefix_cache_bytes is the size for nframes = T (an upper bound).
  * The cache is opaque to the caller and only valid for the precision that wrote it: GENIE_PREC_EXACT / _F16X3 store f32;
  * GENIE_PREC_BF16 stores bf16 values (models with T <= 16 and head_dim 32 / 64) in the first half of each layer's slice --
- * the slice strides stay those of the f32 layout, so the size above holds for every precision. */
+ * the slice strides stay those of the f32 layout, so the size above holds for every precision.
+ * A clean pass with cache_frames == nframes < T makes a cache for genie_masked_frames_logits ONLY (a cache genie_frame_pass can
+ * continue has T frame slots: cache_frames = T).  For the shipped geometry in GENIE_PREC_BF16 (d 256, 8 heads of 32, fused
+ * streams present, 8 <= nframes < T, B * S >= 512) such a cache holds, per (clip, position, head), the K and V operand
+ * fragments of the fused temporal kernel instead of qkv rows (csrc/kernels_fused_prefix.hip: both passes run the temporal
+ * sub-block as one kernel); producer and consumer decide by the same predicate of (cfg, weights, B, nframes). */
 size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B);
 int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int nframes, int cache_frames,
                      float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);

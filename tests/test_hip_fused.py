@@ -315,3 +315,76 @@ def test_spatial_attn_proj_fused_entry_point_vs_reference_math(n_seq, with_x16):
         assert (x16 == 0).all()
     # below the kernel's size threshold the entry point must refuse, not compute garbage
     assert lib.genie_spatial_attn_proj_fused_bf16(cfg, aw, planes.data_ptr(), xd.data_ptr(), 0, 64, st) == _lib.E_UNSUPPORTED
+
+
+# ---- the prefix-cache passes of the evaluator (evaluate.py:107-116) on the fused temporal kernel (csrc/kernels_fused_prefix.hip)
+def _prefix_passes(m, ids, n, frame0, masked_ids):
+    """genie_clean_pass over frames 0..n-1, then one genie_masked_frames_logits on `masked_ids` (B, n, S): logits (B, n, S, V)."""
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    cfg, w = m._weights()[:2]
+    B, S = ids.shape[0], m.config.S
+    V = m.config.factored_vocab_size * m.config.num_factored_vocabs
+    ws = m._workspace(B)
+    nbytes = lib.genie_prefix_cache_bytes(cfg, B)
+    cache = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ctx = ids[:, :n].contiguous()
+    _lib.check(lib.genie_clean_pass(cfg, w, ctx.data_ptr(), B, n, n, cache.data_ptr(), nbytes, ws.data_ptr(), ws.numel(), st), "clean")
+    logits = torch.empty(B, n, S, V, dtype=torch.float32, device="cuda")
+    _lib.check(lib.genie_masked_frames_logits(cfg, w, masked_ids.data_ptr(), B, frame0, n, cache.data_ptr(), nbytes, logits.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), st), "masked")
+    torch.cuda.synchronize()
+    return logits.cpu().numpy()
+
+
+@pytest.mark.parametrize("qkv_bias,n,frame0,B", [(False, 15, 1, 19), (True, 15, 1, 3), (False, 12, 1, 5), (True, 9, 0, 2), (False, 15, 0, 4)])
+def test_prefix_passes_fused_temporal_matches_unfused(monkeypatch, qkv_bias, n, frame0, B):
+    """Clean pass + masked pass with the temporal sub-block as ONE kernel each (K / V fragment images in the cache) against the
+    launches they replace (qkv GEMM -> bf16 qkv rows in the cache, attn_temporal(_prefix)_f32_mfma, proj GEMM): same rounding
+    points, so the logits differ by accumulation order and one-ulp bf16 flips.  n < 15: phantom frame slots; frame0 = 0: slot i sees
+    cached frames < i only; 19 clips: persistent workgroups carry their ring from block to block, ragged last round."""
+    cfg = pkg("config").GenieConfig(num_layers=3, num_heads=8, d_model=256, T=16, S=256, num_factored_vocabs=2, qk_norm=False,
+                                    use_mup=False, qkv_bias=qkv_bias)
+    synth = pkg("synthetic")
+    sd = synth.make_state_dict(cfg, seed=177, law="conditioned")
+    if qkv_bias:
+        g = np.random.default_rng(6)
+        for k in sd:
+            if k.endswith("qkv.bias"):
+                sd[k] = (0.05 * g.standard_normal(sd[k].shape)).astype(np.float32)
+    ids = dev(synth.make_clips(B, cfg, seed=178).reshape(B, 16, 256))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    masked = ids[:, frame0:frame0 + n].clone()
+    hide = (torch.rand(masked.shape, generator=g) < 0.6).to("cuda")
+    masked[hide] = cfg.image_vocab_size
+    masked = masked.contiguous()
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    mf = _model(cfg, sd, True, monkeypatch)
+    _lib.check(lib.genie_profile_enable(1 << _lib.KC_FUSED), "profile_enable")
+    lib.genie_profile_reset()
+    lf = _prefix_passes(mf, ids, n, frame0, masked)
+    import ctypes
+    kbuf = ctypes.create_string_buffer(4096)
+    _lib.check(lib.genie_profile_kernels(_lib.KC_FUSED, kbuf, len(kbuf)), "profile_kernels")
+    lib.genie_profile_enable(0)
+    launched = {ln.split("\t")[0].split(" ")[0]: int(float(ln.split("\t")[1])) for ln in kbuf.value.decode().splitlines()}
+    print("fused launches:", launched)
+    L = cfg.num_layers
+    assert launched.get("temporal_prefix_fused_bf16_kernel<1>", 0) == L, launched     # clean pass, every layer (the last one for its K / V only)
+    assert launched.get("temporal_prefix_fused_bf16_kernel<2>", 0) == L, launched     # masked pass
+    mu = _model(cfg, sd, False, monkeypatch)
+    lu = _prefix_passes(mu, ids, n, frame0, masked)
+    d = np.abs(lf - lu)
+    print("prefix passes fused vs unfused logits: max", d.max(), "median", np.median(d), "scale", np.abs(lu).max())
+    assert np.isfinite(lf).all()
+    assert np.median(d) < 4e-3 and d.max() < 8e-2
+    # and against the full forward on the clean clip where the two coincide: with nothing masked, slot i of the masked pass IS frame
+    # frame0 + i of the plain forward (the cached keys are the clean ones, its own key is clean too)
+    if frame0 == 0:
+        lc = _prefix_passes(mf, ids, n, 0, ids[:, :n].contiguous())
+        full = mf.compute_logits_frames(ids.view(B, 16, 16, 16), 0, n, "token").cpu().numpy().reshape(B, n, 256, -1)
+        dc = np.abs(lc - full)
+        print("unmasked prefix pass vs full forward: max", dc.max(), "median", np.median(dc))
+        assert np.median(dc) < 4e-3 and dc.max() < 8e-2
