@@ -955,8 +955,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                 int ln = lane;
                 asm volatile("" : "+v"(ln));       // (everything lane-derived below is formed here, per block: hoisted to kernel entry it is spilled)
                 const int t4 = ln >> 2, pc = (ln & 3) * 8, rq = ln & 31, hq = ln >> 5;
+#ifndef GENIE_VAR_M_QWAIT
+#define GENIE_VAR_M_QWAIT 2     // (0: every stage also waits out the previous stage's two plane stores)
+#endif
                 for (int n = 0; n < 24; ++n) {
-                    fs_wait_vm<0>();
+                    // stage n's four LDS-DMA loads were requested at the top of stage n - 1; the only younger vector-memory operations are
+                    // that stage's two plane stores (vmcnt retires in order) -- they stay in flight.  n = 0: behind the row stores above.
+                    if (n == 0) fs_wait_vm<0>();
+                    else fs_wait_vm<GENIE_VAR_M_QWAIT>();
                     fs_barrier();      // stage n landed for every wave; the other half is free (n = 0: everyone's phase above is over too)
                     if (n + 1 < 24) issue_q(n + 1);
                     const unsigned char* sb = smem + ((n & 1) ? 2 * FS_STAGE : FS_STAGE) + ln * 16;
@@ -964,9 +970,42 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                     f32x16 acc;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    // the stage's 16 fragments through 8 rotating buffers, reads the compiler does not schedule (it pairs them: read, read,
+                    // wait, MFMA, wait, MFMA -- one LDS round trip per two matrix instructions, 44 % of the matrix rate; GENIE_VAR_M_QPF 0)
+#ifndef GENIE_VAR_M_QPF
+#define GENIE_VAR_M_QPF 8
+#endif
+#if GENIE_VAR_M_QPF > 0
+                    const unsigned lq = fs_lds_addr(sb);
+                    s16x8 qf[GENIE_VAR_M_QPF];
+#define QS_SWAPPED(f) acc = mma32x32(qf[(f) % GENIE_VAR_M_QPF], yk[f], acc);
+#define QS_PLAIN(f) acc = mma32x32(yk[f], qf[(f) % GENIE_VAR_M_QPF], acc);
+#define QS_STEP(f, OP)                                                                                                            \
+    {                                                                                                                             \
+        fs_lds_wait<((15 - (f)) < (GENIE_VAR_M_QPF - 1) ? (15 - (f)) : (GENIE_VAR_M_QPF - 1))>(qf[(f) % GENIE_VAR_M_QPF]);          \
+        OP(f)                                                                                                                     \
+        if constexpr ((f) + GENIE_VAR_M_QPF < 16) fs_lds_rd<((f) + GENIE_VAR_M_QPF) * 1024>(qf[(f) % GENIE_VAR_M_QPF], lq);        \
+    }
+#define QS_ALL(OP)                                                                                                                 \
+    {                                                                                                                             \
+        fs_lds_rd<0>(qf[0], lq);                                                                                                  \
+        if constexpr (GENIE_VAR_M_QPF > 1) fs_lds_rd<1024>(qf[1 % GENIE_VAR_M_QPF], lq);                                          \
+        if constexpr (GENIE_VAR_M_QPF > 2) { fs_lds_rd<2048>(qf[2 % GENIE_VAR_M_QPF], lq); fs_lds_rd<3072>(qf[3 % GENIE_VAR_M_QPF], lq); } \
+        if constexpr (GENIE_VAR_M_QPF > 4) {                                                                                      \
+            fs_lds_rd<4096>(qf[4 % GENIE_VAR_M_QPF], lq); fs_lds_rd<5120>(qf[5 % GENIE_VAR_M_QPF], lq);                             \
+            fs_lds_rd<6144>(qf[6 % GENIE_VAR_M_QPF], lq); fs_lds_rd<7168>(qf[7 % GENIE_VAR_M_QPF], lq);                             \
+        }                                                                                                                         \
+        QS_STEP(0, OP) QS_STEP(1, OP) QS_STEP(2, OP) QS_STEP(3, OP) QS_STEP(4, OP) QS_STEP(5, OP) QS_STEP(6, OP) QS_STEP(7, OP)     \
+        QS_STEP(8, OP) QS_STEP(9, OP) QS_STEP(10, OP) QS_STEP(11, OP) QS_STEP(12, OP) QS_STEP(13, OP) QS_STEP(14, OP) QS_STEP(15, OP) \
+    }
+#else
+#define QS_SWAPPED(f) acc = mma32x32(frag(sb, f), yk[f], acc);
+#define QS_PLAIN(f) acc = mma32x32(yk[f], frag(sb, f), acc);
+#define QS_ALL(OP)                                                                                                                 \
+    { OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15) }
+#endif
                     if (part < 2) {    // swapped: D[feature][token]
-#pragma unroll
-                        for (int f = 0; f < 16; ++f) acc = mma32x32(frag(sb, f), yk[f], acc);
+                        QS_ALL(QS_SWAPPED)
                         const float sc = part == 0 ? qscale : 1.0f;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -978,8 +1017,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_bf16_kernel(float* __restric
                             *reinterpret_cast<s16x8*>(dst + (t4 + 16 * ps) * 32 + pc) = *reinterpret_cast<const s16x8*>(tl + (t4 + 16 * ps) * 40 + pc);
                         fs_wave_lds_fence();
                     } else {           // plain: D[token][feature] -- a lane holds 16 keys of ONE feature, in the planes' key order
-#pragma unroll
-                        for (int f = 0; f < 16; ++f) acc = mma32x32(yk[f], frag(sb, f), acc);
+                        QS_ALL(QS_PLAIN)
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2)
                             *reinterpret_cast<s16x8*>(tl + rq * 40 + 16 * g2 + 8 * hq) =
