@@ -1112,6 +1112,69 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     if (lane == 0) { samples[n] = sample; conf[n] = cf; }
 }
 
+// The same for token-major logits with vf = 64 PER: a lane's PER consecutive logits arrive as 16-byte loads and stay in registers
+// for the three passes (sample_kernel issues PER 4-byte loads at a 4 PER-byte lane stride per pass: 16 lines touched per
+// instruction for 2 lines of data).  Same operations in the same order: bit-identical samples and confidences.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int PER>
+__global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restrict__ logits, long n_tok, long V, int vf, int nfac,
+                                                          float temperature, const float* __restrict__ uniforms,
+                                                          int64_t* __restrict__ samples, float* __restrict__ conf) {
+    static_assert(PER % 4 == 0, "16-byte loads");
+    const int lane = threadIdx.x & 63;
+    const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    const float* lp = logits + (size_t)n * V;
+    int64_t sample = 0;
+    float cf = 1.0f;
+    for (int k = 0; k < nfac; ++k) {
+        const int f = nfac - 1 - k;  // flip(2): hi factor first (:179)
+        const float* lf = lp + (size_t)f * vf;
+        float v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(lf + lane * PER + q);
+            v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
+        }
+        float mx = -INFINITY;
+        int mi = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            if (v[q] > mx) { mx = v[q]; mi = lane * PER + q; }
+        wave_argmax(mx, mi);
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) part += expf(v[q] - mx);
+        const float tot = wave_sum(part);
+        int pick = mi;
+        float p = 1.0f / tot;
+        if (temperature > 1e-8f) {
+            const float u = uniforms[(size_t)k * n_tok + n] * tot;
+            float incl = part;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            float run = incl - part;
+            int cntl = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                run += expf(v[q] - mx);
+                cntl += (run < u) ? 1 : 0;
+            }
+            int total = cntl;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+            pick = total < vf - 1 ? total : vf - 1;
+            p = expf(lf[pick] - mx) / tot;
+        }
+        sample = sample * vf + pick;
+        cf *= p;
+    }
+    if (lane == 0) { samples[n] = sample; conf[n] = cf; }
+}
+
 int launch_sample(const genie_cfg& c, const float* logits, int layout, int B, float temperature,
                   const float* uniforms, int64_t* samples, float* conf, hipStream_t st) {
     long V = (long)c.factored_vocab * c.num_factored;
@@ -1119,6 +1182,12 @@ int launch_sample(const genie_cfg& c, const float* logits, int layout, int B, fl
     if (layout == GENIE_LAYOUT_TOKEN_MAJOR) { sb = (long)c.S * V; ss = V; vs = 1; }
     else { sb = (long)c.S * V; ss = 1; vs = c.S; }
     long n = (long)B * c.S;
+    if (layout == GENIE_LAYOUT_TOKEN_MAJOR && c.factored_vocab == 512 && ((uintptr_t)logits & 15) == 0) {
+        sample_rows_kernel<8><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(logits, n, V, c.factored_vocab, c.num_factored, temperature,
+                                                                       uniforms, samples, conf);
+        GENIE_LAUNCH_CHECK("sample_rows");
+        return GENIE_OK;
+    }
     sample_kernel<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(logits, sb, ss, vs, B, c.S, c.factored_vocab,
                                                             c.num_factored, temperature, uniforms, samples, conf);
     GENIE_LAUNCH_CHECK("sample");

@@ -413,3 +413,34 @@ def test_sample_temperature_distribution(golden):
         assert abs(fj - pj) < 6 * (pj * (1 - pj) / N) ** 0.5
         want = (p_hi[hi] * p_lo[lo]).float()
         assert (conf.view(-1) - want).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("temperature", [0.0, 0.8])
+def test_sample_row_kernel_equals_strided_kernel(temperature):
+    """Token-major logits of the 512-entry factored vocabularies take sample_rows_kernel (16-byte loads, values kept in registers);
+    the same logits in the reference's (B, V, S) layout take the strided kernel.  Same operations in the same order: samples and
+    confidences bit-identical (st_mask_git.py:171-190), argmax and inverse-CDF draws alike; ties included (duplicated maxima)."""
+    lib = pkg("_lib")
+    L = lib.load()
+    cfg = pkg("config").GenieConfig(num_layers=1, num_heads=2, d_model=64, T=4, S=256, num_factored_vocabs=2, qk_norm=False, use_mup=False)
+    c = lib.make_cfg(cfg, lib.PREC_EXACT)
+    g = np.random.default_rng(23)
+    R, S, Vf = 9, cfg.S, 512
+    logits = (g.standard_normal((R, S, 2 * Vf)) * 2.5).astype(np.float32)
+    logits[0, :, 100] = logits[0, :, 300] = 20.0       # ties: the first maximum wins in both kernels
+    logits[1, :, Vf + 7] = logits[1, :, Vf + 8] = 19.0
+    uni = g.random((2, R, S), dtype=np.float32)
+    d_tok, d_uni = dev(logits), dev(uni)
+    d_bvs = d_tok.permute(0, 2, 1).contiguous()         # (B, V, S)
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for name, buf, layout in (("rows", d_tok, lib.LAYOUT_TOKEN_MAJOR), ("strided", d_bvs, lib.LAYOUT_BCTHW)):
+        samples = torch.empty(R, S, dtype=torch.int64, device="cuda")
+        conf = torch.empty(R, S, dtype=torch.float32, device="cuda")
+        lib.check(L.genie_sample(c, buf.data_ptr(), layout, R, temperature, d_uni.data_ptr(), samples.data_ptr(), conf.data_ptr(), st),
+                  "genie_sample")
+        out[name] = (samples.cpu().numpy(), conf.cpu().numpy())
+    assert np.array_equal(out["rows"][0], out["strided"][0])
+    assert np.array_equal(out["rows"][1].view(np.uint32), out["strided"][1].view(np.uint32))
+    if temperature == 0.0:
+        assert (out["rows"][0][0] % Vf == 100).all() and (out["rows"][0][1] // Vf == 7).all()
