@@ -468,7 +468,20 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
         // ---- epilogue.  The accumulators hold one COLUMN per lane; each wave transposes its tile through its own 8 KB of
         // the ring's second buffer, 32 rows at a time, and then works on whole rows: 16 lanes x float4 = one 256-byte row
         // segment per quarter-wave for the residual read, the f32 store and the 16-bit operand store.
-        if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0) {
+#ifndef GENIE_VAR_QKV_ABL
+#define GENIE_VAR_QKV_ABL 0    // timing variants (results WRONG): 1 no plane stores, 2 no epilogue at all, 4 plain (not nt) stores
+#endif
+#define QKV_STORE(val, rs, vo, so)                                                                              \
+    do {                                                                                                        \
+        if constexpr ((GENIE_VAR_QKV_ABL & 1) != 0) asm volatile("" ::"v"(val));                                \
+        else __builtin_amdgcn_raw_buffer_store_b128(val, rs, vo, so, (GENIE_VAR_QKV_ABL & 4) ? 0 : 2 /* nt */);  \
+    } while (0)
+        if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0 && (GENIE_VAR_QKV_ABL & 2) != 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[q][j]));
+        } else if constexpr (EPI >= 0 && (EPI & G16X_QKV) != 0) {
             // ---- spatial-attention operand layout (N = 3d, d % 256 == 0, so a 256-column tile is all-Q, all-K or all-V; the
             // 256 rows of a tile are exactly one (clip, frame) sequence).  C16 holds 3*NPL planes of M*d 16-bit values:
             //   [Q planes | K planes | V^T planes], Q and K head-major [(sequence, head)][256 rows][head_dim] with Q multiplied by qscale (= scale * log2 e),
@@ -527,14 +540,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                                            (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16),
                                            (uint32_t)f32_to_bf16(u.x) | ((uint32_t)f32_to_bf16(u.y) << 16),
                                            (uint32_t)f32_to_bf16(u.z) | ((uint32_t)f32_to_bf16(u.w) << 16)};
-                            __builtin_amdgcn_raw_buffer_store_b128(t, rsH, voff, soff, 2 /* nt */);
+                            QKV_STORE(t, rsH, voff, soff);
                         } else {
                             uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
                             split_f16_x4(v.x, v.y, v.z, v.w, h01, h23, l01, l23);
                             split_f16_x4(u.x, u.y, u.z, u.w, h45, h67, l45, l67);
                             const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
-                            __builtin_amdgcn_raw_buffer_store_b128(th, rsH, voff, soff, 2);
-                            __builtin_amdgcn_raw_buffer_store_b128(tl, rsL, voff, soff, 2);
+                            QKV_STORE(th, rsH, voff, soff);
+                            QKV_STORE(tl, rsL, voff, soff);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -578,14 +591,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                                            (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16),
                                            (uint32_t)f32_to_bf16(v4) | ((uint32_t)f32_to_bf16(v5) << 16),
                                            (uint32_t)f32_to_bf16(v6) | ((uint32_t)f32_to_bf16(v7) << 16)};
-                            __builtin_amdgcn_raw_buffer_store_b128(t, rsH, voff, soff, 2 /* nt */);
+                            QKV_STORE(t, rsH, voff, soff);
                         } else {
                             uint32_t h01, h23, l01, l23, h45, h67, l45, l67;
                             split_f16_x4(v0, v1, v2, v3, h01, h23, l01, l23);
                             split_f16_x4(v4, v5, v6, v7, h45, h67, l45, l67);
                             const u4v th = {h01, h23, h45, h67}, tl = {l01, l23, l45, l67};
-                            __builtin_amdgcn_raw_buffer_store_b128(th, rsH, voff, soff, 2);
-                            __builtin_amdgcn_raw_buffer_store_b128(tl, rsL, voff, soff, 2);
+                            QKV_STORE(th, rsH, voff, soff);
+                            QKV_STORE(tl, rsL, voff, soff);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
