@@ -896,11 +896,14 @@ def main():
             with open(pmc) as f:
                 pj = json.load(f)
             pe = pj.get(args.precision, {})
-            g = pe.get("gemm")
+            kname = str(out["roofline"].get("kernel", ""))
+            pmc_class = ("fused_mlp" if "mlp_fused" in kname else "fused_spatial" if "spatial_attn_proj" in kname else
+                         "fused_temporal" if "temporal_" in kname and "fused" in kname else "gemm")   # the class of the roofline's kernel
+            g = pe.get(pmc_class) or pe.get("gemm")
             if g:
                 out["roofline"]["traffic"] = g["hbm_bytes_per_launch_per_clip"] * B
                 out["roofline"]["traffic_source"] = (f"profiles/pmc_bench.json ({pj.get('_source', '')}): FETCH_SIZE x2 "
-                                                     f"(gfx950 correction) + WRITE_SIZE per GEMM launch at {g['clips']} "
+                                                     f"(gfx950 correction) + WRITE_SIZE per launch of that kernel class at {g['clips']} "
                                                      f"clips, scaled linearly to {B} clips; not measured in this run")
                 out["roofline"]["mfma_busy_frac_pmc"] = g.get("mfma_busy_frac")
                 out["roofline"]["sclk_ghz_pmc"] = g.get("sclk_ghz")
