@@ -47,6 +47,7 @@ class Weights(C.Structure):
 
 WIDE_QKV, WIDE_PROJ, WIDE_FC1, WIDE_FC2 = 1, 2, 1, 2          # bits of the w16_wide fields (genie_hip.h)
 FUSED_QKV_STREAM = 4                                        # spatial attention: fused_w16 = [proj stream | qkv stream]
+TEMPORAL_QKV_F16X3_ELEMS = 393216   # f16 values of the f16x3 temporal qkv stream (csrc/kernels_fused_f16x3.hip)
 TEMPORAL_FUSED_ELEMS, MLP_FUSED_ELEMS, SPATIAL_PROJ_FUSED_ELEMS, SPATIAL_QKV_FUSED_ELEMS = 262144, 524288, 65536, 196608        # bf16 values of the fused kernels' weight streams
 ABI_VERSION = 3
 
@@ -124,6 +125,7 @@ SIGNATURES = {
     "genie_profile_kernels": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "genie_study_build": (C.c_int, []),
     "genie_pack_temporal_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
+    "genie_pack_temporal_qkv_f16x3": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "genie_pack_mlp_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_pack_spatial_proj_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "genie_pack_spatial_qkv_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgenie_hip.so")
-SOURCES = ["api.hip", "kernels_exact.hip", "kernels_bf16.hip", "kernels_gemm_pp.hip", "kernels_gemm_sm.hip", "kernels_gemm_tn.hip", "kernels_attn16.hip", "kernels_attn_dma.hip", "kernels_fused.hip", "kernels_fused_prefix.hip", "kernels_frame.hip", "kernels_conv.hip",
+SOURCES = ["api.hip", "kernels_exact.hip", "kernels_bf16.hip", "kernels_gemm_pp.hip", "kernels_gemm_sm.hip", "kernels_gemm_tn.hip", "kernels_attn16.hip", "kernels_attn_dma.hip", "kernels_fused.hip", "kernels_fused_prefix.hip", "kernels_fused_f16x3.hip", "kernels_frame.hip", "kernels_conv.hip",
            "kernels_train.hip", "kernels_train16.hip", "kernels_attn_bwd16.hip", "train_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # per-source extras.  kernels_frame.hip: its launches are a few microseconds long and begin by fetching their arguments -- let the

@@ -826,6 +826,10 @@ int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint
     GENIE_CHECK_ARG(qkv_w && proj_w && dst, "pack_temporal_fused: NULL pointer");
     return launch_pack_temporal_fused(qkv_w, proj_w, dst, as_stream(stream));
 }
+int genie_pack_temporal_qkv_f16x3(const float* qkv_w, uint16_t* dst, void* stream) {
+    GENIE_CHECK_ARG(qkv_w && dst, "pack_temporal_qkv_f16x3: NULL pointer");
+    return launch_pack_temporal_qkv_f16x3(qkv_w, dst, as_stream(stream));
+}
 int genie_temporal_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* x16, float* x, int B, void* stream) {
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(aw && x && B >= 1, "temporal_fused: bad argument");   // x16 == NULL: operands rounded from x itself

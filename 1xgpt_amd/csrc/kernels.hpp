@@ -71,6 +71,13 @@ bool temporal_prefix_fused_takes(const genie_cfg& c, const genie_attn_weights& a
 int launch_temporal_prefix_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, float* x, uint16_t* kv, int B, int mode,
                                       int shift, int model_T, hipStream_t st);
 
+// kernels_fused_f16x3.hip: temporal qkv Linear + temporal attention of the shipped geometry in GENIE_PREC_F16X3 (mode 0 plain, 1 clean pass
+// writing the k / v accumulators to `kv`, 2 masked pass reading them); aw.fused_w16 = the stream of genie_pack_temporal_qkv_f16x3
+bool temporal_qkv_attn_f16x3_takes(const genie_cfg& c, const genie_attn_weights& aw, int B, int model_T, bool cache_mode);
+int launch_temporal_qkv_attn_f16x3(const genie_cfg& c, const genie_attn_weights& aw, const float* x, uint16_t* a16, long plane, float* kv, int B,
+                                   int mode, int shift, int model_T, hipStream_t st);
+int launch_pack_temporal_qkv_f16x3(const float* qkv_w, uint16_t* out, hipStream_t st);
+
 // Study builds only (-DGENIE_STUDY): which Linear of the block the next GEMM launch is, and the layer it belongs to, so that
 // tools/precision_study.py can run individual classes / layer ranges on 2 of the 3 split-f16 terms.
 #ifdef GENIE_STUDY

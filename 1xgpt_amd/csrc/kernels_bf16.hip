@@ -1123,12 +1123,21 @@ int st_block_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, 
     }
     GENIE_TRY(rc);
     GENIE_STUDY_CLASS(2);
+    // the shipped geometry: temporal qkv Linear + attention as one kernel on the f32 rows of x (kernels_fused_f16x3.hip) -- the spatial
+    // out-projection then need not write the split planes of x; in the prefix-cache passes the cache slice holds that kernel's k, v accumulators
+    const bool fused_tq = w.frame_t < 0 && (!w.tqkv || w.tq_frames <= c.T) &&
+                          temporal_qkv_attn_f16x3_takes(c, lw.temporal, B, w.model_T, w.tqkv || w.tcache);
     GENIE_TRY(launch_gemm16<2>(as, d, pd, lw.spatial.proj_w16, d, pw_proj, c.proj_bias ? lw.spatial.proj_b : nullptr, x,
-                               xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | G16_OUT16 | wsp, 1.0f, st));
+                               xs, pd, d, M, d, d, G16_ACCUM | G16_OUTF32 | (fused_tq ? 0 : G16_OUT16) | wsp, 1.0f, st));
     // ---- temporal
     GENIE_STUDY_CLASS(1);
     float* tq = w.tqkv ? w.tqkv : qkv;
-    if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
+    if (fused_tq) {
+        GENIE_TRY(launch_temporal_qkv_attn_f16x3(c, lw.temporal, x, as, (long)pd, w.tqkv ? w.tqkv : const_cast<float*>(w.tcache), B,
+                                                 w.tqkv ? 1 : (w.tcache ? 2 : 0), w.tshift, w.model_T, st));
+        if (w.stop_after_tqkv) return GENIE_OK;
+        rc = GENIE_OK;
+    } else if (w.frame_t >= 0) {  // single-frame decode: qkv -> cache slot frame_t, attend slots 0..frame_t
         float* slot = w.fcache + (size_t)w.frame_t * c.S * 3 * d;
         GENIE_TRY(launch_gemm16<2>(xs, d, pd, lw.temporal.qkv_w16, d, pw_qkv, c.qkv_bias ? lw.temporal.qkv_b : nullptr,
                                    slot, nullptr, 0, 3 * d, c.S, 3 * d, d, G16_OUTF32 | wtq, 1.0f, st, B, (long)c.S * d,

@@ -87,6 +87,15 @@ class _Packer:
                 and os.environ.get("GENIE_NO_FUSED", "0") != "1")
 
     def temporal_fused(self, attn):
+        c = self.config
+        if (self.prec == _lib.PREC_F16X3 and c.d_model == 256 and c.num_heads == 8 and not c.qk_norm and c.T <= 16
+                and os.environ.get("GENIE_NO_FUSED", "0") != "1"):
+            # f16x3: the temporal qkv Linear + attention run as one kernel (csrc/kernels_fused_f16x3.hip) on this split-f16 stream
+            t = torch.empty(_lib.TEMPORAL_QKV_F16X3_ELEMS, dtype=torch.float16, device=self.dev)
+            _lib.check(self.lib.genie_pack_temporal_qkv_f16x3(attn.qkv.weight.data_ptr(), t.data_ptr(), self._stream()),
+                       "genie_pack_temporal_qkv_f16x3")
+            self.keep.append(t)
+            return t.data_ptr()
         if not (self._fused_geometry() and self.config.T == 16):
             return 0
         t = torch.empty(_lib.TEMPORAL_FUSED_ELEMS, dtype=torch.bfloat16, device=self.dev)

@@ -158,6 +158,11 @@ enum { GENIE_WIDE_QKV = 1, GENIE_WIDE_PROJ = 2, GENIE_WIDE_FC1 = 1, GENIE_WIDE_F
 #define GENIE_SPATIAL_QKV_FUSED_ELEMS 196608
 #define GENIE_SPATIAL_FUSED_ELEMS (GENIE_SPATIAL_PROJ_FUSED_ELEMS + GENIE_SPATIAL_QKV_FUSED_ELEMS)
 int genie_pack_temporal_fused_bf16(const float* qkv_w, const float* proj_w, uint16_t* dst, void* stream);
+/* GENIE_PREC_F16X3, same geometry (d 256, 8 heads of 32): the TEMPORAL attention's `fused_w16` holds the split-f16 fragment stream of its
+ * qkv weights (768, 256) f32 -> 393,216 f16 values, and the temporal qkv Linear + temporal attention run as one kernel on the f32 rows of x
+ * (csrc/kernels_fused_f16x3.hip; st_transformer.py:77-78, attention.py:36-58).  No |w| < 32 contract: nothing is scaled. */
+#define GENIE_TEMPORAL_QKV_F16X3_ELEMS 393216
+int genie_pack_temporal_qkv_f16x3(const float* qkv_w, uint16_t* dst, void* stream);
 /* Unit entry points of the fused sub-blocks (parity tests, tuning).  All update the f32 residual stream x in place and return
  * GENIE_E_UNSUPPORTED outside the geometry above or below their size thresholds -- temporal / mlp: 2 clips' worth of rows (8,192), spatial:
  * 128 sequences; measured break-evens, DESIGN.md section 4 -- (the layer drivers then run the unfused launches).
