@@ -66,6 +66,17 @@ __device__ __forceinline__ f32x4 qa_mma(const u32x4& a, const u32x4& b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 qa_mma4(float a, float b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// Fragment reads the compiler does not schedule (it pairs them: read, read, wait, three MFMAs -- one exposed LDS round trip per 48 matrix
+// cycles): qa_lds_rd issues a read it knows nothing about, qa_lds_wait2<N> is "all but my N youngest LDS reads have landed", tied to the
+// two fragments it guards.  LDS reads return in order; anything else outstanding on lgkmcnt only makes the wait stricter.
+template <int OFF>
+__device__ __forceinline__ void qa_lds_rd(u32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void qa_lds_wait2(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
 template <int OFF>
 __device__ __forceinline__ void qa_ld16(f32x4& dst, unsigned voff, const float* base) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(OFF) : "memory");
@@ -225,6 +236,39 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+#ifndef GENIE_VAR_TQA_PF
+#define GENIE_VAR_TQA_PF 0      // 1: hand-issued fragment reads, 4 pairs in flight (measured: 3,937-3,967 vs 3,951-3,960 frames/s on --model c35 f16x3,
+#endif                          // profiles/r05tq_c35_f16x3_ab.txt -- the kernel is bound by LDS bytes, 3.8 MB per workgroup block, not by read latency)
+#if GENIE_VAR_TQA_PF
+                    {   // the stage's 16 fragments (8 pairs hi | lo') through 8 rotating buffers: 4 pairs in flight
+                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)stg;
+                        u32x4 fb[8];
+#define QA_PAIR(i)                                                                                                            \
+    {                                                                                                                         \
+        qa_lds_wait2<(14 - 2 * (i)) < 6 ? (14 - 2 * (i)) : 6>(fb[(2 * (i)) & 7], fb[(2 * (i) + 1) & 7]);                       \
+        const u32x4 whi = fb[(2 * (i)) & 7], wlo = fb[(2 * (i) + 1) & 7];                                                     \
+        constexpr int ft = (i) & 1;                                                                                           \
+        const int ks = 4 * half + ((i) >> 1);                                                                                 \
+        if (part < 2) {                                                                                                       \
+            accm[ft] = qa_mma(whi, xhi[ks], accm[ft]);                                                                        \
+            accc[ft] = qa_mma(whi, xlo[ks], accc[ft]);                                                                        \
+            accc[ft] = qa_mma(wlo, xhi[ks], accc[ft]);                                                                        \
+        } else {                                                                                                              \
+            accm[ft] = qa_mma(xhi[ks], whi, accm[ft]);                                                                        \
+            accc[ft] = qa_mma(xlo[ks], whi, accc[ft]);                                                                        \
+            accc[ft] = qa_mma(xhi[ks], wlo, accc[ft]);                                                                        \
+        }                                                                                                                     \
+        if constexpr (2 * (i) + 8 < 16) {                                                                                     \
+            qa_lds_rd<(2 * (i) + 8) * 1024>(fb[(2 * (i)) & 7], la);                                                           \
+            qa_lds_rd<(2 * (i) + 9) * 1024>(fb[(2 * (i) + 1) & 7], la);                                                       \
+        }                                                                                                                     \
+    }
+                        qa_lds_rd<0>(fb[0], la); qa_lds_rd<1024>(fb[1], la); qa_lds_rd<2048>(fb[2], la); qa_lds_rd<3072>(fb[3], la);
+                        qa_lds_rd<4096>(fb[4], la); qa_lds_rd<5120>(fb[5], la); qa_lds_rd<6144>(fb[6], la); qa_lds_rd<7168>(fb[7], la);
+                        QA_PAIR(0) QA_PAIR(1) QA_PAIR(2) QA_PAIR(3) QA_PAIR(4) QA_PAIR(5) QA_PAIR(6) QA_PAIR(7)
+#undef QA_PAIR
+                    }
+#else
 #pragma unroll
                     for (int ks4 = 0; ks4 < 4; ++ks4)
 #pragma unroll
@@ -241,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
                                 accc[ft] = qa_mma(xhi[ks], wlo, accc[ft]);
                             }
                         }
+#endif
                 }
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {

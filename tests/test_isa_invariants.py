@@ -83,7 +83,7 @@ def test_frame_kernels_have_no_scratch(rows):
 def test_fused_subblock_kernels_have_no_scratch(rows):
     # kernels_fused.hip sits at the 256-register edge (2 workgroups per CU): an innocent-looking edit makes the allocator spill,
     # and a spill in the region loop once cost 2x on the whole forward.  Main loops carry only the counted / region waits.
-    for sub in ("temporal_fused_bf16_kernel<", "temporal_prefix_fused_bf16_kernel<", "mlp_fused_bf16_kernel<"):
+    for sub in ("temporal_fused_bf16_kernel<", "temporal_prefix_fused_bf16_kernel<", "temporal_qkv_attn_f16x3_kernel<", "mlp_fused_bf16_kernel<"):
         for name, r in pick(rows, sub).items():
             assert r[6] == 0, f"{name}: {r[6]} bytes of scratch per lane"
             assert r[7] <= 256 and r[5] >= 64, (name, r)
