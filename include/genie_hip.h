@@ -272,7 +272,9 @@ int genie_compute_logits(const genie_cfg* cfg, const genie_weights* w, const int
  * continue has T frame slots: cache_frames = T).  For the shipped geometry in GENIE_PREC_BF16 (d 256, 8 heads of 32, fused
  * streams present, 8 <= nframes < T, B * S >= 512) such a cache holds, per (clip, position, head), the K and V operand
  * fragments of the fused temporal kernel instead of qkv rows (csrc/kernels_fused_prefix.hip: both passes run the temporal
- * sub-block as one kernel); producer and consumer decide by the same predicate of (cfg, weights, B, nframes). */
+ * sub-block as one kernel), and in GENIE_PREC_F16X3 (same geometry, temporal fused_w16 = the genie_pack_temporal_qkv_f16x3
+ * stream, 11 <= nframes < T) the f32 k / v accumulators of csrc/kernels_fused_f16x3.hip; producer and consumer decide by the
+ * same predicate of (cfg, weights, B, nframes). */
 size_t genie_prefix_cache_bytes(const genie_cfg* cfg, int B);
 int genie_clean_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int nframes, int cache_frames,
                      float* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);
