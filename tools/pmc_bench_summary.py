@@ -14,7 +14,7 @@ from collections import defaultdict
 
 csv.field_size_limit(1 << 30)
 CLASSES = {"gemm": ("gemm16_", "gemm_f32"), "attention_spatial": ("attn_spatial",), "attention_temporal": ("attn_temporal",),
-           "fused_mlp": ("mlp_fused_bf16",), "fused_spatial": ("spatial_attn_proj_bf16",), "fused_temporal": ("temporal_fused_bf16", "temporal_prefix_fused_bf16"),
+           "fused_mlp": ("mlp_fused_bf16",), "fused_spatial": ("spatial_attn_proj_bf16",), "fused_temporal": ("temporal_fused_bf16", "temporal_prefix_fused_bf16", "temporal_qkv_attn_f16x3"),
            "layernorm": ("layer_norm_fast",)}
 
 
