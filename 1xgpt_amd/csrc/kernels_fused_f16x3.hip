@@ -19,7 +19,9 @@
 //   lane-linear into the layer's cache slice (4 KB per clip, position and head); MODE 2 masked passes: loaded back one head ahead,
 //   scores against the cached keys (j < i + shift) and the own key (diagonal), one softmax -- as kernels_fused_prefix.hip.
 // vmcnt bookkeeping as there: an acquire allows for every vector-memory operation issued since the needed stage's loads (the ring's two
-// younger stages + the cached-fragment loads and the output / dump stores of the last three intervals): they retire in order.
+// younger stages + the cached-fragment loads and the output / dump stores of the last three intervals): they retire in order -- loads AND
+// stores on the one vmcnt counter (tools/micro/vmcnt_order_probe.hip: 4.2e8 lane-trials of a cold load followed by 1-6 hot stores and
+// s_waitcnt vmcnt(#stores), none consumed an unlanded load; profiles/r05v_vmcnt_order_probe.txt).
 #include <stdio.h>
 #include <stdlib.h>
 
