@@ -126,6 +126,8 @@ SIGNATURES = {
     "genie_study_build": (C.c_int, []),
     "genie_pack_temporal_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_pack_temporal_qkv_f16x3": (C.c_int, [c_ptr, c_ptr, c_ptr]),
+    "genie_temporal_prefix_fused_bf16": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "genie_temporal_qkv_attn_f16x3": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(AttnWeights), c_ptr, c_ptr, C.c_int64, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "genie_pack_mlp_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "genie_pack_spatial_proj_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "genie_pack_spatial_qkv_fused_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr]),

@@ -830,6 +830,22 @@ int genie_pack_temporal_qkv_f16x3(const float* qkv_w, uint16_t* dst, void* strea
     GENIE_CHECK_ARG(qkv_w && dst, "pack_temporal_qkv_f16x3: NULL pointer");
     return launch_pack_temporal_qkv_f16x3(qkv_w, dst, as_stream(stream));
 }
+int genie_temporal_prefix_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, float* x, uint16_t* kv, int B, int nframes, int mode,
+                                     int shift, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(aw && x && kv && B >= 1 && nframes >= 1, "temporal_prefix_fused: bad argument");
+    genie_cfg c2 = *cfg;
+    c2.T = nframes;   // the pass's frames; cfg->T is the model's
+    return launch_temporal_prefix_fused_bf16(c2, *aw, x, kv, B, mode, shift, cfg->T, as_stream(stream));
+}
+int genie_temporal_qkv_attn_f16x3(const genie_cfg* cfg, const genie_attn_weights* aw, const float* x, uint16_t* a16, int64_t plane_elems,
+                                  float* kv, int B, int nframes, int mode, int shift, void* stream) {
+    GENIE_TRY(check_cfg(cfg));
+    GENIE_CHECK_ARG(aw && x && a16 && B >= 1 && nframes >= 1, "temporal_qkv_attn_f16x3: bad argument");
+    genie_cfg c2 = *cfg;
+    c2.T = nframes;
+    return launch_temporal_qkv_attn_f16x3(c2, *aw, x, a16, (long)plane_elems, kv, B, mode, shift, cfg->T, as_stream(stream));
+}
 int genie_temporal_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* x16, float* x, int B, void* stream) {
     GENIE_TRY(check_cfg(cfg));
     GENIE_CHECK_ARG(aw && x && B >= 1, "temporal_fused: bad argument");   // x16 == NULL: operands rounded from x itself

@@ -178,6 +178,16 @@ int genie_pack_temporal_qkv_f16x3(const float* qkv_w, uint16_t* dst, void* strea
  *             of the result, or -- when next_norm_w / next_norm_b are given -- LayerNorm(result; next_norm_*) in bf16 (the next
  *             block's norm1 output, st_transformer.py:73); needs lw->mlp_fused_w16.  Reference: st_transformer.py:81, 16-25. */
 int genie_temporal_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* x16, float* x, int B, void* stream);
+/* ... of the prefix-cache passes (cfg->T = the model's T, nframes < T the pass's frames; x (B, nframes, S, 256)):
+ *   genie_temporal_prefix_fused_bf16: x += proj_t(attention(qkv_t(x))) in GENIE_PREC_BF16; mode 1 = causal + the K / V fragment images written to
+ *     `kv` (B * S * 16 KB), mode 2 = query slot i attends the images' slots j < i + shift and its own key (evaluate.py:107-116).
+ *   genie_temporal_qkv_attn_f16x3: a = attention(qkv_t(x)) in GENIE_PREC_F16X3 as operand planes a16 = [hi | lo'] `plane_elems` apart, rows
+ *     (B nframes S) x 256; mode 0 = plain causal (nframes <= T, kv unused), 1 / 2 as above with the f32 k / v accumulators in `kv` (B * S * 32 KB).
+ * Reference counterpart: st_transformer.py:77-78, attention.py:36-61.  Tests: tests/test_hip_fused.py, tests/test_hip_fused_f16x3.py. */
+int genie_temporal_prefix_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, float* x, uint16_t* kv, int B, int nframes, int mode,
+                                     int shift, void* stream);
+int genie_temporal_qkv_attn_f16x3(const genie_cfg* cfg, const genie_attn_weights* aw, const float* x, uint16_t* a16, int64_t plane_elems,
+                                  float* kv, int B, int nframes, int mode, int shift, void* stream);
 int genie_spatial_attn_proj_fused_bf16(const genie_cfg* cfg, const genie_attn_weights* aw, const uint16_t* qkv_planes, float* x,
                                        uint16_t* x16, int64_t n_seq, void* stream);
 int genie_mlp_fused_bf16(const genie_cfg* cfg, const genie_layer_weights* lw, float* x, uint16_t* x16_out, int64_t rows,

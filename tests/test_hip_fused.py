@@ -388,3 +388,36 @@ def test_prefix_passes_fused_temporal_matches_unfused(monkeypatch, qkv_bias, n, 
         dc = np.abs(lc - full)
         print("unmasked prefix pass vs full forward: max", dc.max(), "median", np.median(dc))
         assert np.median(dc) < 4e-3 and dc.max() < 8e-2
+
+
+def test_temporal_prefix_fused_entry_point_vs_oracle():
+    """genie_temporal_prefix_fused_bf16 on random operands, 8 clips x 15 frames: mode 1 (clean pass) = x += proj(causal_attention(qkv(x))) over
+    the 15 frames (st_transformer.py:77-78, attention.py:36-61) against the bf16-contract oracle; mode 2 with shift 0 on the SAME input reads the
+    fragment images mode 1 left: slot i sees the cached keys j < i and its own -- which are the clean ones -- so it must reproduce the same update."""
+    _lib, lib, c, cfg, st = _unit_setup()
+    g = np.random.default_rng(12)
+    B, nf, S, D = 8, 15, 256, 256
+    x = (g.standard_normal((B, nf, S, D)) * 1.5).astype(np.float32)
+    sd = {"p.qkv.weight": (g.standard_normal((768, 256)) * 0.06).astype(np.float32),
+          "p.proj.weight": (g.standard_normal((256, 256)) * 0.06).astype(np.float32),
+          "p.proj.bias": (g.standard_normal(256) * 0.05).astype(np.float32)}
+    qw, pw, pb = dev(sd["p.qkv.weight"]), dev(sd["p.proj.weight"]), dev(sd["p.proj.bias"])
+    tf = torch.empty(_lib.TEMPORAL_FUSED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.genie_pack_temporal_fused_bf16(qw.data_ptr(), pw.data_ptr(), tf.data_ptr(), st), "pack")
+    aw = _lib.AttnWeights()
+    aw.fused_w16, aw.proj_b = tf.data_ptr(), pb.data_ptr()
+    kv = torch.zeros(B * S * 16 * 1024, dtype=torch.uint8, device="cuda")
+    x1 = dev(x)
+    _lib.check(lib.genie_temporal_prefix_fused_bf16(cfg, aw, x1.data_ptr(), kv.data_ptr(), B, nf, 1, 0, st), "mode 1")
+    x2 = dev(x)
+    _lib.check(lib.genie_temporal_prefix_fused_bf16(cfg, aw, x2.data_ptr(), kv.data_ptr(), B, nf, 2, 0, st), "mode 2")
+    x_tc = x.transpose(0, 2, 1, 3).reshape(B * S, nf, D)
+    ref = x_tc + O.self_attention(x_tc, sd, "p.", c, True, O.BF16_MFMA, chunk=4096)
+    ref = ref.reshape(B, S, nf, D).transpose(0, 2, 1, 3)
+    upd = np.abs(ref - x).max()
+    for name, got in (("mode 1", x1.cpu().numpy()), ("mode 2", x2.cpu().numpy())):
+        d = np.abs(got - ref)
+        print(name, "update", upd, "max err", d.max(), "median", np.median(d))
+        assert np.isfinite(got).all() and d.max() < 2e-2 * upd and np.median(d) < 1e-3 * upd
+    # the pass must have fewer frames than the model (a full-length cache is genie_frame_pass's): refused, nothing computed
+    assert lib.genie_temporal_prefix_fused_bf16(cfg, aw, x1.data_ptr(), kv.data_ptr(), B, 16, 1, 0, st) != 0

@@ -125,3 +125,45 @@ def test_prefix_passes_fused_temporal_matches_unfused(monkeypatch, qkv_bias, n, 
         dc = np.abs(lc - full)
         print("unmasked prefix pass vs full forward: max", dc.max(), "median", np.median(dc))
         assert dc.max() < 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("nf", [16, 13])
+def test_temporal_qkv_attn_entry_point_vs_oracle(nf):
+    """genie_temporal_qkv_attn_f16x3 on random operands, 6 clips: a = causal_attention_T(qkv_t(x)) (attention.py:36-58) as [hi | lo'] planes
+    against the oracle's f16x3 contract (split Linear operands, f32 everything else) with an identity out-projection -- the oracle then
+    returns the 22-bit rounding of the attention output, which is what the planes hold.  nf = 13: modes 1 and 2 (shift 0 on the same input:
+    the cached keys ARE the own ones) must reproduce mode 0's result; phantom frame slots."""
+    from oracle import genie_oracle as O
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    c = pkg("config").c35()
+    cfg = _lib.make_cfg(c, _lib.PREC_F16X3)
+    st = torch.cuda.current_stream().cuda_stream
+    g = np.random.default_rng(13)
+    B, S, D = 6, 256, 256
+    x = (g.standard_normal((B, nf, S, D)) * 1.5).astype(np.float32)
+    sd = {"p.qkv.weight": (g.standard_normal((768, 256)) * 0.06).astype(np.float32), "p.proj.weight": np.eye(256, dtype=np.float32)}
+    qw = dev(sd["p.qkv.weight"])
+    ts = torch.empty(_lib.TEMPORAL_QKV_F16X3_ELEMS, dtype=torch.float16, device="cuda")
+    _lib.check(lib.genie_pack_temporal_qkv_f16x3(qw.data_ptr(), ts.data_ptr(), st), "pack")
+    aw = _lib.AttnWeights()
+    aw.fused_w16 = ts.data_ptr()
+    M = B * nf * S
+    xd = dev(x)
+    kv = torch.zeros(B * S * 8 * 1024, dtype=torch.float32, device="cuda")
+    x_tc = x.transpose(0, 2, 1, 3).reshape(B * S, nf, D)
+    import dataclasses
+    cc = dataclasses.replace(c, proj_bias=False)   # (the identity out-projection of this test has no bias)
+    ref = O.self_attention(x_tc, sd, "p.", cc, True, O.F16X3, chunk=4096).reshape(B, S, nf, D).transpose(0, 2, 1, 3)
+    scale = np.abs(ref).max()
+    modes = [0] if nf == 16 else [0, 1, 2]
+    for mode in modes:
+        planes = torch.zeros(2, M, D, dtype=torch.float16, device="cuda")
+        _lib.check(lib.genie_temporal_qkv_attn_f16x3(cfg, aw, xd.data_ptr(), planes.data_ptr(), M * D, kv.data_ptr(), B, nf, mode, 0, st), f"mode {mode}")
+        got = (planes[0].float() + planes[1].float() / 2048.0).cpu().numpy().reshape(B, nf, S, D)
+        d = np.abs(got - ref)
+        print("mode", mode, "max err", d.max(), "median", np.median(d), "scale", scale)
+        assert np.isfinite(got).all() and d.max() < 3e-5 * scale and np.median(d) < 2e-6 * scale
+    # a cache pass needs 11 <= nframes < T: refused otherwise, nothing computed
+    planes = torch.zeros(2, M, D, dtype=torch.float16, device="cuda")
+    assert lib.genie_temporal_qkv_attn_f16x3(cfg, aw, xd.data_ptr(), planes.data_ptr(), M * D, kv.data_ptr(), B, nf, 1, 0, st) == (0 if nf == 13 else _lib.E_UNSUPPORTED)
