@@ -114,12 +114,14 @@ int launch_pack_temporal_qkv_f16x3(const float* qkv_w, uint16_t* out, hipStream_
 
 // x: (B, nf, S, 256) f32 (read only).  a16: the attention output's operand planes, (B nf S) x 256 row-major, [hi | lo'] `plane` elements apart.
 // kv: this layer's cache slice, [(b S + s) 8 + head][k tile 0 | k tile 1 | v tile 0 | v tile 1][64 lanes][4] floats (MODE 1 written, MODE 2 read).
-// A block = 4 consecutive spatial positions of one clip x 16 frame slots; wave w owns position w.
-template <bool QKV_BIAS, int MODE>
+// A block = 4 G consecutive spatial positions of one clip x 16 frame slots; wave w owns positions G w .. G w + G - 1.  G = 2 (every weight
+// fragment read from LDS feeds two groups: the kernel is bound by LDS bytes) where the registers allow: no bias, no cached accumulators.
+template <bool QKV_BIAS, int MODE, int G>
 __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wstream,
                                                                          const float* __restrict__ qkv_b, uint16_t* __restrict__ a16,
                                                                          long plane, float* __restrict__ kv, int n_blocks, int S, int nf,
                                                                          int sh, float scale_log2e) {
+    static_assert(G == 1 || (MODE != 2 && !QKV_BIAS), "two groups per wave: registers");
     constexpr int D = 256, NH = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -164,20 +166,23 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
     issue_stage();
     issue_stage();
 
-    const int bps = S / 4;  // blocks per clip
+    const int bps = S / (4 * G);  // blocks per clip
     // row-major side of the operand load: lane -> frame slots tt and 8 + tt, columns 4 (lane & 7) .. + 3 of a 32-column slab
     int tt = lane >> 3, cc = (lane & 7) * 4;
     asm volatile("" : "+v"(tt), "+v"(cc));
     const int fa = tt < nf ? tt : nf - 1, fb = 8 + tt < nf ? 8 + tt : nf - 1;
+    const int dab = (fb - fa) * S * D;   // the second frame slot's row, relative to the first's (one register instead of a second pointer)
     float* tile = reinterpret_cast<float*>(smem + QA_RING + 4096 + wid * 2304);   // 16 x 36 floats
 
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int b = blk / bps, s = (blk - b * bps) * 4 + wid;
-        const float* xa = x + (((size_t)b * nf + fa) * S + s) * D + cc;
-        const float* xb = x + (((size_t)b * nf + fb) * S + s) * D + cc;
-        float* kvw = kv + ((size_t)b * S + s) * (NH * 1024);   // this wave's position: 32 KB, wave-uniform
+        const int b = blk / bps, s0 = (blk - b * bps) * (4 * G) + wid * G;   // group grp = position s0 + grp
+        int lane_off = fa * S * D + cc;      // (lane-dependent address parts are formed per block behind an empty asm: hoisted out of the
+        asm volatile("" : "+v"(lane_off));   // persistent loop they are 64-bit values that live -- or spill -- across the whole main loop)
+        const float* xa = x + ((size_t)b * nf * S + s0) * D + lane_off;
+        const float* xb = xa + dab;
+        float* kvw = kv + ((size_t)b * S + s0) * (NH * 1024);   // the wave's positions: 32 KB each, wave-uniform
 
-        f32x4 kc[2][2], vc[2][2];   // [head parity][feature tile]   cached k, v accumulators (MODE 2)
+        f32x4 kc[2][2], vc[2][2];   // [head parity][feature tile]   cached k, v accumulators (MODE 2; one group)
         if constexpr (MODE == 2) {
             qa_ld16<0>(kc[0][0], voff, kvw);
             qa_ld16<1024>(kc[0][1], voff, kvw);
@@ -185,22 +190,23 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
             qa_ld16<3072>(vc[0][1], voff, kvw);
         }
 
-        u32x4 xhi[8], xlo[8];
+        u32x4 xhi[G][8], xlo[G][8];
         {
-            f32x4 raw[8][2];
-            auto load_slab = [&](int i) {   // K-step i: columns 32 i ..
-                raw[i][0] = *reinterpret_cast<const f32x4*>(xa + 32 * i);
-                raw[i][1] = *reinterpret_cast<const f32x4*>(xb + 32 * i);
+            f32x4 raw[8 * G][2];
+            auto load_slab = [&](int i) {   // slab i = (group i >> 3, K-step i & 7: columns 32 (i & 7) ..)
+                raw[i][0] = *reinterpret_cast<const f32x4*>(xa + (i >> 3) * D + 32 * (i & 7));
+                raw[i][1] = *reinterpret_cast<const f32x4*>(xb + (i >> 3) * D + 32 * (i & 7));
             };
 #pragma unroll
             for (int i = 0; i < 4; ++i) load_slab(i);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i + 4 < 8) load_slab(i + 4);
+            for (int i = 0; i < 8 * G; ++i) {
+                if (i + 4 < 8 * G) load_slab(i + 4);
                 *reinterpret_cast<f32x4*>(tile + tt * 36 + cc) = raw[i][0];
                 *reinterpret_cast<f32x4*>(tile + (8 + tt) * 36 + cc) = raw[i][1];
                 qa_wave_lds_fence();
-                qa_split8(*reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * g), *reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * g + 4), xhi[i], xlo[i]);
+                qa_split8(*reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * g), *reinterpret_cast<const f32x4*>(tile + r * 36 + 8 * g + 4),
+                          xhi[i >> 3][i & 7], xlo[i >> 3][i & 7]);
                 qa_wave_lds_fence();
             }
             qa_wait_vm<0>();   // (also the ring's run-ahead stages, the previous block's stores and MODE 2's first cached accumulators)
@@ -209,10 +215,10 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
 
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            f32x4 qv[2], kk[2], vv[2];
+            f32x4 qv[G][2], kk[G][2], vv[G][2];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                f32x4 accm[2], accc[2];
+                f32x4 accm[G][2], accc[G][2];
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
                     f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
@@ -221,8 +227,11 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
                         if (part < 2) b0 = *reinterpret_cast<const f32x4*>(bp + 4 * g);  // lane holds features 4 g .. 4 g + 3 of the tile
                         else b0 = f32x4{bp[r], bp[r], bp[r], bp[r]};                     // lane holds feature r
                     }
-                    accm[ft] = b0;
-                    accc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int grp = 0; grp < G; ++grp) {
+                        accm[grp][ft] = b0;
+                        accc[grp][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -238,73 +247,52 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-#ifndef GENIE_VAR_TQA_PF
-#define GENIE_VAR_TQA_PF 0      // 1: hand-issued fragment reads, 4 pairs in flight (measured: 3,937-3,967 vs 3,951-3,960 frames/s on --model c35 f16x3,
-#endif                          // profiles/r05tq_c35_f16x3_ab.txt -- the kernel is bound by LDS bytes, 3.8 MB per workgroup block, not by read latency)
-#if GENIE_VAR_TQA_PF
-                    {   // the stage's 16 fragments (8 pairs hi | lo') through 8 rotating buffers: 4 pairs in flight
-                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)stg;
-                        u32x4 fb[8];
-#define QA_PAIR(i)                                                                                                            \
-    {                                                                                                                         \
-        qa_lds_wait2<(14 - 2 * (i)) < 6 ? (14 - 2 * (i)) : 6>(fb[(2 * (i)) & 7], fb[(2 * (i) + 1) & 7]);                       \
-        const u32x4 whi = fb[(2 * (i)) & 7], wlo = fb[(2 * (i) + 1) & 7];                                                     \
-        constexpr int ft = (i) & 1;                                                                                           \
-        const int ks = 4 * half + ((i) >> 1);                                                                                 \
-        if (part < 2) {                                                                                                       \
-            accm[ft] = qa_mma(whi, xhi[ks], accm[ft]);                                                                        \
-            accc[ft] = qa_mma(whi, xlo[ks], accc[ft]);                                                                        \
-            accc[ft] = qa_mma(wlo, xhi[ks], accc[ft]);                                                                        \
-        } else {                                                                                                              \
-            accm[ft] = qa_mma(xhi[ks], whi, accm[ft]);                                                                        \
-            accc[ft] = qa_mma(xlo[ks], whi, accc[ft]);                                                                        \
-            accc[ft] = qa_mma(xhi[ks], wlo, accc[ft]);                                                                        \
-        }                                                                                                                     \
-        if constexpr (2 * (i) + 8 < 16) {                                                                                     \
-            qa_lds_rd<(2 * (i) + 8) * 1024>(fb[(2 * (i)) & 7], la);                                                           \
-            qa_lds_rd<(2 * (i) + 9) * 1024>(fb[(2 * (i) + 1) & 7], la);                                                       \
-        }                                                                                                                     \
-    }
-                        qa_lds_rd<0>(fb[0], la); qa_lds_rd<1024>(fb[1], la); qa_lds_rd<2048>(fb[2], la); qa_lds_rd<3072>(fb[3], la);
-                        qa_lds_rd<4096>(fb[4], la); qa_lds_rd<5120>(fb[5], la); qa_lds_rd<6144>(fb[6], la); qa_lds_rd<7168>(fb[7], la);
-                        QA_PAIR(0) QA_PAIR(1) QA_PAIR(2) QA_PAIR(3) QA_PAIR(4) QA_PAIR(5) QA_PAIR(6) QA_PAIR(7)
-#undef QA_PAIR
-                    }
-#else
+                    // (hand-issued fragment reads, 4 pairs in flight, were measured on the one-group form: 3,937-3,967 vs 3,951-3,960 frames/s on
+                    // --model c35 f16x3, profiles/r05tq_c35_f16x3_ab.txt -- the kernel is bound by LDS bytes, not by read latency)
 #pragma unroll
                     for (int ks4 = 0; ks4 < 4; ++ks4)
 #pragma unroll
                         for (int ft = 0; ft < 2; ++ft) {
                             const u32x4 whi = frag(stg, (ks4 * 2 + ft) * 2), wlo = frag(stg, (ks4 * 2 + ft) * 2 + 1);
                             const int ks = 4 * half + ks4;
-                            if (part < 2) {
-                                accm[ft] = qa_mma(whi, xhi[ks], accm[ft]);
-                                accc[ft] = qa_mma(whi, xlo[ks], accc[ft]);
-                                accc[ft] = qa_mma(wlo, xhi[ks], accc[ft]);
-                            } else {
-                                accm[ft] = qa_mma(xhi[ks], whi, accm[ft]);
-                                accc[ft] = qa_mma(xlo[ks], whi, accc[ft]);
-                                accc[ft] = qa_mma(xhi[ks], wlo, accc[ft]);
+#pragma unroll
+                            for (int grp = 0; grp < G; ++grp) {
+                                if (part < 2) {
+                                    accm[grp][ft] = qa_mma(whi, xhi[grp][ks], accm[grp][ft]);
+                                    accc[grp][ft] = qa_mma(whi, xlo[grp][ks], accc[grp][ft]);
+                                    accc[grp][ft] = qa_mma(wlo, xhi[grp][ks], accc[grp][ft]);
+                                } else {
+                                    accm[grp][ft] = qa_mma(xhi[grp][ks], whi, accm[grp][ft]);
+                                    accc[grp][ft] = qa_mma(xlo[grp][ks], whi, accc[grp][ft]);
+                                    accc[grp][ft] = qa_mma(xhi[grp][ks], wlo, accc[grp][ft]);
+                                }
                             }
                         }
-#endif
                 }
 #pragma unroll
-                for (int ft = 0; ft < 2; ++ft) {
-                    const f32x4 val = accm[ft] + accc[ft] * (1.0f / 2048.0f);
-                    if (part == 0) qv[ft] = val;
-                    else if (part == 1) kk[ft] = val;
-                    else vv[ft] = val;
-                }
+                for (int grp = 0; grp < G; ++grp)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) {
+                        const f32x4 val = accm[grp][ft] + accc[grp][ft] * (1.0f / 2048.0f);
+                        if (part == 0) qv[grp][ft] = val;
+                        else if (part == 1) kk[grp][ft] = val;
+                        else vv[grp][ft] = val;
+                    }
                 if constexpr (MODE == 1) {   // dump the accumulators (lane-linear: whole lines)
-                    if (part == 1) {
-                        *reinterpret_cast<f32x4*>(kvw + h * 1024 + lane * 4) = kk[0];
-                        *reinterpret_cast<f32x4*>(kvw + h * 1024 + 256 + lane * 4) = kk[1];
-                        ex2 += 2;
-                    } else if (part == 2) {
-                        *reinterpret_cast<f32x4*>(kvw + h * 1024 + 512 + lane * 4) = vv[0];
-                        *reinterpret_cast<f32x4*>(kvw + h * 1024 + 768 + lane * 4) = vv[1];
-                        ex2 += 2;
+#pragma unroll
+                    for (int grp = 0; grp < G; ++grp) {
+                        int l4 = lane * 4;
+                        asm volatile("" : "+v"(l4));   // (formed here: see lane_off)
+                        float* kd = kvw + grp * (NH * 1024) + h * 1024 + l4;
+                        if (part == 1) {
+                            *reinterpret_cast<f32x4*>(kd) = kk[grp][0];
+                            *reinterpret_cast<f32x4*>(kd + 256) = kk[grp][1];
+                            ex2 += 2;
+                        } else if (part == 2) {
+                            *reinterpret_cast<f32x4*>(kd + 512) = vv[grp][0];
+                            *reinterpret_cast<f32x4*>(kd + 768) = vv[grp][1];
+                            ex2 += 2;
+                        }
                     }
                 }
             }
@@ -312,73 +300,77 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_f16x3_kernel(const f
                 // this head's cached accumulators landed at least three acquires ago (header); from here on they are ordinary values
                 asm volatile("" : "+v"(kc[h & 1][0]), "+v"(kc[h & 1][1]), "+v"(vc[h & 1][0]), "+v"(vc[h & 1][1]));
             }
-            // attention over the frame slots (attention.py:48-58), f32: lane = query frame r, keys 4 g + e
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft)
+            for (int grp = 0; grp < G; ++grp) {
+                // attention over the frame slots (attention.py:48-58), f32: lane = query frame r, keys 4 g + e
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    st = qa_mma4(MODE == 2 ? kc[h & 1][ft][e] : kk[ft][e], qv[ft][e], st);
-                    if constexpr (MODE == 2) so = qa_mma4(kk[ft][e], qv[ft][e], so);   // own keys: the diagonal is used
-                }
-            float mx = -INFINITY;
+                for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = 4 * g + e;
-                if constexpr (MODE == 2) {
-                    if (j >= r + sh || j >= nf) st[e] = -INFINITY;   // cached clip frames strictly before the query's
-                    if (j != r) so[e] = -INFINITY;
-                    mx = fmaxf(mx, so[e]);
-                } else {
-                    if (j > r) st[e] = -INFINITY;
-                }
-                mx = fmaxf(mx, st[e]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mxs = mx * scale_log2e;
-            float sum = 0.f;
-            f32x4 p, po;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                p[e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, -mxs));
-                sum += p[e];
-                if constexpr (MODE == 2) {
-                    po[e] = __builtin_amdgcn_exp2f(fmaf(so[e], scale_log2e, -mxs));
-                    sum += po[e];
-                }
-            }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            f32x4 o[2];
-#pragma unroll
-            for (int ft = 0; ft < 2; ++ft) {
-                o[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; ++e) {
+                        st = qa_mma4(MODE == 2 ? kc[h & 1][ft][e] : kk[grp][ft][e], qv[grp][ft][e], st);
+                        if constexpr (MODE == 2) so = qa_mma4(kk[grp][ft][e], qv[grp][ft][e], so);   // own keys: the diagonal is used
+                    }
+                float mx = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[ft] = qa_mma4(MODE == 2 ? vc[h & 1][ft][e] : vv[ft][e], p[e], o[ft]);
-                    if constexpr (MODE == 2) o[ft] = qa_mma4(vv[ft][e], po[e], o[ft]);
+                    const int j = 4 * g + e;
+                    if constexpr (MODE == 2) {
+                        if (j >= r + sh || j >= nf) st[e] = -INFINITY;   // cached clip frames strictly before the query's
+                        if (j != r) so[e] = -INFINITY;
+                        mx = fmaxf(mx, so[e]);
+                    } else {
+                        if (j > r) st[e] = -INFINITY;
+                    }
+                    mx = fmaxf(mx, st[e]);
                 }
-                o[ft] *= inv;
-            }
-            // the head's 32 output features of the wave's 16 tokens -> the proj GEMM's operand planes, row-major through the tile
-            *reinterpret_cast<f32x4*>(tile + r * 36 + 4 * g) = o[0];
-            *reinterpret_cast<f32x4*>(tile + r * 36 + 16 + 4 * g) = o[1];
-            qa_wave_lds_fence();
-            {
-                int t2 = lane >> 2, c8 = (lane & 3) * 8;
-                const f32x4 va = *reinterpret_cast<const f32x4*>(tile + t2 * 36 + c8), vb2 = *reinterpret_cast<const f32x4*>(tile + t2 * 36 + c8 + 4);
-                u32x4 hi, lo;
-                qa_split8(va, vb2, hi, lo);
-                uint16_t* dst = a16 + (((size_t)b * nf + t2) * S + s) * D + h * 32 + c8;
-                if (t2 < nf) {
-                    *reinterpret_cast<u32x4*>(dst) = hi;
-                    *reinterpret_cast<u32x4*>(dst + plane) = lo;
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mxs = mx * scale_log2e;
+                float sum = 0.f;
+                f32x4 p, po;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, -mxs));
+                    sum += p[e];
+                    if constexpr (MODE == 2) {
+                        po[e] = __builtin_amdgcn_exp2f(fmaf(so[e], scale_log2e, -mxs));
+                        sum += po[e];
+                    }
                 }
-                ex2 += 2;
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+                f32x4 o[2];
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    o[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[ft] = qa_mma4(MODE == 2 ? vc[h & 1][ft][e] : vv[grp][ft][e], p[e], o[ft]);
+                        if constexpr (MODE == 2) o[ft] = qa_mma4(vv[grp][ft][e], po[e], o[ft]);
+                    }
+                    o[ft] *= inv;
+                }
+                // the head's 32 output features of the group's 16 tokens -> the proj GEMM's operand planes, row-major through the tile
+                *reinterpret_cast<f32x4*>(tile + r * 36 + 4 * g) = o[0];
+                *reinterpret_cast<f32x4*>(tile + r * 36 + 16 + 4 * g) = o[1];
+                qa_wave_lds_fence();
+                {
+                    int t2 = lane >> 2, c8 = (lane & 3) * 8;
+                    asm volatile("" : "+v"(t2), "+v"(c8));
+                    const f32x4 va = *reinterpret_cast<const f32x4*>(tile + t2 * 36 + c8), vb2 = *reinterpret_cast<const f32x4*>(tile + t2 * 36 + c8 + 4);
+                    u32x4 hi, lo;
+                    qa_split8(va, vb2, hi, lo);
+                    uint16_t* dst = a16 + ((size_t)b * nf * S + s0 + grp) * D + h * 32 + (t2 * S * D + c8);
+                    if (t2 < nf) {
+                        *reinterpret_cast<u32x4*>(dst) = hi;
+                        *reinterpret_cast<u32x4*>(dst + plane) = lo;
+                    }
+                    ex2 += 2;
+                }
+                qa_wave_lds_fence();
             }
-            qa_wave_lds_fence();
         }
     }
     qa_wait_vm<0>();  // the ring's run-ahead stages must not outlive the workgroup's LDS allocation
@@ -405,7 +397,12 @@ int launch_temporal_qkv_attn_f16x3(const genie_cfg& c, const genie_attn_weights&
                                    int mode, int shift, int model_T, hipStream_t st) {
     if (!temporal_qkv_attn_f16x3_takes(c, aw, B, model_T, mode != 0)) return GENIE_E_UNSUPPORTED;
     GENIE_CHECK_ARG(x && a16 && (mode == 0 || kv) && mode >= 0 && mode <= 2 && (shift == 0 || shift == 1), "temporal_qkv_attn_f16x3: bad argument");
-    const int n_blocks = B * c.S / 4;
+    const bool qb = c.qkv_bias && aw.qkv_b;
+#ifndef GENIE_VAR_TQA_G2
+#define GENIE_VAR_TQA_G2 1     // two 16-token groups per wave where the registers allow (plain / clean pass, no qkv bias)
+#endif
+    const int G = (GENIE_VAR_TQA_G2 && mode != 2 && !qb && c.S % 8 == 0) ? 2 : 1;
+    const int n_blocks = B * c.S / (4 * G);
     static const int cus = [] {
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
@@ -420,18 +417,17 @@ int launch_temporal_qkv_attn_f16x3(const genie_cfg& c, const genie_attn_weights&
                                : "temporal_qkv_attn_f16x3_kernel<2> (masked pass: qkv + attention over cached accumulators)");
     const size_t lds = QA_RING + 4096 + 4 * 2304;   // ring, bias, one 16 x 36-float tile per wave
     const float sl2e = c.attn_scale * 1.4426950408889634f;
-    const bool qb = c.qkv_bias && aw.qkv_b;
-#define QA_LAUNCH(QB_, MODE_)                                                                                                            \
+#define QA_LAUNCH(QB_, MODE_, G_)                                                                                                            \
     do {                                                                                                                                 \
-        static const hipError_t once = hipFuncSetAttribute((const void*)temporal_qkv_attn_f16x3_kernel<QB_, MODE_>,                      \
+        static const hipError_t once = hipFuncSetAttribute((const void*)temporal_qkv_attn_f16x3_kernel<QB_, MODE_, G_>,                      \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
         (void)once;                                                                                                                      \
-        temporal_qkv_attn_f16x3_kernel<QB_, MODE_><<<grid, 256, lds, st>>>(x, aw.fused_w16, QB_ ? aw.qkv_b : nullptr, a16, plane, kv,   \
+        temporal_qkv_attn_f16x3_kernel<QB_, MODE_, G_><<<grid, 256, lds, st>>>(x, aw.fused_w16, QB_ ? aw.qkv_b : nullptr, a16, plane, kv,   \
                                                                             n_blocks, c.S, c.T, shift, sl2e);                            \
     } while (0)
-    if (mode == 0) { if (qb) QA_LAUNCH(true, 0); else QA_LAUNCH(false, 0); }
-    else if (mode == 1) { if (qb) QA_LAUNCH(true, 1); else QA_LAUNCH(false, 1); }
-    else { if (qb) QA_LAUNCH(true, 2); else QA_LAUNCH(false, 2); }
+    if (mode == 0) { if (qb) QA_LAUNCH(true, 0, 1); else if (G == 2) QA_LAUNCH(false, 0, 2); else QA_LAUNCH(false, 0, 1); }
+    else if (mode == 1) { if (qb) QA_LAUNCH(true, 1, 1); else if (G == 2) QA_LAUNCH(false, 1, 2); else QA_LAUNCH(false, 1, 1); }
+    else { if (qb) QA_LAUNCH(true, 2, 1); else QA_LAUNCH(false, 2, 1); }
 #undef QA_LAUNCH
     GENIE_LAUNCH_CHECK("temporal_qkv_attn_f16x3");
     return GENIE_OK;
