@@ -87,6 +87,7 @@ SIGNATURES = {
                                    c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "genie_frames_pass": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_size_t,
                                     c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "genie_generate_workspace_bytes": (C.c_size_t, [C.POINTER(GenieCfg), C.c_int, C.c_int]),
     "genie_generate_cached": (C.c_int, [C.POINTER(GenieCfg), C.POINTER(Weights), c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                         C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, C.c_size_t, c_ptr, C.c_size_t, c_ptr]),
     "genie_pack_frame_w16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),

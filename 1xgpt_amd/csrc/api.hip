@@ -489,10 +489,11 @@ int genie_frames_pass(const genie_cfg* cfg, const genie_weights* wt, const int64
     c1.T = nf;  // every buffer of this pass is a dense (B, nf, S, *) tensor
     // the fragment-order kernels (kernels_frame.hip) take the pass when they cover every layer; several frames per pass exist
     // only there
-    bool fr = cfg->precision == GENIE_PREC_F16X3 && wt->out_frame_w16 && cfg->T <= 16;   // (the decode attention kernel holds 16 cache slots)
+    // (the decode attention kernel holds 16 cache slots; the readout Linear writes 64-column tiles with no tail handling)
+    bool fr = cfg->precision == GENIE_PREC_F16X3 && wt->out_frame_w16 && cfg->T <= 16 && (cfg->factored_vocab * cfg->num_factored) % 64 == 0;
     for (int i = 0; fr && i < c1.num_layers; ++i) fr = frame_path_takes(c1, wt->layers_host[i], (long)B * nf * cfg->S);
     if (nf > 1 && !fr) {
-        set_error("frames_pass: %d frames per pass need the fragment-order kernels (f16x3, head_dim 64 or 32, LayerNorm blocks, frame_w16 "
+        set_error("frames_pass: %d frames per pass need the fragment-order kernels (f16x3, head_dim 64 or 32, frame_w16 "
                   "streams, B * nf * S <= 16,384 rows)", nf);
         return GENIE_E_UNSUPPORTED;
     }
@@ -505,6 +506,8 @@ int genie_frames_pass(const genie_cfg* cfg, const genie_weights* wt, const int64
     if (!fr) {
         if (c1.precision == GENIE_PREC_BF16) GENIE_TRY(prepare_bf16(c1, w.x, w, B, st));
         if (c1.precision == GENIE_PREC_F16X3) GENIE_TRY(prepare_f16x3(c1, w.x, w, B, st));
+    } else {
+        GENIE_TRY(frame_prepare_f16x3(c1, w.x, w, B, nf, st));
     }
     const size_t per_layer = (size_t)B * cfg->T * cfg->S * 3 * cfg->d_model;
     for (int i = 0; i < c1.num_layers; ++i) {
@@ -546,6 +549,22 @@ static int put_frame_ids(const int64_t* src, long src_stride, int64_t* dst, long
     return GENIE_OK;
 }
 
+// where the loop scratch of genie_generate_cached starts: behind the workspace of its largest pass
+static size_t generate_scratch_offset(const genie_cfg& c, int B, int P) {
+    genie_cfg cm = c;
+    cm.T = P > 2 ? P : 2;
+    return carve(cm, B, nullptr).total;
+}
+
+size_t genie_generate_workspace_bytes(const genie_cfg* cfg, int B, int P) {
+    if (check_cfg(cfg) != GENIE_OK || B < 1 || P < 1 || P > cfg->T) return 0;
+    const size_t BS = (size_t)B * cfg->S, V = (size_t)cfg->factored_vocab * cfg->num_factored;
+    size_t off = generate_scratch_offset(*cfg, B, P);
+    for (size_t bytes : {BS * P * 8, BS * 2 * 8, BS * 8, BS * 8, BS * 8, BS * 4, BS, BS * V * 4}) off += align_up(bytes, 256);
+    const size_t full = carve(*cfg, B, nullptr).total;   // (the passes themselves check against the model's own workspace size)
+    return off > full ? off : full;
+}
+
 int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const int64_t* ids, int B, int P, int n_new, int steps,
                           float temperature, int unmask_mode, const float* noise, const float* uniforms, int teacher_force_time,
                           int merge_commit, int64_t* gen_out, float* logits0_out, float* cache, size_t cache_bytes, void* workspace,
@@ -567,11 +586,10 @@ int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const i
     hipStream_t st = as_stream(stream);
     const int S = c.S, T = P + n_new;   // frames per clip in `ids` (the cache keeps the model's c.T slots per clip)
     const size_t BS = (size_t)B * S, V = (size_t)c.factored_vocab * c.num_factored;
-    // scratch of the loop behind the workspace of its largest pass (the prompt's P frames; two frames for the merged passes)
-    genie_cfg cm = c;
-    cm.T = P > 2 ? P : 2;
+    // scratch of the loop behind the workspace of its largest pass (the prompt's P frames; two frames for the merged passes):
+    // genie_generate_workspace_bytes(cfg, B, P) is the size to allocate
     char* base = (char*)workspace;
-    size_t off = carve(cm, B, nullptr).total;
+    size_t off = generate_scratch_offset(c, B, P);
     auto take = [&](size_t bytes) { char* r = base + off; off += align_up(bytes, 256); return r; };
     int64_t* idsP = (int64_t*)take(BS * P * 8);
     int64_t* two = (int64_t*)take(BS * 2 * 8);
@@ -581,7 +599,8 @@ int genie_generate_cached(const genie_cfg* cfg, const genie_weights* wt, const i
     float* conf = (float*)take(BS * 4);
     uint8_t* unmasked = (uint8_t*)take(BS);
     float* logits = (float*)take(BS * V * 4);
-    GENIE_CHECK_ARG(off <= workspace_bytes, "generate_cached: workspace too small (%zu < %zu bytes)", workspace_bytes, off);
+    GENIE_CHECK_ARG(off <= workspace_bytes, "generate_cached: workspace too small (%zu < %zu bytes: size it with genie_generate_workspace_bytes)",
+                    workspace_bytes, off);
 
     // ---- the prompt fills cache slots 0 .. P-1: one P-frame pass where the fragment-order kernels cover it, else the clean pass
     // with the cache's T-frame layout, else frame by frame

@@ -193,6 +193,36 @@ constexpr int study_env(const char*, int dflt) { return dflt; }
 constexpr bool kStudyBuild = false;
 #endif
 
+// One-time per-DEVICE launch setup (hipFuncSetAttribute(MaxDynamicSharedMemorySize), the CU count that sizes a persistent grid): a
+// process may drive several devices and call from several host threads, so "once per process" is wrong on the second device.
+//   static PerDevice<bool> ready;  if (ready.needs()) { hipFuncSetAttribute(...); ready.set(true); }
+// needs() is true until set() has been called on the current device; two racing threads both run the (idempotent) setup, neither
+// launches before it has run.
+constexpr int GENIE_MAX_DEVICES = 64;
+inline int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return (d < 0 || d >= GENIE_MAX_DEVICES) ? 0 : d;
+}
+template <typename T>
+struct PerDevice {
+    T v[GENIE_MAX_DEVICES] = {};
+    volatile bool ok[GENIE_MAX_DEVICES] = {};
+    bool needs() const { return !__atomic_load_n(&ok[current_device()], __ATOMIC_ACQUIRE); }
+    void set(T x) { const int d = current_device(); v[d] = x; __atomic_store_n(&ok[d], true, __ATOMIC_RELEASE); }
+    T get() const { return v[current_device()]; }
+};
+// multiprocessor count of the CURRENT device (cached per device)
+inline int device_cu_count() {
+    static PerDevice<int> cus;
+    if (cus.needs()) {
+        int n = 0;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, current_device());
+        cus.set(n > 0 ? n : 256);
+    }
+    return cus.get();
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

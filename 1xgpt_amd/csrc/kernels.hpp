@@ -213,7 +213,8 @@ int launch_wgrad16_tn(const uint16_t* dY, long ldy, const uint16_t* X, long ldx,
                       float beta, float* slabs, size_t slab_floats, hipStream_t st);
 int launch_cast16(int npl, const float* src, uint16_t* dst, size_t n, hipStream_t st);
 enum { G16X_GELU = 1, G16X_ACCUM = 2, G16X_OUT16 = 4, G16X_OUTF32 = 8, G16X_GELU16 = 16, G16X_NT = 32,
-       G16X_QKV = 64 /* gemm16_pp only: the spatial-attention operand layout, see launch_gemm16_pp */ };  // = the G16_* flags of kernels_bf16.hip
+       G16X_QKV = 64 /* gemm16_pp only: the spatial-attention operand layout, see launch_gemm16_pp */,
+       G16X_QKNORM = 128 /* with G16X_QKV: q and k leave through the per-head LayerNorm (qn_g, qn_b; attention.py:31-34, 42-47) */ };  // = the G16_* flags of kernels_bf16.hip
 int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw, long planeW,
                      const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M, int N,
                      int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC);
@@ -221,7 +222,7 @@ int launch_gemm16_ex(int npl, const uint16_t* A, long lda, long planeA, const ui
 int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw,
                      long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M,
                      int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC,
-                     float qscale = 1.0f, int head_dim = 0);
+                     float qscale = 1.0f, int head_dim = 0, const float* qn_g = nullptr, const float* qn_b = nullptr);
 // kernels_attn_bwd16.hip: spatial attention backward on the bf16 matrix cores (bf16 training precision)
 int launch_attn_spatial_bwd_bf16(const float* qkv, const float* qk, long qk_ld, const float* dO, float* dqkv, float* stats, long n_bt,
                                  int S, int d, int H, int Dh, float scale, hipStream_t st);
@@ -235,6 +236,7 @@ int launch_gemm16_sm_ln(int npl, const float* x, long ldx, const float* ln_g, co
 // kernels_frame.hip: the one-frame passes of generate on fragment-ordered operands (GENIE_PREC_F16X3)
 int launch_pack_frame_w16(const float* src, uint16_t* dst, int N, int K, hipStream_t st);
 bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows);
+int frame_prepare_f16x3(const genie_cfg& c, const float* x, Workspace& w, int B, int nf, hipStream_t st);
 int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, float* x, Workspace& w, int B, int nf, bool want_xs,
                          hipStream_t st);
 int launch_frame_linear(const uint16_t* A, const uint16_t* W, const float* bias, float* y, int M, int N, int K, int mode, hipStream_t st);

@@ -834,14 +834,19 @@ static int spatial_attention_fused(int npl, const genie_cfg& c, const genie_laye
     if (npl == 2 && study_terms() != 3) return GENIE_E_UNSUPPORTED;
 #endif
     if (npl == 2 && (lw.spatial.w16_wide & GENIE_WIDE_QKV)) return GENIE_E_UNSUPPORTED;  // |w| >= 32: two-accumulator GEMM + f32-qkv attention
-    if (!on || c.S != 256 || c.qk_norm || (c.head_dim != 64 && c.head_dim != 32) || d % 256 || d != c.num_heads * c.head_dim)
+    // (qk_norm: the per-head LayerNorm of q and k is the QKV GEMM's epilogue -- G16X_QKNORM -- so the planes hold normalised, scaled
+    // operands and the attention kernels below are the same in both variants)
+    if (!on || c.S != 256 || (c.head_dim != 64 && c.head_dim != 32) || d % 256 || d != c.num_heads * c.head_dim ||
+        (c.qk_norm && !(lw.spatial.norm_w && lw.spatial.norm_b)))
         return GENIE_E_UNSUPPORTED;
     const long n_seq = (long)B * c.T;
     const int M = (int)(n_seq * c.S);
     uint16_t* qkv16 = (uint16_t*)w.big;  // 3 * npl planes of M * d 16-bit values <= the (M, 3d) f32 buffer
     const int rc = launch_gemm16_pp(npl, 3, npl == 2, u, d, (long)planeA, lw.spatial.qkv_w16, d, (long)planeW,
                                     c.qkv_bias ? lw.spatial.qkv_b : nullptr, nullptr, nullptr, qkv16, (long)M * d, d, M, 3 * d, d,
-                                    G16X_OUT16 | G16X_QKV, 1.0f, st, 1, 0, 0, 0, c.attn_scale * 1.4426950408889634f, c.head_dim);
+                                    G16X_OUT16 | G16X_QKV | (c.qk_norm ? G16X_QKNORM : 0), 1.0f, st, 1, 0, 0, 0,
+                                    c.attn_scale * 1.4426950408889634f, c.head_dim, c.qk_norm ? lw.spatial.norm_w : nullptr,
+                                    c.qk_norm ? lw.spatial.norm_b : nullptr);
     if (rc != GENIE_OK) return rc;
     if (npl == 1 && x && x16 && proj_done) {   // shipped geometry, bf16: attention over all heads + out-projection + residual in one kernel
         const int rf = launch_spatial_attn_proj_bf16(c, lw.spatial, qkv16, x, shadow16 ? x16 : nullptr, n_seq, st);

@@ -686,13 +686,8 @@ int launch_conv3x3_igemm(const uint16_t* X, const uint16_t* Wt, const float* bia
     static const int slab = study_env("GENIE_CONV_SLAB", 1);
     if (slab && stride == 1) {
         const int fl = (d2s ? CONV_D2S : 0) | abl;
-        static const int n_cu = [] {
-            int dev = 0, n = 0;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            if (!study_env("GENIE_CONV_PERSIST", 1)) return 1 << 30;  // 0: one workgroup per tile (A/B runs)
-            return n > 0 ? n : 256;
-        }();
+        static const bool persist = study_env("GENIE_CONV_PERSIST", 1) != 0;  // 0: one workgroup per tile (A/B runs)
+        const int n_cu = persist ? device_cu_count() : 1 << 30;               // (per device: common.hpp)
         if (Cout <= 32 && !gn_part) {
             const size_t lds = 2 * 33 * 1024 + 3 * 8 * 1024 + 8 * 16 * 32 * 4;
             const int tiles = mt * ((Cout + 31) / 32);

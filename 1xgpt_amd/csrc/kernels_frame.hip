@@ -64,6 +64,27 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// sum over aligned groups of 8 lanes (a head of 32 features at 4 per lane), the same bits in every lane of the group
+__device__ __forceinline__ float lanes8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    return v;
+}
+// The reference's default attention variant (qk_norm, attention.py:31-34, 42-47): LayerNorm over the head_dim features of ONE head
+// (eps 1e-5, biased variance, one affine shared by q, k and all heads), for a row-major phase in which a lane holds 4 consecutive
+// features and a head's features sit in Dh / 4 consecutive aligned lanes (16 = one DPP row, or 8).
+__device__ __forceinline__ f32x4 head_layer_norm(f32x4 v, int Dh, const f32x4& gm, const f32x4& bt) {
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+    s = Dh == 64 ? row16_sum(s) : lanes8_sum(s);
+    const float mean = s * (1.0f / (float)Dh);
+    v -= mean;
+    float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    q = Dh == 64 ? row16_sum(q) : lanes8_sum(q);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / (float)Dh) + 1e-5f);
+    return v * rstd * gm + bt;
+}
+
 // Hand-placed LDS fragment reads for the LDS-tiled kernel: left to the compiler every group of matrix instructions sits behind an
 // s_waitcnt lgkmcnt(0) (a full LDS round trip per group); fr_lds_rd issues a read the compiler knows nothing about, fr_lds_wait<N>
 // is "all but my N youngest LDS reads have landed", tied to the fragment it guards (LDS reads return in order; no scalar load may
@@ -109,6 +130,8 @@ struct FrGemmArgs {
     uint16_t* qkvs;              // EPI_QKVS: attention operand planes
     float qscale;                // EPI_QKVS: softmax scale * log2(e), folded into Q
     int H, S, Dh;                // EPI_QKVS: heads, rows per sequence (256), head_dim (64 or 32 columns per head)
+    const float* qn_g;           // EPI_QKVS, qk_norm: gamma | beta (Dh floats each) of the per-head LayerNorm of q and k, or NULL
+    const float* qn_b;
 };
 
 // The spatial attention's operand planes (FR_EPI_QKVS), written from a finished 32 x 32 sub-tile of the qkv output that sits in LDS
@@ -185,6 +208,12 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
     static_assert(NT % C4 == 0, "a thread keeps its columns over the passes of the row-major phase");
     f32x4 pre_b = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.bias) pre_b = *reinterpret_cast<const f32x4*>(a.bias + n0 + (tid % C4) * 4);
+    f32x4 pre_qg = f32x4{0.f, 0.f, 0.f, 0.f}, pre_qb = pre_qg;   // qk-norm: the affine of this thread's 4 features of a head
+    const bool qkn = EPI == FR_EPI_QKVS && a.qn_g != nullptr && n0 < 2 * a.H * a.Dh;   // (a q or k column tile: workgroup-uniform)
+    if (qkn) {
+        pre_qg = *reinterpret_cast<const f32x4*>(a.qn_g + ((tid % C4) * 4) % a.Dh);
+        pre_qb = *reinterpret_cast<const f32x4*>(a.qn_b + ((tid % C4) * 4) % a.Dh);
+    }
     f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (LNF) {   // gamma | beta: one float4 per thread (K / 2 <= NT float4s), staged through LDS
         if (tid < a.K / 4) gbv = reinterpret_cast<const f32x4*>(a.ln_g)[tid];
@@ -358,6 +387,9 @@ void gemm16_fr_kernel(const FrGemmArgs a) {
                 const genie_f2 g0 = gelu_erf_fast2(genie_f2{v[0], v[1]}), g1 = gelu_erf_fast2(genie_f2{v[2], v[3]});
                 v = f32x4{g0[0], g0[1], g1[0], g1[1]};
             }
+            if constexpr (EPI == FR_EPI_QKVS) {   // (every pass is full: ITEMS % NT == 0 for 64-column tiles, so all lanes of a head take part)
+                if (qkn) v = head_layer_norm(v, a.Dh, pre_qg, pre_qb);
+            }
             if constexpr (EPI == FR_EPI_RES) v += pre_r[q];
             if constexpr (EPI == FR_EPI_F32 || EPI == FR_EPI_RES) {
                 const long row = m0 + rl;
@@ -422,6 +454,14 @@ __device__ __forceinline__ void frm_epilogue(const FrGemmArgs& a, const f32x16 (
         const int c4 = (lane % C4) * 4, rl0 = lane / C4;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + c4);
+        f32x4 qg = f32x4{0.f, 0.f, 0.f, 0.f}, qb = qg;
+        // qk-norm: the wave's tile holds whole heads (the launcher picks 64-column wave tiles for head_dim 64)
+        const bool qkn = EPI == FR_EPI_QKVS && a.qn_g != nullptr && n0 < 2 * a.H * a.Dh;
+        if (qkn && TNW % a.Dh != 0) __builtin_trap();   // (launch_frm_any never pairs 32-column wave tiles with heads of 64 under qk-norm)
+        if (qkn) {
+            qg = *reinterpret_cast<const f32x4*>(a.qn_g + c4 % a.Dh);
+            qb = *reinterpret_cast<const f32x4*>(a.qn_b + c4 % a.Dh);
+        }
 #pragma unroll 4
         for (int it = 0; it < 32 * MI / RPI; ++it) {
             const int rl = it * RPI + rl0;
@@ -429,6 +469,9 @@ __device__ __forceinline__ void frm_epilogue(const FrGemmArgs& a, const f32x16 (
             if constexpr (EPI == FR_EPI_GELU) {
                 const genie_f2 g0 = gelu_erf_fast2(genie_f2{v[0], v[1]}), g1 = gelu_erf_fast2(genie_f2{v[2], v[3]});
                 v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+            }
+            if constexpr (EPI == FR_EPI_QKVS) {
+                if (qkn) v = head_layer_norm(v, a.Dh, qg, qb);
             }
             if constexpr (EPI == FR_EPI_F32 || EPI == FR_EPI_RES) {
                 const long row = m0 + rl;
@@ -781,7 +824,8 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __restrict__ cache, uint16_t* __restrict__ out16,
-                                                               long n_items, int T, int S, int t0, int nf, int d, int H, float scale) {
+                                                               long n_items, int T, int S, int t0, int nf, int d, int H, float scale,
+                                                               const float* __restrict__ qn_g, const float* __restrict__ qn_b) {
     constexpr int LPF = DH / 4, FPI = 64 / LPF, NI = 16 / FPI;     // lanes per frame, frames per instruction, instructions
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -795,8 +839,10 @@ __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __re
     const int g = lane / LPF, c = lane % LPF;
     const size_t tok = (size_t)S * 3 * d;
     const float* hb = cache + ((size_t)(b * T) * S + s) * 3 * d + head * DH + 4 * c;
-    const f32x4 qv = *reinterpret_cast<const f32x4*>(hb + (size_t)t * tok);
+    f32x4 qv = *reinterpret_cast<const f32x4*>(hb + (size_t)t * tok);
     f32x4 kv[NI], vv[NI];
+    f32x4 qg = f32x4{0.f, 0.f, 0.f, 0.f}, qb = qg;
+    if (qn_g) { qg = *reinterpret_cast<const f32x4*>(qn_g + 4 * c); qb = *reinterpret_cast<const f32x4*>(qn_b + 4 * c); }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = FPI * i + g;
@@ -805,6 +851,11 @@ __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __re
         vv[i] = *reinterpret_cast<const f32x4*>(src + 2 * d);
     }
     FR_PIN_LOADS();
+    if (qn_g) {   // qk-norm (attention.py:42-47): the cache holds the raw q and k; a frame's head slice = the LPF lanes of its group
+        qv = head_layer_norm(qv, DH, qg, qb);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) kv[i] = head_layer_norm(kv[i], DH, qg, qb);
+    }
     float sc[NI];
     float mx = -INFINITY;
 #pragma unroll
@@ -845,6 +896,27 @@ __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __re
     *reinterpret_cast<u32x2*>(dst + 4 * FR) = u32x2{l01, l23};
 }
 
+// f32 rows (M, K) -> fragment-ordered split operand (the activation split: split8).  qk-norm blocks have no LayerNorm in front of their
+// spatial qkv Linear (norm1 = Identity, st_transformer.py:44): the first block of a pass reads this copy of the embedded rows, every later
+// Linear reads the copy its producer's epilogue wrote.  One thread per 16-byte piece of the hi plane.
+__global__ void cast_fr_kernel(const float* __restrict__ X, uint16_t* __restrict__ out16, long M, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KB = K / 64;
+    if (i >= (size_t)(M / 32) * KB * 256) return;
+    const int fl = (int)(i & 63), s = (int)((i >> 6) & 3);
+    const size_t blk = i >> 8;
+    const int kb = (int)(blk % KB);
+    const long rb = (long)(blk / KB);
+    const float* p = X + (size_t)(rb * 32 + (fl & 31)) * K + 64 * kb + 16 * s + 8 * (fl >> 5);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    uint16_t* o = out16 + fr_frag(rb, kb, KB, 0, s) + fl * 8;
+    *reinterpret_cast<u32x4*>(o) = hi;
+    *reinterpret_cast<u32x4*>(o + 4 * FR) = lo;
+}
+
 // f32 (N, K) row-major -> fragment order, split f16 planes (the split of genie_pack_split_f16: hi flushed below the f16 normal range)
 __global__ void pack_frame_w16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int N, int K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte piece of the hi plane
@@ -883,10 +955,14 @@ int launch_fr(const FrGemmArgs& a, hipStream_t st) {
         const size_t stage = (size_t)MI * NW * NPL * 4 * 1056 + (size_t)2 * a.K * 4;
         lds = lds > stage ? lds : stage;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice<bool> attr_set;
+    if (attr_set.needs()) {
         (void)hipFuncSetAttribute((const void*)gemm16_fr_kernel<NW, MI, NJ, NKB, EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.set(true);
+    }
+    if (a.M % TM || a.N % TN) {   // (no tail handling: a ragged width would leave columns unwritten)
+        set_error("gemm16_fr: (M, N) = (%d, %d) must be multiples of the (%d, %d) tile", a.M, a.N, TM, TN);
+        return GENIE_E_UNSUPPORTED;
     }
     const unsigned grid = (unsigned)((a.M / TM) * (a.N / TN));
     gemm16_fr_kernel<NW, MI, NJ, NKB, EPI, LNF><<<grid, NW * 64, lds, st>>>(a);
@@ -929,10 +1005,10 @@ int launch_frm(const FrGemmArgs& a, hipStream_t st) {
     constexpr int BM = 32 * WM * MI, BN = 32 * WN * NJ;
     constexpr size_t lds = (size_t)NST * (WM * MI + WN * NJ) * 4096;
     if (a.M % BM || a.N % BN || a.K % 64) return GENIE_E_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice<bool> attr_set;
+    if (attr_set.needs()) {
         (void)hipFuncSetAttribute((const void*)gemm16_frm_kernel<WM, WN, MI, NJ, NST, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.set(true);
     }
     gemm16_frm_kernel<WM, WN, MI, NJ, NST, EPI><<<(unsigned)((a.M / BM) * (a.N / BN)), 64 * WM * WN, lds, st>>>(a);
     GENIE_LAUNCH_CHECK("gemm16_frm");
@@ -947,6 +1023,9 @@ int launch_frm_any(const FrGemmArgs& a, hipStream_t st) {
     // qkv 32.6 -> 29.4 us, fc1 38.6 -> 33.2 at 4,096 rows, fc1 73.4 -> 64.9 at 8,192; at 2,048 rows (96 tiles) they lose
     // (17.7 -> 26.6): profiles/r05j_frame_gemm.txt against r05i
     static const int big = study_env("GENIE_FRM_256", 1);
+    if constexpr (EPI == FR_EPI_QKVS) {   // qk-norm: a wave's tile must hold whole heads -> 64-column wave tiles (128 x 128 per workgroup of 4 waves)
+        if (a.qn_g) return launch_frm<2, 2, 2, 2, 4, EPI>(a, st);
+    }
     if (big && a.N >= 1024 && a.N % 128 == 0 && a.M % 256 == 0 && a.M >= 4096) return launch_frm<4, 2, 2, 2, 3, EPI>(a, st);
     if (a.N % 128 == 0 && (EPI == FR_EPI_QKVS || t128 >= 160 || a.N >= 1024)) return launch_frm<2, 4, 2, 1, 4, EPI>(a, st);
     if constexpr (EPI != FR_EPI_QKVS) {
@@ -963,8 +1042,8 @@ int launch_ln_fr(const float* x, long ldx, const float* g, const float* b, float
     const size_t lds = (size_t)(K / 64) * NPL * 4 * 1056 + (size_t)2 * K * 4;
 #define LN_FR(NW_)                                                                                                           \
     case NW_: {                                                                                                              \
-        static bool attr_set = false;                                                                                        \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)ln_fr_kernel<NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        static PerDevice<bool> attr_set;                                                                                     \
+        if (attr_set.needs()) { (void)hipFuncSetAttribute((const void*)ln_fr_kernel<NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set.set(true); } \
         ln_fr_kernel<NW_><<<(unsigned)(M / 32), NW_ * 64, lds, st>>>(x, ldx, g, b, eps, out16);                              \
         break;                                                                                                               \
     }
@@ -980,10 +1059,13 @@ int launch_ln_fr(const float* x, long ldx, const float* g, const float* b, float
 
 bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows) {
     static const int on = study_env("GENIE_FRAME_KERNELS", 1);
-    return on && c.precision == GENIE_PREC_F16X3 && !c.qk_norm && c.S == 256 && (c.head_dim == 64 || c.head_dim == 32) &&
+    // LayerNorm blocks need norm1 / norm2; qk-norm blocks (norm1 = norm2 = Identity, st_transformer.py:44,67) the two per-head affines
+    const bool norms = c.qk_norm ? (lw.spatial.norm_w && lw.spatial.norm_b && lw.temporal.norm_w && lw.temporal.norm_b)
+                                 : (lw.norm1_w && lw.norm1_b && lw.norm2_w && lw.norm2_b);
+    return on && c.precision == GENIE_PREC_F16X3 && c.S == 256 && (c.head_dim == 64 || c.head_dim == 32) &&
            c.d_model == c.num_heads * c.head_dim &&
            (c.d_model == 512 || c.d_model == 256 || c.d_model == 128) && c.hidden == 4 * c.d_model && rows % 256 == 0 && rows <= 16384 &&
-           lw.spatial.frame_w16 && lw.temporal.frame_w16 && lw.mlp_frame_w16 && lw.norm1_w && lw.norm2_w;
+           lw.spatial.frame_w16 && lw.temporal.frame_w16 && lw.mlp_frame_w16 && norms;
 }
 
 // One STBlock (st_transformer.py:70-83) of a frame pass: B clips x nf frames (slots t0 .. t0 + nf - 1 of the cache) x S rows.
@@ -1019,19 +1101,26 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     a.M = M;
     a.rows_per_batch = M;
     // ---- spatial: LayerNorm + qkv -> attention operand planes; attention; out-projection + residual (+ operand copy of x)
+    // (qk-norm blocks: no LayerNorm in front -- the Linear reads the operand copy of x -- and q, k leave through the per-head LayerNorm)
+    const bool qkn = c.qk_norm != 0;
     {
         FrGemmArgs g = a;
         g.W = wq_s; g.bias = c.qkv_bias ? lw.spatial.qkv_b : nullptr; g.N = 3 * d; g.K = d;
         g.qkvs = big; g.qscale = c.attn_scale * 1.4426950408889634f; g.H = H; g.S = S; g.Dh = c.head_dim;
+        if (qkn) { g.qn_g = lw.spatial.norm_w; g.qn_b = lw.spatial.norm_b; g.A = xs; }
         if (mid) {
-            {
+            if (!qkn) {
                 ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * M * d, 8.0 * M * d, st, "ln_fr_kernel");
                 GENIE_TRY(launch_ln_fr(x, d, lw.norm1_w, lw.norm1_b, 1e-5f, as, M, d, st));
+                g.A = as;
             }
-            g.A = as;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
                            "gemm16_frm_kernel (qkv -> attention operand planes)");
             GENIE_TRY(launch_frm_any<FR_EPI_QKVS>(g, st));
+        } else if (qkn) {
+            ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
+                           "gemm16_fr_kernel (qkv + qk-norm -> attention operand planes)");
+            GENIE_TRY((launch_fr_w<2, 1, FR_EPI_QKVS, false>(nw, g, st)));
         } else {
             g.X = x; g.ldx = d; g.ln_g = lw.norm1_w; g.ln_b = lw.norm1_b; g.ln_eps = 1e-5f;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d, 4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st,
@@ -1045,8 +1134,8 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         const dim3 grid((unsigned)(B * nf), H, 8);
         if (c.head_dim == 64) {
             const size_t lds = (size_t)8 * 32 * 68 * 4 + 8 * 32 * 2 * 4;
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_spatial_fr_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            static PerDevice<bool> attr_set;
+            if (attr_set.needs()) { (void)hipFuncSetAttribute((const void*)attn_spatial_fr_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set.set(true); }
             attn_spatial_fr_kernel<64><<<grid, 512, lds, st>>>(big, as, H);
         } else {
             const size_t lds = (size_t)8 * 32 * 36 * 4 + 8 * 32 * 2 * 4;
@@ -1079,15 +1168,17 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         ProfScope prof(GENIE_KC_ATTN_TEMPORAL, 4.0 * (w.frame_t + nf) * c.head_dim * (double)n, (double)n * c.head_dim * 4.0 * (2 * (w.frame_t + nf) + 2), st,
                        "attn_temporal_fr_kernel");
         if (c.head_dim == 64)
-            attn_temporal_fr_kernel<64><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale);
+            attn_temporal_fr_kernel<64><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale,
+                                                                                 qkn ? lw.temporal.norm_w : nullptr, qkn ? lw.temporal.norm_b : nullptr);
         else
-            attn_temporal_fr_kernel<32><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale);
+            attn_temporal_fr_kernel<32><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale,
+                                                                                 qkn ? lw.temporal.norm_w : nullptr, qkn ? lw.temporal.norm_b : nullptr);
         GENIE_LAUNCH_CHECK("attn_temporal_fr");
     }
     {
         FrGemmArgs g = a;
         g.A = as; g.W = wp_t; g.bias = c.proj_bias ? lw.temporal.proj_b : nullptr; g.N = d; g.K = d;
-        g.Cf = x; g.ldc = d; g.C16 = nullptr;
+        g.Cf = x; g.ldc = d; g.C16 = qkn ? xs : nullptr;   // (qk-norm: fc1 has no LayerNorm in front and reads the operand copy of x)
         ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)d * d, 4.0 * M * d * 3 + 4.0 * d * d, st,
                        mid_proj ? "gemm16_frm_kernel (proj + residual)" : "gemm16_fr_kernel (proj + residual)");
         if (mid_proj) GENIE_TRY(launch_frm_any<FR_EPI_RES>(g, st));
@@ -1097,15 +1188,20 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     {
         FrGemmArgs g = a;
         g.W = w1; g.bias = c.mlp_bias ? lw.fc1_b : nullptr; g.N = hid; g.K = d; g.C16 = big;
+        if (qkn) g.A = xs;
         if (mid) {
-            {
+            if (!qkn) {
                 ProfScope prof(GENIE_KC_LAYERNORM, 8.0 * M * d, 8.0 * M * d, st, "ln_fr_kernel");
                 GENIE_TRY(launch_ln_fr(x, d, lw.norm2_w, lw.norm2_b, 1e-5f, as, M, d, st));
+                g.A = as;
             }
-            g.A = as;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
                            "gemm16_frm_kernel (fc1 + GELU)");
             GENIE_TRY(launch_frm_any<FR_EPI_GELU>(g, st));
+        } else if (qkn) {
+            ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
+                           "gemm16_fr_kernel (fc1 + GELU)");
+            GENIE_TRY((launch_fr_w<2, 1, FR_EPI_GELU, false>(nw, g, st)));
         } else {
             g.X = x; g.ldx = d; g.ln_g = lw.norm2_w; g.ln_b = lw.norm2_b; g.ln_eps = 1e-5f;
             ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * d + 4.0 * hid * d + 4.0 * M * hid, st,
@@ -1116,12 +1212,22 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     {
         FrGemmArgs g = a;
         g.A = big; g.W = w2; g.bias = c.mlp_bias ? lw.fc2_b : nullptr; g.N = d; g.K = hid;
-        g.Cf = x; g.ldc = d; g.C16 = want_xs ? xs : nullptr;
+        g.Cf = x; g.ldc = d; g.C16 = (want_xs || qkn) ? xs : nullptr;   // (qk-norm: the next block's spatial qkv reads it)
         ProfScope prof(GENIE_KC_GEMM, 2.0 * M * (double)hid * d, 4.0 * M * hid + 4.0 * hid * d + 4.0 * M * d * 2, st,
                        mid ? "gemm16_frm_kernel (fc2 + residual)" : "gemm16_fr_kernel (fc2 + residual)");
         if (mid) GENIE_TRY(launch_frm_any<FR_EPI_RES>(g, st));
         else GENIE_TRY((launch_fr_w<1, 4, FR_EPI_RES, false>(nw, g, st)));
     }
+    return GENIE_OK;
+}
+
+// In front of the first block of a frame pass: qk-norm blocks read the operand copy of the embedded rows (cast_fr_kernel)
+int frame_prepare_f16x3(const genie_cfg& c, const float* x, Workspace& w, int B, int nf, hipStream_t st) {
+    if (!c.qk_norm) return GENIE_OK;
+    const long M = (long)B * nf * c.S;
+    const size_t total = (size_t)(M / 32) * (c.d_model / 64) * 256;
+    cast_fr_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, (uint16_t*)w.xn, M, c.d_model);
+    GENIE_LAUNCH_CHECK("cast_fr");
     return GENIE_OK;
 }
 

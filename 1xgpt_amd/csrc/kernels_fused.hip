@@ -1071,20 +1071,11 @@ int launch_pack_spatial_qkv(const float* qkv_w, uint16_t* out, hipStream_t st) {
 // plus a tile of slack must stay below 2^31 bytes.  ONE predicate for the producer (fused MLP kernel, mode 2) and the consumer
 // (spatial_attn_proj): planes that are written can always be read (n_seq < ~15,200).
 static bool spatial_planes_addressable(long n_seq) { return (double)n_seq * 256 * 256 * 2 + 4096.0 * 256 < 2.0e9; }
-// multiprocessor count of the current device, read once (the fused launches size their persistent grids with it)
-static int device_cus() {
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n;
-    }();
-    return cus;
-}
+static int device_cus() { return device_cu_count(); }   // (common.hpp: cached per device)
 
 int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, float* x, uint16_t* x16_out, long rows, hipStream_t st,
                           const float* nx_g, const float* nx_b, const uint16_t* nx_qkv_stream, uint16_t* planes) {
-    if (!lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < GENIE_VAR_M_MIN_CLIPS * 4096 || !lw.norm2_w ||
+    if (c.precision != GENIE_PREC_BF16 || !lw.mlp_fused_w16 || c.d_model != 256 || c.hidden != 1024 || c.qk_norm || rows % 128 || rows < GENIE_VAR_M_MIN_CLIPS * 4096 || !lw.norm2_w ||
         !lw.norm2_b)
         return GENIE_E_UNSUPPORTED;
     GENIE_CHECK_ARG((nx_g == nullptr) == (nx_b == nullptr) && (!nx_g || x16_out || planes), "mlp_fused: next-norm parameters need both pointers and an output");
@@ -1105,15 +1096,15 @@ int launch_mlp_fused_bf16(const genie_cfg& c, const genie_layer_weights& lw, flo
     const int abl = study_env("GENIE_FUSED_ABL", 0);
     fs_stamps_prepare();
     if (qkv) {
-        { static const hipError_t once = hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); (void)once; }
+        { static PerDevice<bool> once; if (once.needs()) { (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); once.set(true); } }
         mlp_fused_bf16_kernel<2><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, planes, nx_g, nx_b, n_blocks,
                                                             1e-5f, abl, nx_qkv_stream, rows * 256, c.attn_scale * 1.4426950408889634f);
     } else if (nx_g) {
-        { static const hipError_t once = hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); (void)once; }
+        { static PerDevice<bool> once; if (once.needs()) { (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); once.set(true); } }
         mlp_fused_bf16_kernel<1><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nx_g, nx_b,
                                                             n_blocks, 1e-5f, abl, nullptr, 0, 0.f);
     } else {
-        { static const hipError_t once = hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); (void)once; }
+        { static PerDevice<bool> once; if (once.needs()) { (void)hipFuncSetAttribute((const void*)mlp_fused_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS); once.set(true); } }
         mlp_fused_bf16_kernel<0><<<grid, 256, ML_LDS, st>>>(x, lw.mlp_fused_w16, lw.norm2_w, lw.norm2_b, fb1, fb2, x16_out, nullptr,
                                                             nullptr, n_blocks, 1e-5f, abl, nullptr, 0, 0.f);
     }
@@ -1420,7 +1411,8 @@ __global__ __launch_bounds__(512, 2) void spatial_attn_proj_bf16_kernel(const ui
 // x += proj_s(attention_S(planes)) and x16 = bf16(x) for n_seq sequences of 256 tokens; GENIE_E_UNSUPPORTED outside d 256 / 8 x 32
 int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* qkv16, float* x, uint16_t* x16,
                                   long n_seq, hipStream_t st) {
-    if (!aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.S != 256 || c.qk_norm || n_seq < GENIE_VAR_S_MIN_SEQ)
+    if (c.precision != GENIE_PREC_BF16 || !aw.fused_w16 || c.d_model != 256 || c.num_heads != 8 || c.head_dim != 32 || c.S != 256 || c.qk_norm ||
+        n_seq < GENIE_VAR_S_MIN_SEQ)
         return GENIE_E_UNSUPPORTED;
     const long P = n_seq * 256 * 256;
     if (!spatial_planes_addressable(n_seq)) return GENIE_E_UNSUPPORTED;   // 32-bit scalar offsets inside the plane descriptors
@@ -1429,7 +1421,7 @@ int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& 
     const double M = (double)n_seq * 256;
     ProfScope prof(GENIE_KC_FUSED, M * (4.0 * 256 * 256 + 2.0 * 256 * 256), M * (3 * 512.0 + 2048.0 + 512.0), st,
                    "spatial_attn_proj_bf16_kernel (attention over S, all heads + proj + residual)");
-    { static const hipError_t once = hipFuncSetAttribute((const void*)spatial_attn_proj_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS); (void)once; }
+    { static PerDevice<bool> once; if (once.needs()) { (void)hipFuncSetAttribute((const void*)spatial_attn_proj_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS); once.set(true); } }
 #ifndef GENIE_VAR_S_STAGGER
 #define GENIE_VAR_S_STAGGER 0     // (measured: 3-15 us per class only adds the delay -- profiles/r04_fused_experiments.txt)
 #endif
@@ -1445,8 +1437,11 @@ int launch_spatial_attn_proj_bf16(const genie_cfg& c, const genie_attn_weights& 
 #endif
 // x += proj_t(attention_T(qkv_t(x16))) on dense (B, 16, S, 256) buffers; GENIE_E_UNSUPPORTED for any other geometry
 bool temporal_fused_takes(const genie_cfg& c, const genie_attn_weights& aw, int B) {
-    return aw.fused_w16 && c.d_model == 256 && c.num_heads == 8 && c.head_dim == 32 && c.T == 16 && c.S % 8 == 0 && !c.qk_norm &&
-           (long)B * c.S >= GENIE_VAR_T_MIN_CLIPS * 256;
+    // (precision: in GENIE_PREC_F16X3 `fused_w16` is the split-f16 qkv stream of kernels_fused_f16x3.hip, not this kernel's bf16
+    // [qkv | proj] stream; qk_norm: the shipped config -- genie/configs/magvit_n32_h8_d256.json -- has LayerNorm blocks, and the d = 256
+    // fused kernels are specialisations for it: a qk-norm model of this width runs the unfused launches)
+    return c.precision == GENIE_PREC_BF16 && aw.fused_w16 && c.d_model == 256 && c.num_heads == 8 && c.head_dim == 32 && c.T == 16 &&
+           c.S % 8 == 0 && !c.qk_norm && (long)B * c.S >= GENIE_VAR_T_MIN_CLIPS * 256;
 }
 
 int launch_temporal_fused_bf16(const genie_cfg& c, const genie_attn_weights& aw, const uint16_t* x16, float* x, int B,

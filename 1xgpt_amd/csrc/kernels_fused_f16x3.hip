@@ -419,9 +419,11 @@ int launch_temporal_qkv_attn_f16x3(const genie_cfg& c, const genie_attn_weights&
     const float sl2e = c.attn_scale * 1.4426950408889634f;
 #define QA_LAUNCH(QB_, MODE_, G_)                                                                                                            \
     do {                                                                                                                                 \
-        static const hipError_t once = hipFuncSetAttribute((const void*)temporal_qkv_attn_f16x3_kernel<QB_, MODE_, G_>,                      \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-        (void)once;                                                                                                                      \
+        static PerDevice<bool> once;                                                                                                     \
+        if (once.needs()) {                                                                                                              \
+            (void)hipFuncSetAttribute((const void*)temporal_qkv_attn_f16x3_kernel<QB_, MODE_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            once.set(true);                                                                                                              \
+        }                                                                                                                                \
         temporal_qkv_attn_f16x3_kernel<QB_, MODE_, G_><<<grid, 256, lds, st>>>(x, aw.fused_w16, QB_ ? aw.qkv_b : nullptr, a16, plane, kv,   \
                                                                             n_blocks, c.S, c.T, shift, sl2e);                            \
     } while (0)

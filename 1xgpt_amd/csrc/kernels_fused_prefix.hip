@@ -403,9 +403,11 @@ int launch_temporal_prefix_fused_bf16(const genie_cfg& c, const genie_attn_weigh
     const bool qb = c.qkv_bias && aw.qkv_b;
 #define TP_LAUNCH(QB_, MODE_)                                                                                                              \
     do {                                                                                                                                   \
-        static const hipError_t once = hipFuncSetAttribute((const void*)temporal_prefix_fused_bf16_kernel<QB_, MODE_>,                     \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-        (void)once;                                                                                                                        \
+        static PerDevice<bool> once;                                                                                                       \
+        if (once.needs()) {                                                                                                                \
+            (void)hipFuncSetAttribute((const void*)temporal_prefix_fused_bf16_kernel<QB_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            once.set(true);                                                                                                                \
+        }                                                                                                                                  \
         temporal_prefix_fused_bf16_kernel<QB_, MODE_><<<grid, 256, lds, st>>>(x, aw.fused_w16, QB_ ? aw.qkv_b : nullptr, pb, kv, n_blocks, \
                                                                                c.S, c.T, shift, sl2e);                                     \
     } while (0)

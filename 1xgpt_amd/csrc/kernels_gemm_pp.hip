@@ -103,7 +103,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                                                             const float* __restrict__ bias, float* __restrict__ Cf,
                                                             uint16_t* __restrict__ C16, long plane16, long ldc, int M, int N,
                                                             int K, int flags, float alpha, long strideA, long strideC,
-                                                            const float* Rf, long strideW, float qscale, int head_dim) {
+                                                            const float* Rf, long strideW, float qscale, int head_dim,
+                                                            const float* __restrict__ qn_g, const float* __restrict__ qn_b) {
     constexpr int KK = NPL == 1 ? 4 : 2;  // k16 steps per K-tile
     constexpr int BK = 16 * KK;
     constexpr int BM = 256, BN = 256;
@@ -389,6 +390,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
     const auto rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)(bias ? (const void*)bias : (const void*)W), 0, -1, 0x00020000);
     float* const bias_lds = reinterpret_cast<float*>(smem + 2 * PP_BUF);
     int bias_slot = 0;
+    // G16X_QKNORM (the reference's default attention variant, attention.py:31-34, 42-47): gamma | beta of the per-head LayerNorm of q
+    // and k (head_dim floats each, shared by all heads) sit behind the bias slots for the whole launch -- plain loads, before the
+    // first LDS-DMA is requested (a global load later on would make the compiler drain the ring); visible after the first barrier
+    constexpr bool kQkNorm = EPI >= 0 && (EPI & G16X_QKNORM) != 0;
+    float* const norm_lds = bias_lds + 512;
+    if constexpr (kQkNorm) {
+        if (tid < head_dim) { norm_lds[tid] = qn_g[tid]; norm_lds[64 + tid] = qn_b[tid]; }
+    }
     auto stage_bias = [&](int slot, int n0_) {
         if (bias && wid == 0)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (__attribute__((address_space(3))) void*)(bias_lds + slot * 256), 16,
@@ -510,6 +519,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                 const int voff = ((((hq << 8) + wm * 128 + lrow) << hd_shift) + fq) * 2;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (bias) { b0 = lds_ld4(bl + c8); b1 = lds_ld4(bl + c8 + 4); }
+                float4 g0 = b0, g1 = b0, e0 = b0, e1 = b0;   // qk-norm: gamma / beta of this lane's 8 features
+                if constexpr (kQkNorm) {
+                    g0 = lds_ld4(norm_lds + fq); g1 = lds_ld4(norm_lds + fq + 4);
+                    e0 = lds_ld4(norm_lds + 64 + fq); e1 = lds_ld4(norm_lds + 64 + fq + 4);
+                }
+                const float inv_hd = 1.0f / (float)head_dim;
+                // sum over the lanes that hold one head's features of a row: 8 lanes x 8 columns (head_dim 64) or 4 (head_dim 32);
+                // every lane of the group ends with the same bits (commutative pairings)
+                auto head_sum = [&](float t) {
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+                    if (head_dim == 64)
+                        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, false));  // row_half_mirror
+                    return t;
+                };
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -530,10 +554,26 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
                         const int sw = (rl & 1) << 2;
                         float4 v = lds_ld4(ct + rl * 64 + (c8 ^ sw));
                         float4 u = lds_ld4(ct + rl * 64 + ((c8 + 4) ^ sw));
+                        if constexpr (kQkNorm) {
+                            // q = LN_head(q), k = LN_head(k): two-pass statistics over the head's features of this row (eps 1e-5,
+                            // biased variance: nn.LayerNorm), then the shared affine, then (q only) scale * log2 e
+                            v.x = v.x * ascale + b0.x; v.y = v.y * ascale + b0.y; v.z = v.z * ascale + b0.z; v.w = v.w * ascale + b0.w;
+                            u.x = u.x * ascale + b1.x; u.y = u.y * ascale + b1.y; u.z = u.z * ascale + b1.z; u.w = u.w * ascale + b1.w;
+                            const float mean = head_sum(((v.x + v.y) + (v.z + v.w)) + ((u.x + u.y) + (u.z + u.w))) * inv_hd;
+                            v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
+                            const float var = head_sum(((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) +
+                                                       ((u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w))) * inv_hd;
+                            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                            v.x = (v.x * rstd * g0.x + e0.x) * qs; v.y = (v.y * rstd * g0.y + e0.y) * qs;
+                            v.z = (v.z * rstd * g0.z + e0.z) * qs; v.w = (v.w * rstd * g0.w + e0.w) * qs;
+                            u.x = (u.x * rstd * g1.x + e1.x) * qs; u.y = (u.y * rstd * g1.y + e1.y) * qs;
+                            u.z = (u.z * rstd * g1.z + e1.z) * qs; u.w = (u.w * rstd * g1.w + e1.w) * qs;
+                        } else {
                         v.x = (v.x * ascale + b0.x) * qs; v.y = (v.y * ascale + b0.y) * qs;
                         v.z = (v.z * ascale + b0.z) * qs; v.w = (v.w * ascale + b0.w) * qs;
                         u.x = (u.x * ascale + b1.x) * qs; u.y = (u.y * ascale + b1.y) * qs;
                         u.z = (u.z * ascale + b1.z) * qs; u.w = (u.w * ascale + b1.w) * qs;
+                        }
                         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
                         if constexpr (NPL == 1) {
                             const u4v t = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
@@ -797,8 +837,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_pp_kernel(const uint16_t* __res
 int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, long planeA, const uint16_t* W, long ldw,
                      long planeW, const float* bias, const float* Rf, float* Cf, uint16_t* C16, long plane16, long ldc, int M,
                      int N, int K, int flags, float alpha, hipStream_t st, int batch, long strideA, long strideW, long strideC,
-                     float qscale, int head_dim) {
+                     float qscale, int head_dim, const float* qn_g, const float* qn_b) {
     const int bk = npl == 1 ? 64 : 32;
+    if ((flags & G16X_QKNORM) && (!(flags & G16X_QKV) || !qn_g || !qn_b || (head_dim != 32 && head_dim != 64))) return GENIE_E_UNSUPPORTED;
     if (flags & G16X_QKV) {  // C16 = [Q | K | V^T] operand planes of the spatial attention (plane16 = M * d, ldc unused)
         if (N % 3 || (N / 3) % 256 || M % 256 || batch != 1 || head_dim <= 0 || (N / 3) % head_dim || 64 % head_dim ||
             !(flags & G16X_OUT16) || (flags & (G16X_ACCUM | G16X_GELU | G16X_OUTF32 | G16X_GELU16)) || f16 != (npl == 2) ||
@@ -826,26 +867,21 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
                    st, npl == 2 ? (terms == 3 ? "gemm16_pp_kernel<2,3,true,...> (256x256 tile, two-group phase schedule, 3x v_mfma_f32_32x32x16_f16 per algorithmic MFMA into one accumulator)" : "gemm16_pp_kernel<2,2,...> (STUDY: 2 of 3 split terms)")
                                  : (f16 ? "gemm16_pp_kernel<1,1,true,...> (STUDY: plain f16)" : "gemm16_pp_kernel<1,1,false,...> (256x256 tile, two-group phase schedule, v_mfma_f32_32x32x16_bf16)"));
     // persistent: one workgroup per CU (128 KB of LDS: one fits), each walking tiles bid, bid + grid.x, ...
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (!study_env("GENIE_PP_PERSIST", 1)) return 1 << 30;   // 0: one workgroup per tile (the non-persistent launch, for A/B runs)
-        return n > 0 ? n : 256;
-    }();
+    static const bool persist = study_env("GENIE_PP_PERSIST", 1) != 0;   // 0: one workgroup per tile (the non-persistent launch, for A/B runs)
+    const int n_cu = persist ? device_cu_count() : 1 << 30;            // (per device: common.hpp)
     const long tiles_x = (long)(M / 256) * (N / 256);
     const dim3 grid((unsigned)(tiles_x < n_cu ? tiles_x : n_cu), (unsigned)batch);
     static const int stagger = study_env("GENIE_PP_STAGGER", 0);
     static const long stagger_min = study_env("GENIE_PP_STAGGER_MIN_TILES", (int)(1024));
     if (stagger > 1 && batch == 1 && tiles >= stagger_min) flags |= (stagger & 15) << 8;
-    constexpr size_t lds = 2 * PP_BUF + 2048;   // ring + two 1 KB bias slots
+    constexpr size_t lds = 2 * PP_BUF + 2048 + 512;   // ring + two 1 KB bias slots + gamma | beta of the qk-norm epilogue
 #define PP_LAUNCH(NPL_, TERMS_, F16_, ABL_, SCHED_)                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, TERMS_, F16_, ABL_, SCHED_>,                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
         gemm16_pp_kernel<NPL_, TERMS_, F16_, ABL_, SCHED_><<<grid, 512, lds, st>>>(                                       \
             A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,     \
-            strideW, qscale, head_dim);                                                                                                     \
+            strideW, qscale, head_dim, qn_g, qn_b);                                                                                                     \
     } while (0)
 #define PP_LAUNCH_ABL(ABL_)                                                                                               \
     do {                                                                                                                  \
@@ -875,9 +911,9 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
     else if (abl == 224) PP_LAUNCH_ABL(224);   // stamps + nt on both
     else if (abl == 33) {  // stamps with the compile-time OUTF32 | NT epilogue
         if (npl == 1) { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim); }
+            gemm16_pp_kernel<1, 1, false, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim, qn_g, qn_b); }
         else { (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim); }
+            gemm16_pp_kernel<2, 3, true, 32, 0, G16X_OUTF32 | G16X_NT><<<grid, 512, lds, st>>>(A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf, strideW, qscale, head_dim, qn_g, qn_b); }
     }
     else
 #endif
@@ -885,14 +921,14 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
         // compile-time epilogues for the model's Linear flavours (qkv / readout: OUTF32; proj, fc2: ACCUM | OUTF32 [| OUT16];
         // fc1: GELU | OUT16; bf16 temporal qkv: OUT16; the training forward's fc1: OUTF32 | OUT16 | GELU16), each with and without
         // non-temporal stores; anything else takes the run-time-flag kernel (which spills: 80-236 bytes per lane)
-        const int e = flags & 127;
+        const int e = flags & 255;
 #define PP_EPI(NPL_, F16_, E_)                                                                                            \
         case E_: {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, PP_SCHED, E_>,    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             gemm16_pp_kernel<NPL_, (NPL_ == 2 ? 3 : 1), F16_, 0, PP_SCHED, E_><<<grid, 512, lds, st>>>(                   \
                 A, lda, planeA, W, ldw, planeW, bias, Cf, C16, plane16, ldc, M, N, K, flags, alpha, strideA, strideC, Rf,  \
-                strideW, qscale, head_dim);                                                                                                 \
+                strideW, qscale, head_dim, qn_g, qn_b);                                                                                                 \
             done = true;                                                                                                  \
         } break;
 #define PP_EPI_ALL(NPL_, F16_)                                                                                            \
@@ -908,6 +944,7 @@ int launch_gemm16_pp(int npl, int terms, int f16, const uint16_t* A, long lda, l
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16)                                                                    \
             PP_EPI(NPL_, F16_, G16X_GELU | G16X_OUT16 | G16X_NT)                                                          \
             PP_EPI(NPL_, F16_, G16X_OUT16 | G16X_QKV | G16X_NT)                                                           \
+            PP_EPI(NPL_, F16_, G16X_OUT16 | G16X_QKV | G16X_NT | G16X_QKNORM)   /* + per-head LayerNorm of q and k */      \
             PP_EPI(NPL_, F16_, G16X_OUTF32 | G16X_OUT16 | G16X_GELU16)         /* training forward fc1 */                 \
             PP_EPI(NPL_, F16_, G16X_OUTF32 | G16X_OUT16 | G16X_GELU16 | G16X_NT)                                          \
             default: break;                                                                                               \

@@ -64,7 +64,7 @@ def generate_frames_cached(model, example_THW: torch.LongTensor, num_prompt_fram
     assert P <= T and P >= 1
     dev = ex.device
     ids = ex.view(B, T, S)
-    ws = model._workspace(B)
+    ws = model._workspace(B, generate_prompt_frames=P)
     nbytes = lib.genie_prefix_cache_bytes(cfg, B)
     cache = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream

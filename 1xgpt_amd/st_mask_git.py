@@ -117,15 +117,15 @@ class _Packer:
         return t.data_ptr()
 
     def _frame_geometry(self):
-        # the fragment-order kernels of the one-frame passes (csrc/kernels_frame.hip): f16x3, LayerNorm blocks, heads of 64 or 32
+        # the fragment-order kernels of the one-frame passes (csrc/kernels_frame.hip): f16x3, LayerNorm or qk-norm blocks, heads of 64 or 32
         c = self.config
-        return (self.prec == _lib.PREC_F16X3 and not c.qk_norm and c.S == 256 and c.d_model in (128, 256, 512)
+        return (self.prec == _lib.PREC_F16X3 and c.S == 256 and c.d_model in (128, 256, 512)
                 and c.d_model in (64 * c.num_heads, 32 * c.num_heads) and os.environ.get("GENIE_NO_FRAME_KERNELS", "0") != "1")
 
     def frame_stream(self, *weights):
         """The given Linear weights back to back as split f16 in fragment order (genie_pack_frame_w16), or 0."""
-        if not self._frame_geometry() or any(w.shape[0] % 32 or w.shape[1] % 64 for w in weights):
-            return 0
+        if not self._frame_geometry() or any(w.shape[0] % 64 or w.shape[1] % 64 for w in weights):
+            return 0   # (output widths in 64-column tiles -- no tail handling in gemm16_fr --, contraction in 64-k blocks)
         t = torch.empty(sum(2 * w.numel() for w in weights), dtype=torch.float16, device=self.dev)
         off = 0
         for w in weights:
@@ -241,9 +241,12 @@ class STMaskGIT(nn.Module):
         self._wide = sorted(packed.wide) if packed is not None else []
         return self._table
 
-    def _workspace(self, B):
+    def _workspace(self, B, generate_prompt_frames=0):
+        """The model's workspace for B clips; generate_prompt_frames = P > 0: large enough for genie_generate_cached with P prompt frames too."""
         cfg = self._weights()[0]
         need = _lib.load().genie_workspace_bytes(cfg, B)
+        if generate_prompt_frames:
+            need = max(need, _lib.load().genie_generate_workspace_bytes(cfg, B, generate_prompt_frames))
         if self._ws is None or self._ws.numel() < need or self._ws.device != self._device():
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self._device())
@@ -451,7 +454,7 @@ class STMaskGIT(nn.Module):
             lg0 = torch.empty(B, n_new, S, V, dtype=torch.float32, device=dev) if return_logits else None
             nbytes = lib.genie_prefix_cache_bytes(cfg, B)
             cache = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            ws = self._workspace(B)
+            ws = self._workspace(B, generate_prompt_frames=n_prompt)
             _lib.check(lib.genie_generate_cached(cfg, w, clip.data_ptr(), B, n_prompt, n_new, steps, float(temperature), _lib.UNMASK_RANDOM,
                                                  0 if nz is None else nz.data_ptr(), 0 if uni is None else uni.data_ptr(), 0, 1,
                                                  gen.data_ptr(), 0 if lg0 is None else lg0.data_ptr(), cache.data_ptr(), nbytes,

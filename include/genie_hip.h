@@ -306,7 +306,8 @@ int genie_frame_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t
  * carries the first MaskGIT step of frame t + 1 (all-mask tokens), so a new frame costs `steps` passes instead of `steps + 1`
  * (generate.py:81-95: the reference recomputes everything per step).  nf == 1 is genie_frame_pass; nf > 1 returns
  * GENIE_E_UNSUPPORTED (nothing enqueued) unless the fragment-order kernels cover the model (GENIE_PREC_F16X3, head_dim 64 or 32,
- * LayerNorm blocks, S 256, frame_w16 streams present, B * nf * S <= 16,384 rows): the caller then runs the frames one by one. */
+ * LayerNorm or qk-norm blocks, S 256, vocabulary columns % 64 == 0, frame_w16 streams present, B * nf * S <= 16,384 rows): the caller then
+ * runs the frames one by one. */
 int genie_frames_pass(const genie_cfg* cfg, const genie_weights* w, const int64_t* frame_ids, int B, int t0, int nf, float* cache,
                       size_t cache_bytes, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 /* generate.py:77-103 / STMaskGIT.generate (st_mask_git.py:65-113) on the temporal KV cache, the WHOLE loop enqueued by one call (no
@@ -317,8 +318,10 @@ int genie_frames_pass(const genie_cfg* cfg, const genie_weights* w, const int64_
  * shares a two-frame pass with step 0 of frame t + 1 where the library covers it and merge_commit != 0.  noise: the unmasking draws
  * (n_new, steps - 1, B, S) f32 ('random' mode with steps > 1; st_mask_git.py:204-206 draws them with torch.rand_like); uniforms:
  * (n_new, steps, num_factored, B, S) for temperature > 0; both may be NULL otherwise.  cache: genie_prefix_cache_bytes(cfg, B);
- * workspace: genie_workspace_bytes(cfg, B).  Same frames as the full-forward schedule (generate.py:81-95) up to f32 accumulation
- * order. */
+ * workspace: genie_generate_workspace_bytes(cfg, B, P) (the loop keeps its token / sample / logits scratch behind the workspace of its
+ * largest pass; for models whose T exceeds max(P, 2) genie_workspace_bytes(cfg, B) is that large too).  Same frames as the full-forward
+ * schedule (generate.py:81-95) up to f32 accumulation order. */
+size_t genie_generate_workspace_bytes(const genie_cfg* cfg, int B, int P);
 int genie_generate_cached(const genie_cfg* cfg, const genie_weights* w, const int64_t* ids, int B, int P, int n_new, int steps,
                           float temperature, int unmask_mode, const float* noise, const float* uniforms, int teacher_force_time,
                           int merge_commit, int64_t* gen_out, float* logits0_out, float* cache, size_t cache_bytes, void* workspace,

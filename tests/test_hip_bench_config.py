@@ -58,7 +58,11 @@ def check_samples_against_reference(z, samples_clip, what):
 @pytest.mark.parametrize("name,precision", [("ev_c138", "f16x3"), ("ev_c138_h16", "f16x3"), ("ev_c138", "exact"),
                                             # the SHIPPED config (genie/configs/magvit_n32_h8_d256.json) through the same
                                             # 15-timestep loop at full depth: BASELINE config 1's workload (tools/make_goldens.py c35_ev)
-                                            ("ev_c35", "f16x3"), ("ev_c35", "exact")])
+                                            ("ev_c35", "f16x3"), ("ev_c35", "exact"),
+                                            # the reference's DEFAULT attention variant on the GENIE_138M shape (qk_norm=True, genie/config.py:33;
+                                            # tools/make_goldens.py c138_ev_qknorm), and the dataclass defaults proper (qk_norm + use_mup:
+                                            # c138_ev_default; the muP readout factor is the documented formula, mup_pinned = 0)
+                                            ("ev_c138_qknorm", "f16x3"), ("ev_c138_qknorm", "exact"), ("ev_c138_default", "f16x3")])
 def test_bench_config_against_reference_and_full_schedule(golden, name, precision):
     z, cfg, sd = golden(name)
     B = 12 if precision == "f16x3" else 4   # 12 clips x 15 frames: >= 192 tiles of 256x256 in every GEMM of the masked passes

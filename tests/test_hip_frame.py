@@ -16,8 +16,8 @@ def dev(a):
 
 
 def _model(d, heads, layers=2, precision="f16x3", seed=11, **kw):
-    cfg = pkg("config").GenieConfig(num_layers=layers, num_heads=heads, d_model=d, T=16, S=256, num_factored_vocabs=2,
-                                    qk_norm=False, use_mup=False, **kw)
+    kw = dict(dict(qk_norm=False, use_mup=False), **kw)
+    cfg = pkg("config").GenieConfig(num_layers=layers, num_heads=heads, d_model=d, T=16, S=256, num_factored_vocabs=2, **kw)
     sd = pkg("synthetic").make_state_dict(cfg, seed=seed, law="conditioned")
     g = np.random.default_rng(seed + 1)
     for k in sd:       # the synthetic law leaves biases at zero: make every bias the kernels add count
@@ -49,7 +49,11 @@ def test_pack_frame_w16_is_the_row_major_split_in_fragment_order():
 @pytest.mark.parametrize("d,heads,kw", [(512, 8, {}), (256, 4, {}), (128, 2, {}), (256, 4, dict(qkv_bias=True)),
                                         (128, 2, dict(qkv_bias=True, proj_bias=False, mlp_bias=False)),
                                         (256, 8, {}),                       # the shipped geometry magvit_n32_h8_d256: heads of 32
-                                        (512, 16, dict(qkv_bias=True)), (128, 4, {})])
+                                        (512, 16, dict(qkv_bias=True)), (128, 4, {}),
+                                        # the reference's default attention variant (genie/config.py:33: per-head LayerNorm of q and k,
+                                        # norm1 / norm2 = Identity), heads of 64 and of 32, and the dataclass defaults proper (+ muP scale)
+                                        (512, 8, dict(qk_norm=True)), (256, 8, dict(qk_norm=True, qkv_bias=True)),
+                                        (128, 2, dict(qk_norm=True, use_mup=True))])
 def test_frame_passes_equal_full_forward_frames(d, heads, kw):
     """genie_frame_pass / genie_frames_pass on the fragment-order kernels against the full 16-frame forward of the same model
     (256x256-tile GEMMs, LDS-DMA attention kernels: validated against the oracle and the reference goldens elsewhere): logits of
@@ -231,3 +235,24 @@ def test_module_generate_on_kv_cache_equals_full_forward_schedule(B, n_prompt, n
     if n_prompt + 1 < cfg.T:
         with pytest.raises(RuntimeError):
             m.generate(ids, None, max_new_tokens=S, maskgit_steps=steps, kv_cache=False)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "exact"])
+def test_generate_when_the_prompt_fills_all_but_one_frame_of_a_short_model(precision):
+    """T = 2, one prompt frame: max(P, 2) == T, so the loop scratch of genie_generate_cached does not fit behind the passes' workspace inside
+    genie_workspace_bytes(cfg, B) -- the module sizes its buffer with genie_generate_workspace_bytes and generate() (KV cache = the default)
+    works; a caller that passes the smaller buffer gets GENIE_E_ARG, nothing enqueued."""
+    cfg = pkg("config").GenieConfig(num_layers=2, num_heads=2, d_model=128, T=2, S=256, num_factored_vocabs=2, qk_norm=False, use_mup=False)
+    sd = pkg("synthetic").make_state_dict(cfg, seed=5, law="conditioned")
+    m = pkg("st_mask_git").STMaskGIT(cfg, precision=precision).load_numpy_state_dict(sd).to("cuda")
+    _lib = pkg("_lib")
+    lib = _lib.load()
+    c = m._weights()[0]
+    B, S = 2, cfg.S
+    assert lib.genie_generate_workspace_bytes(c, B, 1) > lib.genie_workspace_bytes(c, B)
+    ids = dev(pkg("synthetic").make_clips(B, cfg, seed=6)).view(B, cfg.T, S)[:, :1].reshape(B, S)
+    noise = torch.rand(1, 1, B, S, device="cuda")
+    a = m.generate(ids, None, max_new_tokens=S, maskgit_steps=2, temperature=0.0, noise=noise, kv_cache=True)
+    b = m.generate(ids, None, max_new_tokens=S, maskgit_steps=2, temperature=0.0, noise=noise, kv_cache=False)
+    assert a.shape == b.shape == (B, 2 * S) and torch.equal(a[:, :S], ids)
+    assert (a == b).float().mean().item() > 0.995
