@@ -63,7 +63,7 @@ def _build(force, verbose, LIB, OBJDIR, FLAGS):
 def build_variant(name, defines, verbose=False):
     """An A/B variant of the SHIPPING library (same flags plus `defines`, e.g. ["-DGENIE_VAR_NO_LNOUT"]) in
     1xgpt_amd/lib_ab_<name>.so (in-tree so that it travels to the GPU box; *.so is git-ignored) -- loaded with
-    GENIE_HIP_LIBRARY=<path> by tools/gpu_fwd_ab.sh / tools/gpu_lib_ab2.sh for same-box comparisons."""
+    GENIE_HIP_LIBRARY=<path> by `tools/gpu_run.sh ab <tag> <name> ...` for same-box comparisons."""
     return _build(False, verbose, os.path.join(HERE, f"lib_ab_{name}.so"), os.path.join(HERE, "build", "ab", name), FLAGS + list(defines))
 
 

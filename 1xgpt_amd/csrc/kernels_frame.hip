@@ -896,6 +896,194 @@ __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __re
     *reinterpret_cast<u32x2*>(dst + 4 * FR) = u32x2{l01, l23};
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// ONE-frame passes below 2,048 rows: the temporal qkv Linear AND the temporal decode attention in one launch (round 6).
+// Workgroup = (32-row block of the pass, head h): it computes q_h | k_h | v_h of its rows -- three phases of the register-direct
+// split-K Linear above (same k-block per wave, same wave order in the reduce, same bias add: the cache rows it writes carry the bits
+// gemm16_fr_kernel<NW, ., DH / 32, 1, FR_EPI_F32> writes) -- and then attends: rows 4 w .. 4 w + 3 go to wave w with the lane mapping and
+// the arithmetic of attn_temporal_fr_kernel (lane (g, c): frames FPI i + g, features 4 c .. + 3), q and the frame-t slices of k, v
+// from the workgroup's LDS tiles, slots j < t from the cache (requested right behind the last phase's matrix instructions, so their
+// round trip hides under that phase's reduce).  A workgroup streams 3 x DH x K x 4 B of weights (384 KB at d = 512) instead of 128 KB
+// per workgroup of the plain Linear; what it saves is one launch + its boundary and the attention kernel's own memory round trip.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct FrQkvtArgs {
+    const uint16_t* A;       // fragment-ordered operand copy of x: (M / 32) row blocks x (K / 64) k-blocks
+    const uint16_t* W;       // fragment-ordered temporal qkv weight (3 d, K)
+    const float* bias;       // (3 d) or NULL
+    float* cache;            // this layer's (B, T, S, 3 d) f32 cache slice
+    uint16_t* out16;         // attention output, fragment order (the out-projection's A operand)
+    const float* qn_g;       // qk-norm affine (DH floats each) or NULL
+    const float* qn_b;
+    int K, H, S, T, t;       // contraction, heads, rows per frame, cache slots per clip, the frame of this pass
+    float scale;
+};
+
+template <int NW, int DH>
+__global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW >= 4 ? NW / 4 : 1, NW >= 4 ? NW / 4 : 1)))
+void qkvt_attn_fr_kernel(const FrQkvtArgs a) {
+    constexpr int NT = NW * 64, NJ = DH / 32, TN = DH, PITCH = TN + 4, C4 = TN / 4, ITEMS = 32 * C4, PASSES = (ITEMS + NT - 1) / NT;
+    constexpr int LPF = DH / 4, FPI = 64 / LPF, NI = 16 / FPI, RPW = 32 / NW;   // attention: lanes per frame, frames per instruction, instructions; rows per wave
+    static_assert(NT % C4 == 0, "a thread keeps its columns over the passes of the row-major phase");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);                       // [NW][32][PITCH] partial tiles
+    float* til = red + (size_t)NW * 32 * PITCH;                        // [3][32][PITCH]: q | k | v of the rows, this head
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = blockIdx.x, head = blockIdx.y;
+    const int KB = a.K / 64, d = a.H * DH;
+    asm volatile("" :: "s"(a.A), "s"(a.W), "s"(a.bias), "s"(a.cache), "s"(a.K), "s"(a.H), "s"(a.S), "s"(a.T), "s"(a.t));
+    // ---- requests: biases of the three phases, A fragments of this wave's k-block, the weight fragments of q and k
+    f32x4 pre_b[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        pre_b[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) pre_b[p] = *reinterpret_cast<const f32x4*>(a.bias + p * d + head * DH + (tid % C4) * 4);
+    }
+    u32x4 af[NPL][4], wf[2][NJ][NPL][4];
+    {
+        const uint16_t* src = a.A + fr_frag(rb, wid, KB, 0, 0) + lane * 8;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * FR);
+    }
+    auto load_w = [&](int slot, int ph) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const uint16_t* src = a.W + fr_frag((long)(ph * d + head * DH) / 32 + j, wid, KB, 0, 0) + lane * 8;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wf[slot][j][p][s] = *reinterpret_cast<const u32x4*>(src + (p * 4 + s) * FR);
+        }
+    };
+    load_w(0, 0);
+    load_w(1, 1);
+    FR_PIN_LOADS();
+    // the pass's rows are (clip b, frame t, position s): row block rb = b * (S / 32) + s / 32
+    const int blocks = a.S / 32;
+    const long b = rb / blocks;
+    const int s0 = (rb % blocks) * 32;
+    const size_t tok = (size_t)a.S * 3 * d;                                     // one cache slot of a clip
+    float* const slot_t = a.cache + ((size_t)(b * a.T + a.t) * a.S + s0) * 3 * d;   // row s0 of slot t
+    f32x4 kv[RPW][NI], vv[RPW][NI];
+    const int g = lane / LPF, c = lane % LPF;
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {
+        f32x16 accm[NJ], accc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accm[j][e] = 0.f; accc[j][e] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                accm[j] = mma16(af[0][s], wf[ph & 1][j][0][s], accm[j]);
+                accc[j] = mma16(af[0][s], wf[ph & 1][j][1][s], accc[j]);
+                accc[j] = mma16(af[1][s], wf[ph & 1][j][0][s], accc[j]);
+            }
+        if (ph == 0) { load_w(0, 2); FR_PIN_LOADS(); }
+        if (ph == 2) {
+            // the cached k, v slices of this wave's rows (slots j < t of the same clip and position), one head slice per frame
+#pragma unroll
+            for (int r4 = 0; r4 < RPW; ++r4) {
+                const float* hb = a.cache + ((size_t)(b * a.T) * a.S + s0 + RPW * wid + r4) * 3 * d + head * DH + 4 * c;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int j = FPI * i + g;
+                    kv[r4][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    vv[r4][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (j < a.t) {
+                        kv[r4][i] = *reinterpret_cast<const f32x4*>(hb + (size_t)j * tok + d);
+                        vv[r4][i] = *reinterpret_cast<const f32x4*>(hb + (size_t)j * tok + 2 * d);
+                    }
+                }
+            }
+            FR_PIN_LOADS();
+        }
+        {   // partial tile (accumulator element e of lane (r, h): row 8 (e >> 2) + 4 h + (e & 3), column r)
+            const int r = lane & 31, h = lane >> 5;
+            float* mine = red + (size_t)wid * 32 * PITCH;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mine[(8 * (e >> 2) + 4 * h + (e & 3)) * PITCH + 32 * j + r] = accm[j][e] + accc[j][e] * (1.0f / 2048.0f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const int idx = tid + q * NT;
+            if (idx < ITEMS) {
+                const int rl = idx / C4, c4 = (idx % C4) * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(red + rl * PITCH + c4);
+#pragma unroll
+                for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 32 + rl) * PITCH + c4);
+                v = v * 1.0f + pre_b[ph];
+                *reinterpret_cast<f32x4*>(slot_t + (size_t)rl * 3 * d + ph * d + head * DH + c4) = v;
+                *reinterpret_cast<f32x4*>(til + ((size_t)ph * 32 + rl) * PITCH + c4) = v;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- decode attention of rows RPW wid .. (attn_temporal_fr_kernel's arithmetic, lane for lane)
+    f32x4 qg = f32x4{0.f, 0.f, 0.f, 0.f}, qb = qg;
+    if (a.qn_g) { qg = *reinterpret_cast<const f32x4*>(a.qn_g + 4 * c); qb = *reinterpret_cast<const f32x4*>(a.qn_b + 4 * c); }
+    const int t = a.t;
+#pragma unroll
+    for (int r4 = 0; r4 < RPW; ++r4) {
+        const int rl = RPW * wid + r4;
+        f32x4 qv = *reinterpret_cast<const f32x4*>(til + (size_t)rl * PITCH + 4 * c);
+        const f32x4 kt = *reinterpret_cast<const f32x4*>(til + ((size_t)32 + rl) * PITCH + 4 * c);
+        const f32x4 vt = *reinterpret_cast<const f32x4*>(til + ((size_t)64 + rl) * PITCH + 4 * c);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (FPI * i + g >= t) { kv[r4][i] = kt; vv[r4][i] = vt; }        // frame t itself (frames past t repeat it: their probability is 0)
+        if (a.qn_g) {
+            qv = head_layer_norm(qv, DH, qg, qb);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) kv[r4][i] = head_layer_norm(kv[r4][i], DH, qg, qb);
+        }
+        float sc[NI];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float part = fmaf(qv[3], kv[r4][i][3], fmaf(qv[2], kv[r4][i][2], fmaf(qv[1], kv[r4][i][1], qv[0] * kv[r4][i][0])));
+            if constexpr (LPF == 16) part = row16_sum(part);
+            else {
+#pragma unroll
+                for (int o = 1; o < LPF; o <<= 1) part += __shfl_xor(part, o);
+            }
+            sc[i] = (FPI * i + g <= t) ? part * a.scale : -INFINITY;
+            mx = fmaxf(mx, sc[i]);
+        }
+#pragma unroll
+        for (int o = LPF; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { sc[i] = (FPI * i + g <= t) ? expf(sc[i] - mx) : 0.f; sum += sc[i]; }
+#pragma unroll
+        for (int o = LPF; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i) o += vv[r4][i] * (sc[i] * inv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int x = LPF; x < 64; x <<= 1) o[e] += __shfl_xor(o[e], x);
+        }
+        if (g == 0) {
+            uint32_t h01, h23, l01, l23;
+            split_f16_x4(o[0], o[1], o[2], o[3], h01, h23, l01, l23);
+            const int col = head * DH + 4 * c;
+            uint16_t* dst = a.out16 + fr_frag(rb, col >> 6, d >> 6, 0, (col & 63) >> 4) + (32 * ((col >> 3) & 1) + rl) * 8 + (col & 7);
+            *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
+            *reinterpret_cast<u32x2*>(dst + 4 * FR) = u32x2{l01, l23};
+        }
+    }
+}
+
 // f32 rows (M, K) -> fragment-ordered split operand (the activation split: split8).  qk-norm blocks have no LayerNorm in front of their
 // spatial qkv Linear (norm1 = Identity, st_transformer.py:44): the first block of a pass reads this copy of the embedded rows, every later
 // Linear reads the copy its producer's epilogue wrote.  One thread per 16-byte piece of the hi plane.
@@ -1057,6 +1245,34 @@ int launch_ln_fr(const float* x, long ldx, const float* g, const float* b, float
 }
 }  // namespace
 
+namespace {
+template <int NW, int DH>
+int launch_qkvt_attn_t(const FrQkvtArgs& q, unsigned row_blocks, unsigned heads, hipStream_t st) {
+    constexpr size_t lds = ((size_t)NW * 32 + 3 * 32) * (DH + 4) * 4;
+    static PerDevice<bool> attr_set;
+    if (attr_set.needs()) {
+        (void)hipFuncSetAttribute((const void*)qkvt_attn_fr_kernel<NW, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set.set(true);
+    }
+    qkvt_attn_fr_kernel<NW, DH><<<dim3(row_blocks, heads), NW * 64, lds, st>>>(q);
+    GENIE_LAUNCH_CHECK("qkvt_attn_fr");
+    return GENIE_OK;
+}
+int launch_qkvt_attn(int nw, int dh, const FrQkvtArgs& q, unsigned row_blocks, unsigned heads, hipStream_t st) {
+    if (dh == 64) {
+        if (nw == 8) return launch_qkvt_attn_t<8, 64>(q, row_blocks, heads, st);
+        if (nw == 4) return launch_qkvt_attn_t<4, 64>(q, row_blocks, heads, st);
+        // (2 waves x 16 rows each: the cached k / v slices of 16 rows do not fit the registers -- 568 bytes of scratch; that width keeps the two launches)
+    } else if (dh == 32) {
+        if (nw == 8) return launch_qkvt_attn_t<8, 32>(q, row_blocks, heads, st);
+        if (nw == 4) return launch_qkvt_attn_t<4, 32>(q, row_blocks, heads, st);
+        if (nw == 2) return launch_qkvt_attn_t<2, 32>(q, row_blocks, heads, st);
+    }
+    set_error("qkvt_attn_fr: width %d / head_dim %d not covered", 64 * nw, dh);
+    return GENIE_E_UNSUPPORTED;
+}
+}  // namespace
+
 bool frame_path_takes(const genie_cfg& c, const genie_layer_weights& lw, long rows) {
     static const int on = study_env("GENIE_FRAME_KERNELS", 1);
     // LayerNorm blocks need norm1 / norm2; qk-norm blocks (norm1 = norm2 = Identity, st_transformer.py:44,67) the two per-head affines
@@ -1100,6 +1316,9 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
     a.alpha = 1.0f;
     a.M = M;
     a.rows_per_batch = M;
+    // (Tried and dropped in round 6: extra workgroups that touch the NEXT Linear's weight tiles, XCD-targeted, so that its loads would hit
+    // L2 / the Infinity Cache: neutral at 4 prefetch workgroups per XCD, slower below -- a prefetch workgroup streams at the same per-CU
+    // rate as everybody else and outlives the Linear it rides in; profiles/r06e_weight_prefetch_ab.txt.)
     // ---- spatial: LayerNorm + qkv -> attention operand planes; attention; out-projection + residual (+ operand copy of x)
     // (qk-norm blocks: no LayerNorm in front -- the Linear reads the operand copy of x -- and q, k leave through the per-head LayerNorm)
     const bool qkn = c.qk_norm != 0;
@@ -1153,6 +1372,26 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
         else GENIE_TRY((launch_fr_w<1, 1, FR_EPI_RES, false>(nw, g, st)));
     }
     // ---- temporal: qkv -> cache slots t0 .. ; decode attention over the cache; out-projection + residual
+    // one-frame passes on the register-direct kernels: both as ONE launch (qkvt_attn_fr_kernel)
+    // MEASURED SLOWER and therefore off in the shipping library (profiles/r06d_qkvt_attn_merge_ab.txt, same box: batch 1 4.67 against 4.40 ms
+    // per frame at 2 steps, 16.35 against 14.63 at 8): 64 workgroups streaming 384 KB each run at the per-CU rate of a fragment stream
+    // (bytes in flight / latency: ~64 GB/s), three reduce rounds deep -- more than the launch + boundary + round trip the merge removes.
+    // -DGENIE_VAR_QKVT_ATTN builds the variant (python 1xgpt_amd/build.py --variant qkvt -DGENIE_VAR_QKVT_ATTN); bit-identical results.
+#ifdef GENIE_VAR_QKVT_ATTN
+    static const int merged_on = 1;
+#else
+    static const int merged_on = study_env("GENIE_FRAME_QKVT_ATTN", 0);
+#endif
+    const bool merged_t = merged_on && nf == 1 && !mid && (nw == 8 || nw == 4 || (nw == 2 && c.head_dim == 32)) && w.frame_T <= 16;
+    if (merged_t) {
+        FrQkvtArgs q;
+        q.A = xs; q.W = wq_t; q.bias = c.qkv_bias ? lw.temporal.qkv_b : nullptr; q.cache = w.fcache; q.out16 = as;
+        q.qn_g = qkn ? lw.temporal.norm_w : nullptr; q.qn_b = qkn ? lw.temporal.norm_b : nullptr;
+        q.K = d; q.H = H; q.S = S; q.T = w.frame_T; q.t = w.frame_t; q.scale = c.attn_scale;
+        ProfScope prof(GENIE_KC_GEMM, 2.0 * M * 3.0 * d * d + 4.0 * (w.frame_t + 1) * c.head_dim * (double)M * H,
+                       4.0 * M * d + 4.0 * 3 * d * d + 4.0 * M * 3 * d, st, "qkvt_attn_fr_kernel (temporal qkv -> cache + decode attention)");
+        GENIE_TRY(launch_qkvt_attn(nw, c.head_dim, q, (unsigned)(M / 32), (unsigned)H, st));
+    } else {
     {
         FrGemmArgs g = a;
         g.A = xs; g.W = wq_t; g.bias = c.qkv_bias ? lw.temporal.qkv_b : nullptr; g.N = 3 * d; g.K = d;
@@ -1174,6 +1413,7 @@ int st_block_frame_f16x3(const genie_cfg& c, const genie_layer_weights& lw, floa
             attn_temporal_fr_kernel<32><<<(unsigned)((n + 3) / 4), 256, 0, st>>>(w.fcache, as, n, w.frame_T, S, w.frame_t, nf, d, H, c.attn_scale,
                                                                                  qkn ? lw.temporal.norm_w : nullptr, qkn ? lw.temporal.norm_b : nullptr);
         GENIE_LAUNCH_CHECK("attn_temporal_fr");
+    }
     }
     {
         FrGemmArgs g = a;

@@ -47,3 +47,12 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def record_measure(key, value):
+    """Append `key value` to the file named by GENIE_TEST_RECORD (if set): the measured deltas behind the tolerance bars of the bf16-vs-
+    reference tests, so that a bar can be kept at ~10x what is measured (tools/gpu_run.sh suite collects them into profiles/)."""
+    path = os.environ.get("GENIE_TEST_RECORD")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{key} {value:.6e}\n")

@@ -8,7 +8,7 @@ import math
 import numpy as np
 import pytest
 
-from conftest import pkg
+from conftest import pkg, record_measure
 from oracle import genie_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -96,7 +96,8 @@ def test_ce_and_sampling_vs_bf16_oracle(golden, models, name):
     out = m(dev(z["fwd_input"]), dev(z["ids"]))
     loss16, acc16, _ = O.forward_loss_acc(z["fwd_input"], z["ids"], sd, cfg, O.BF16_MFMA)
     assert abs(out.loss.item() - loss16) < 2e-3
-    assert abs(out.loss.item() - float(z["fwd_loss"])) < 5e-2   # vs f32 reference: bf16 costs ~1e-2 in CE
+    record_measure(f"bf16_tiny[{name}].loss_minus_reference", out.loss.item() - float(z["fwd_loss"]))
+    assert abs(out.loss.item() - float(z["fwd_loss"])) < 1.5e-2   # vs f32 reference on 768 tokens: measured 7e-4 / -1.4e-3 (profiles/r06_bf16_deltas.txt)
     H = W = math.isqrt(cfg.S)
     prompt = dev(z["ids"]).view(-1, cfg.T, H, W).clone()
     prompt[:, 2:] = cfg.image_vocab_size
@@ -117,7 +118,8 @@ def test_real_geometry_vs_bf16_oracle(golden, models, name):
     out = m(dev(x.reshape(1, -1)), dev(ids))
     loss16, acc16, lg16 = O.forward_loss_acc(x.reshape(1, -1), ids, sd, cfg, O.BF16_MFMA)
     assert abs(out.loss.item() - loss16) < 2e-3
-    assert abs(out.loss.item() - float(z["fwd_loss"])) < 5e-2
+    record_measure(f"bf16_real_geometry[{name}].loss_minus_reference", out.loss.item() - float(z["fwd_loss"]))
+    assert abs(out.loss.item() - float(z["fwd_loss"])) < 7e-3   # measured 2e-5 ... -6.4e-4 (profiles/r06_bf16_deltas.txt)
     lg = out.logits.cpu().numpy()
     err = np.abs(lg - lg16)
     # same rounding points, but with 4096 tokens x several bf16 rounding points a handful of activations sit on
@@ -158,7 +160,8 @@ def test_full_size_anchor_bf16(golden, models):
     x = ids.view(-1, 16, 16, 16).clone()
     x[:, 8:] = cfg.image_vocab_size
     out = m(x.view(1, -1), ids)
-    assert abs(out.loss.item() - float(z["fwd_loss"])) < 0.1
+    record_measure("bf16_anchor_c138.loss_minus_reference", out.loss.item() - float(z["fwd_loss"]))
+    assert abs(out.loss.item() - float(z["fwd_loss"])) < 3e-3   # measured 2.5e-4 (profiles/r06_bf16_deltas.txt)
     lg = out.logits.cpu().numpy()
     probe = np.stack([lg[:, :, t, s // 16, s % 16] for t, s in zip(z["probe_t"], z["probe_s"])], 1)
     print("bf16 vs f32 reference: CE delta", out.loss.item() - float(z["fwd_loss"]), "max |dlogit|",

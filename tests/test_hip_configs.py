@@ -170,7 +170,9 @@ def test_config2_c35_bf16_batch64(golden):
     eu = pkg("eval_utils")
     ce = [eu.compute_loss(dev(ids[b:b + 1]), fl[b:b + 1].contiguous()) for b in range(B)]
     # clip 0 against the f32 reference golden (bf16 noise over 32 layers) ...
-    assert abs(ce[0] - float(z["fwd_compute_loss_allframes"])) < 0.1
+    from conftest import record_measure
+    record_measure("config2.bf16_ce0_minus_reference", ce[0] - float(z["fwd_compute_loss_allframes"]))
+    assert abs(ce[0] - float(z["fwd_compute_loss_allframes"])) < 1e-3   # measured -4.3e-5 (profiles/r06_bf16_deltas.txt)
     # ... clips 0 and 63 against the bf16-contract oracle (same rounding points: tight) ...
     for b in (0, B - 1):
         lo = O.compute_logits(x[b:b + 1], sd, cfg, O.BF16_MFMA)

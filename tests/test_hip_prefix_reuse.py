@@ -64,7 +64,9 @@ def test_reuse_equals_full_forward_path(golden, steps):
 def test_reuse_bf16_close(golden):
     z, cfg, ev = make_ev(golden, "shape_dh64", "bf16")
     sums = ev.evaluate_metric_sums_reuse(dev(z["ids"]), noise=dev(z["ev_noise"])).tolist()
-    assert abs(sums[0] / sums[1] - float(z["ev_loss"])) < 5e-2
+    from conftest import record_measure
+    record_measure("prefix_reuse.bf16_ce_minus_reference", sums[0] / sums[1] - float(z["ev_loss"]))
+    assert abs(sums[0] / sums[1] - float(z["ev_loss"])) < 5e-3   # measured -4.1e-4 (profiles/r06_bf16_deltas.txt)
 
 
 @pytest.mark.parametrize("precision", ["exact", "f16x3"])

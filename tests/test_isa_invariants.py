@@ -44,7 +44,10 @@ def test_phase_scheduled_gemm_flavours_have_no_scratch_and_one_drain(rows):
         if name.rstrip().endswith(", -1>"):
             continue
         assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane"
-        assert full <= 1, f"{name}: {full} x s_waitcnt vmcnt(0) (1 is hand-written)"
+        # the qk-norm flavours (epilogue flag 128) load gamma | beta with plain loads at kernel START, before the first LDS-DMA is
+        # requested: one more full drain, outside the persistent loop
+        qknorm = (int(name.rstrip().rstrip(">").split(",")[-1]) & 128) != 0
+        assert full <= (2 if qknorm else 1), f"{name}: {full} x s_waitcnt vmcnt(0) (1 is hand-written)"
         assert dma >= 40 and mfma >= 128 and vgpr <= 256
 
 

@@ -180,7 +180,7 @@ def test_torch_port_matches_oracle(golden):
         assert np.abs(lg - O.compute_logits(x, sd, cfg)).max() < 2e-5 * max(1.0, float(np.abs(z["logits"]).max()) / 8)
 
 
-@pytest.mark.parametrize("name", ["ev_c138", "ev_c138_h16", "ev_c138_qknorm", "ev_c138_default"])
+@pytest.mark.parametrize("name", ["ev_c138", "ev_c138_h16", "ev_c138_qknorm", "ev_c138_default", "ev_c138_robust", "ev_c35_robust"])
 def test_bench_workload_golden(golden, name):
     """The benchmarked workload at full size (bench.py's weights and clip 0 through the reference's teacher-forced evaluate,
     tools/make_goldens.py c138_ev): the oracle's MaskGIT loop over the torch-CPU port of the forward reproduces the reference's
