@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
     // ---- per-lane source offsets of the LDS-DMA pieces (bytes, relative to the item / chunk base in the scalar offset)
     constexpr int NPW = (PCC + 7) / 8;          // chunk pieces per wave (waves beyond PCC issue none)
     static_assert(NPW <= 2 && PCQ <= 8, "piece tables");
-    unsigned voK[2], voV[2], voQ[8];  // literal bounds: a captured array whose bound is a dependent constexpr local makes the
+    unsigned voK[2], voV[2];  // literal bounds: a captured array whose bound is a dependent constexpr local makes the
                                       // HOST-side instantiation of the kernel silently invalid (no device stub is emitted)
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
@@ -117,13 +117,18 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
             voV[j] = (unsigned)((size_t)pl * P * 2 + ((size_t)f * 256 + slot * 8) * 2);
         }
     }
+    // Q pieces: piece j = (plane pl, rows pp * (1024 / ROWB) ..) of this wave's tile.  The lane part of the source offset depends on pp only
+    // through the slot swizzle ((row / RPB) % SPR = (4 pp + lane-part) % SPR: two distinct values at most), the rest is wave-uniform and
+    // rides in the scalar offset -- 2 address registers instead of PCQ (8 at head_dim 64 with split operands)
+    constexpr int RPP = 1024 / ROWB;            // rows per piece
+    unsigned voQ2[2];
 #pragma unroll
-    for (int j = 0; j < PCQ; ++j) {
-        const int pl = j / (32 * ROWB / 1024), pp = j % (32 * ROWB / 1024);
-        const int row = pp * (1024 / ROWB) + lane / SPR;
+    for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = q2 * RPP + lane / SPR;
         const int slot = (lane % SPR) ^ ((row / RPB) % SPR);
-        voQ[j] = (unsigned)((size_t)pl * P * 2 + ((size_t)(wid * 32 + row) * DH + slot * 8) * 2);
+        voQ2[q2] = (unsigned)(((size_t)(lane / SPR) * DH + slot * 8) * 2);
     }
+    static_assert((2 * RPP / RPB) % SPR == 0 || SPR == 8, "swizzle period of the Q pieces");
     int issued = 0;                              // VMEM operations this wave has issued so far
     int idx_slot[4] = {0, 0, 0, 0};              // value of `issued` right after the chunk now owning slot s was issued
     int idx_q = 0;
@@ -151,8 +156,10 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
 #pragma unroll
         for (int j = 0; j < PCQ; ++j) {
             if (j >= j0 && j < j1) {
+                const int pl = j / (32 * ROWB / 1024), pp = j % (32 * ROWB / 1024);
+                const unsigned srow = (unsigned)((size_t)pl * P * 2) + (unsigned)((wid * 32 + pp * RPP) * ROWB);   // wave-uniform
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(smem + OFF_Q + wid * QW + j * 1024),
-                                                         16, voQ[j], soff, 0, 0);
+                                                         16, voQ2[pp & 1], (int)((unsigned)soff + srow), 0, 0);
                 ++issued;
             }
         }
@@ -187,7 +194,34 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
         f32x16 sc[8];
         f32x16 oacc[NDT];
         s16x8 qf[NPL][KK], qup[KK];
-        float mx = 0.f, inv = 0.f;
+        // ONLINE softmax per 64-key chunk (round 6): chunk c's 32 scores of this lane are exponentiated against the chunk's OWN maximum
+        // mloc[c] one phase after its matrix instructions -- VALU work that now sits between the next chunk's matrix instructions instead of
+        // in one block behind the last S tile with the matrix pipe idle -- and rescaled by fsc[c] = 2^(mloc[c] - max) where the probabilities
+        // are packed for P V (folded into the 2^11 scaling of the split, so the rescale costs nothing there).
+        float mloc[4], psum[4], fsc[4];
+        float inv = 0.f;
+        constexpr float UNS = NPL == 2 ? 1.0f / 2048.0f : 1.0f;
+        auto softmax_chunk = [&](int c) {    // tiles 2c, 2c + 1 -> un-normalised probabilities relative to the chunk maximum
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m = fmaxf(m, sc[2 * c + t][e]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const float mc = m * UNS;
+            mloc[c] = mc;
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sc[2 * c + t][e] = __builtin_amdgcn_exp2f(fmaf(sc[2 * c + t][e], UNS, -mc));
+                    sum += sc[2 * c + t][e];
+                }
+            psum[c] = sum;
+            // (pinned here: left alone, the compiler sinks all 96 exponentials of chunks 0-2 down to their first use in phase 4)
+            asm volatile("" : "+v"(sc[2 * c]), "+v"(sc[2 * c + 1]), "+v"(psum[c]), "+v"(mloc[c]));
+        };
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             // ---- chunk p of this item (and, for p = 0, this wave's Q tile) must have landed; then every wave's share has
@@ -213,13 +247,16 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk)
                         qf[pl][kk] = *reinterpret_cast<const s16x8*>(smem + OFF_Q + wid * QW + pl * 32 * ROWB + offK[kk]);
+            }
+            if (p < 4) {
+                // (2048 q_hi is re-made per phase -- 16 packed multiplies -- instead of living in 16 registers through the S phases:
+                // the online softmax's in-flight values need them)
                 if constexpr (NPL == 2) {
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk)
                         qup[kk] = __builtin_bit_cast(s16x8, __builtin_bit_cast(f16x8, qf[0][kk]) * (_Float16)2048.0f);
+                    asm volatile("" : "+v"(qup[0]), "+v"(qup[KK - 1]));
                 }
-            }
-            if (p < 4) {
                 // ---- S^T tiles 2p, 2p+1: sc[kt][e] = score(key kt*32 + (e&3) + 8(e>>2) + 4h, query r) (x 2048 when split)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -240,24 +277,23 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
                     }
                     sc[(p & 3) * 2 + t] = a;
                 }
-                if (p == 3) {
-                    // ---- softmax over the 256 keys of query r (128 in this lane, 128 in lane r ^ 32), log2 domain
-                    constexpr float UNS = NPL == 2 ? 1.0f / 2048.0f : 1.0f;
-                    float m = -INFINITY;
-#pragma unroll
-                    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) m = fmaxf(m, sc[kt][e]);
-                    m = fmaxf(m, __shfl_xor(m, 32));
-                    mx = m * UNS;
+#ifdef GENIE_VAR_ATTN_BLOCK_SOFTMAX   // (A/B variant: all exponentials in one block behind the last S tile, as before round 6)
+                if (p == 3) { softmax_chunk(0); softmax_chunk(1); softmax_chunk(2); }
+#else
+                if (p >= 1) softmax_chunk(p - 1);     // (independent of this phase's matrix instructions: the scheduler interleaves them)
+#endif
+            } else {
+                if (p == 4) {
+                    // chunk 3's maximum closes the row maximum (both halves of the row: mloc is already lane-pair uniform); its
+                    // exponentials are only needed in phase 7 but cost nothing here, between this phase's matrix instructions
+                    softmax_chunk(3);
+                    const float mx = fmaxf(fmaxf(mloc[0], mloc[1]), fmaxf(mloc[2], mloc[3]));
                     float sum = 0.f;
 #pragma unroll
-                    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            sc[kt][e] = __builtin_amdgcn_exp2f(fmaf(sc[kt][e], UNS, -mx));
-                            sum += sc[kt][e];
-                        }
+                    for (int c = 0; c < 4; ++c) {
+                        fsc[c] = __builtin_amdgcn_exp2f(mloc[c] - mx);
+                        sum = fmaf(psum[c], fsc[c], sum);
+                    }
                     sum += __shfl_xor(sum, 32);
                     inv = 1.0f / sum;
 #pragma unroll
@@ -265,8 +301,8 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
 #pragma unroll
                         for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
                 }
-            } else {
                 // ---- O += P V over keys (p-4)*64 .. +63: slot s of MFMA m of key tile kt is key kt*32 + 4h + (s&3) + 8(s>>2) + 16m
+                const float fchunk = fsc[(p - 4) & 3];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int kt = (p - 4) * 2 + t;
@@ -278,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
 #pragma unroll
                             for (int s2 = 0; s2 < 8; s2 += 2) {
                                 const f32x2v pv = {sc[kt][8 * m + s2], sc[kt][8 * m + s2 + 1]};
-                                const f32x2v ps = pv * 2048.0f;
+                                const f32x2v ps = pv * (2048.0f * fchunk);   // p = 2^(s - chunk max) * 2^(chunk max - row max), scaled 2^11
                                 const f16x2v u2 = __builtin_convertvector(ps, f16x2v);
                                 const f32x2v rem = ps - __builtin_convertvector(u2, f32x2v);
                                 const f16x2v l2 = __builtin_convertvector(rem, f16x2v);
@@ -289,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void attn_spatial_dma_kernel(const uint16_t
                             pa = __builtin_bit_cast(s16x8, up); pb = __builtin_bit_cast(s16x8, hi); pc = __builtin_bit_cast(s16x8, lo);
                         } else {
 #pragma unroll
-                            for (int s2 = 0; s2 < 8; ++s2) pa[s2] = (short)f32_to_bf16(sc[kt][8 * m + s2]);
+                            for (int s2 = 0; s2 < 8; ++s2) pa[s2] = (short)f32_to_bf16(sc[kt][8 * m + s2] * fchunk);
                         }
                         // the planes store the keys of a 16-key group as {0-3, 8-11 | 4-7, 12-15}: unit h is exactly the 8 keys
                         // lane half h feeds to MFMA m (slots 0..3 -> key0 + 0..3, slots 4..7 -> key0 + 8..11): one ds_read_b128
