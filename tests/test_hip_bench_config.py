@@ -151,7 +151,7 @@ def test_bench_config_64_clip_shard(golden):
         assert abs(ce_clip[b] - float(z["ev_loss"])) < 1e-4, (b, ce_clip[b], float(z["ev_loss"]))
 
 
-@pytest.mark.parametrize("name,B", [("ev_c138", 12), ("ev_c35", 12)])
+@pytest.mark.parametrize("name,B", [("ev_c138", 12), ("ev_c35", 12), ("ev_c138_qknorm", 12)])
 def test_bench_config_bf16_schedules_agree(golden, name, B):
     """The throughput precision reported beside the headline: reuse and full-forward schedules agree with each other to bf16
     noise, and sit within bf16 noise of the f32 reference (CE within BF16_CE_BAR; DESIGN.md section 2 -- not a parity mode).  For the shipped
