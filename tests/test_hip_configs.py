@@ -138,10 +138,18 @@ def test_f16x3_weight_beyond_32_falls_back_per_tensor():
     g = np.random.default_rng(3)
     ts, ss = g.integers(0, 16, 48), g.integers(0, 256, 48)
     for b in (0, B - 1):
-        ref = O.compute_logits(x[b:b + 1], sd, cfg, O.F32)
-        a, r = _probe(lg[b:b + 1], ts, ss), _probe(ref, ts, ss)
-        err = np.abs(a - r) / np.maximum(1.0, np.abs(r) / 4.0)      # channel 3 of the readout is 300x the others
-        assert err.max() < 5e-5, (b, err.max())
+        # the scaled rows make the hidden state ~10x its usual size (std 6, max 55), so f32 arithmetic itself sits ~1e-4 from the truth here:
+        # the yardstick is the F64 oracle, and the bar is the F32 oracle's OWN distance from it on the same probes (x3) -- "f32-class".
+        # (A fixed 5e-5 against the F32 oracle passed or failed on which f32 summation order a kernel happened to share with NumPy: round 6's
+        # online-softmax attention kernel is as close to the f64 truth as its predecessor -- max 1.07e-4, mean 3.08e-6 on the layer-2 hidden
+        # state, both -- and failed it.)
+        r64 = _probe(O.compute_logits(x[b:b + 1], sd, cfg, O.F64), ts, ss)
+        r32 = _probe(O.compute_logits(x[b:b + 1], sd, cfg, O.F32), ts, ss)
+        a = _probe(lg[b:b + 1], ts, ss)
+        norm = np.maximum(1.0, np.abs(r64) / 4.0)                    # channel 3 of the readout is 300x the others
+        err, own = np.abs(a - r64) / norm, np.abs(r32 - r64) / norm
+        assert err.max() < 3.0 * own.max() + 2e-5, (b, err.max(), own.max())
+        assert np.median(err) < 3.0 * np.median(own) + 2e-6, (b, np.median(err), np.median(own))
     # an |w| beyond the f16 range cannot be represented by the split at all: refused at load time
     sd["out_x_proj.weight"][3, 0] = 1.0e5
     m2 = pkg("st_mask_git").STMaskGIT(cfg, precision="f16x3").load_numpy_state_dict(sd).to("cuda")
