@@ -821,7 +821,7 @@ __global__ void cast16_kernel(const float* __restrict__ src, uint16_t* __restric
 // Spatial attention on the fused operand path: the QKV GEMM writes [Q * scale * log2e | K | V^T] as 16-bit planes in the
 // attention kernel's own layout (kernels_gemm_pp.hip, G16X_QKV) and kernels_attn_dma.hip streams them through LDS -- no f32
 // qkv round trip, no operand split / transpose inside the attention kernel.  Covers the shipped geometry (S = 256, head_dim
-// 32 / 64, d % 256 == 0, LayerNorm blocks, chip-filling batches); anything else returns GENIE_E_UNSUPPORTED and the caller
+// 32 / 64, d % 256 == 0, LayerNorm or qk-norm blocks, chip-filling batches); anything else returns GENIE_E_UNSUPPORTED and the caller
 // runs the f32-qkv path below.
 // x / x16 / proj_done (bf16 only): when given and the geometry allows, the attention AND the out-projection + residual run as
 // kernels_fused.hip's spatial_attn_proj kernel (x, x16 updated, *proj_done = true: the caller skips its proj GEMM)

@@ -820,7 +820,8 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // is the (B, T, S, 3 d) f32 qkv of the earlier passes, slot t written by this pass's qkv Linear.  Whole head slices per request
 // (DH floats = LPF = DH / 4 lanes x 16 bytes): an instruction fetches FPI = 64 / LPF frames (lane = (frame, 4 features)), so K and
 // V are 16 / FPI loads each; scores are 4-feature partial dot products reduced over the LPF lanes of a frame, the softmax runs over
-// the register copies and the lane groups, P.V reduces over the groups.  head_dim 64 / 32, T <= 16, no qk-norm.
+// the register copies and the lane groups, P.V reduces over the groups.  head_dim 64 / 32, T <= 16; qk-norm (qn_g != NULL): the raw cached q / k
+// slices go through the per-head LayerNorm on read (head_layer_norm: a frame's head slice = the LPF lanes of its group).
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_temporal_fr_kernel(const float* __restrict__ cache, uint16_t* __restrict__ out16,
