@@ -142,3 +142,37 @@ def test_shard_range_and_means():
         assert max(sizes) - min(sizes) <= 1
     m = D.means_from_sums([20.0, 2.0, 3.0, 12.0, 30.0, 2.0])
     assert m == dict(loss=10.0, acc=0.25, frames=30, clips=2)
+
+
+def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/genie_hip.h must compile as plain C99 (no C++-isms, no torch / HIP types in the
+    signatures) and a C program must link against libgenie_hip.so and call it -- what a cgo / JNI / FFI binding of the reference's
+    maintainer would do.  No GPU: genie_version / genie_workspace_bytes / genie_check_config are host-only."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    lib = pkg("_lib").LIB_PATH
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "genie_hip.h"\n'
+                   "int main(void) {\n"
+                   "    genie_cfg c; memset(&c, 0, sizeof c);\n"
+                   "    c.num_layers = 2; c.num_heads = 8; c.head_dim = 64; c.d_model = 512; c.T = 16; c.S = 256; c.hidden = 2048;\n"
+                   "    c.factored_vocab = 512; c.num_factored = 2; c.image_vocab_size = 262144; c.attn_scale = 0.125f; c.readout_mult = 1.0f;\n"
+                   "    c.precision = GENIE_PREC_F16X3;\n"
+                   "    if (genie_version() != GENIE_ABI_VERSION) return 1;\n"
+                   "    if (genie_check_config(&c) != GENIE_OK) { puts(genie_last_error()); return 2; }\n"
+                   "    if (genie_workspace_bytes(&c, 4) == 0 || genie_generate_workspace_bytes(&c, 4, 8) < genie_workspace_bytes(&c, 4)) return 3;\n"
+                   "    c.head_dim = 48;\n"
+                   "    if (genie_check_config(&c) == GENIE_OK || strlen(genie_last_error()) == 0) return 4;   /* errors are codes + text, never aborts */\n"
+                   '    printf("%zu\\n", genie_prefix_cache_bytes(&c, 1));\n'
+                   "    return 0;\n}\n")
+    exe = tmp_path / "abi"
+    inc = os.path.join(REPO, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "abi.o")], check=True)
+    subprocess.run([gcc, str(tmp_path / "abi.o"), lib, f"-Wl,-rpath,{os.path.dirname(lib)}", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
