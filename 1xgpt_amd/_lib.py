@@ -179,6 +179,11 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python 1xgpt_amd/build.py` "
                 "(or __graft_entry__.build()).  There is no CPU fallback for the HIP path.")
+        # torch FIRST: it ships its own HIP runtime (torch/lib/libamdhip64.so, same soname as the /opt/rocm one this library links), and the
+        # process must end up with ONE runtime -- torch's, whose streams and device pointers the library is handed.  Loaded the other way
+        # round (this library before torch, e.g. __graft_entry__.build() followed by smoke() in one process) the library's launches fail with
+        # "no ROCm-capable device is detected" on the GPU box.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
